@@ -1,0 +1,245 @@
+"""fp32 PyTorch-CPU restatement of the StableTTS CFM decoder (test infrastructure).
+
+Every function cites the reference lines (relative to /root/reference) it follows.
+Pinned against the real reference modules by oracle/make_golden.py -> tests/golden.
+NOT part of the product: stabletts_amd/ never imports this.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- time embedding
+def sinusoidal_pos_emb(t, dim=256, scale=1000.0):
+    """models/estimator.py:41-49 (SinusoidalPosEmb.forward). t: () or (B,) -> (1|B, dim)."""
+    if t.ndim < 1:
+        t = t.unsqueeze(0)
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    emb = torch.exp(torch.arange(half).float() * -emb)
+    emb = scale * t.unsqueeze(1) * emb.unsqueeze(0)
+    return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
+def time_mlp(sd, emb):
+    """models/estimator.py:55-62 (Linear, SiLU, Linear)."""
+    h = F.linear(emb, sd["time_mlp.layer.0.weight"], sd["time_mlp.layer.0.bias"])
+    h = F.silu(h)
+    return F.linear(h, sd["time_mlp.layer.2.weight"], sd["time_mlp.layer.2.bias"])
+
+
+# ----------------------------------------------------------------------------- conditioning prenet
+def cond_proj(sd, mu, k=3):
+    """models/estimator.py:83-89,118: conv3, SiLU, conv3, SiLU, conv3 on the UNMASKED mu."""
+    p = k // 2
+    h = F.silu(F.conv1d(mu, sd["cond_proj.0.weight"], sd["cond_proj.0.bias"], padding=p))
+    h = F.silu(F.conv1d(h, sd["cond_proj.2.weight"], sd["cond_proj.2.bias"], padding=p))
+    return F.conv1d(h, sd["cond_proj.4.weight"], sd["cond_proj.4.bias"], padding=p)
+
+
+# ----------------------------------------------------------------------------- RoPE / attention / FFN
+def rope(x, d=32, base=10000):
+    """models/diffusion_transformer.py:145-198 (RotaryPositionalEmbeddings), x: (B,H,T,Dh).
+
+    Partial rotary on the first d features; pairs (j, j+d/2); theta_j = base^(-2j/d);
+    position = frame index.
+    """
+    T = x.shape[2]
+    theta = 1.0 / (base ** (torch.arange(0, d, 2).float() / d))
+    idx_theta = torch.einsum("n,d->nd", torch.arange(T).float(), theta)
+    idx_theta2 = torch.cat([idx_theta, idx_theta], dim=1)          # (T, d)
+    cos = idx_theta2.cos()[None, None]
+    sin = idx_theta2.sin()[None, None]
+    x_rope, x_pass = x[..., :d], x[..., d:]
+    d2 = d // 2
+    neg_half = torch.cat([-x_rope[..., d2:], x_rope[..., :d2]], dim=-1)
+    x_rope = x_rope * cos + neg_half * sin
+    return torch.cat((x_rope, x_pass), dim=-1)
+
+
+def attention(q, k, v, mask, n_heads=4):
+    """models/diffusion_transformer.py:67-79 + mask construction :107-108.
+
+    q,k,v: (B, C, T) conv outputs; mask (B,1,T) float 0/1. Returns (B, C, T) and the
+    post-RoPE per-head tensors. Explicit softmax(QK^T/sqrt(Dh) + M)V; a fully masked
+    query row gives a uniform softmax (no NaN), exactly like SDPA with the additive
+    -finfo.max mask.
+    """
+    B, C, T = q.shape
+    dh = C // n_heads
+    qh = q.view(B, n_heads, dh, T).transpose(2, 3)
+    kh = k.view(B, n_heads, dh, T).transpose(2, 3)
+    vh = v.view(B, n_heads, dh, T).transpose(2, 3)
+    qh = rope(qh, int(dh * 0.5))
+    kh = rope(kh, int(dh * 0.5))
+    am = mask.unsqueeze(1) * mask.unsqueeze(-1)                    # (B,1,T,T)
+    am = torch.zeros_like(am).masked_fill(am == 0, -torch.finfo(q.dtype).max)
+    s = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + am
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, vh)
+    out = o.transpose(2, 3).contiguous().view(B, C, T)
+    return out, (qh, kh, vh)
+
+
+def mha(sd, prefix, x, mask, n_heads=4, taps=None):
+    """models/diffusion_transformer.py:58-65 (MultiHeadAttention.forward)."""
+    q = F.conv1d(x, sd[prefix + "conv_q.weight"], sd[prefix + "conv_q.bias"])
+    k = F.conv1d(x, sd[prefix + "conv_k.weight"], sd[prefix + "conv_k.bias"])
+    v = F.conv1d(x, sd[prefix + "conv_v.weight"], sd[prefix + "conv_v.bias"])
+    a, (qh, kh, vh) = attention(q, k, v, mask, n_heads)
+    if taps is not None:
+        taps["q"], taps["k"], taps["v"], taps["attn"] = qh, kh, vh, a
+    return F.conv1d(a, sd[prefix + "conv_o.weight"], sd[prefix + "conv_o.bias"])
+
+
+def ffn(sd, prefix, x, mask, k=3, taps=None):
+    """models/diffusion_transformer.py:25-30 (FFN.forward); dropout is identity in eval."""
+    p = k // 2
+    h = F.conv1d(x * mask, sd[prefix + "conv_1.weight"], sd[prefix + "conv_1.bias"], padding=p)
+    h = F.silu(h)
+    if taps is not None:
+        taps["u"] = h * mask
+    h = F.conv1d(h * mask, sd[prefix + "conv_2.weight"], sd[prefix + "conv_2.bias"], padding=p)
+    return h * mask
+
+
+def layer_norm_c(x):
+    """nn.LayerNorm(C, elementwise_affine=False) on the transposed view
+    (models/diffusion_transformer.py:88,90,111-112). x: (B,C,T)."""
+    return F.layer_norm(x.transpose(1, 2), (x.shape[1],), eps=1e-5).transpose(1, 2)
+
+
+def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None):
+    """DitWrapper.forward (models/estimator.py:15-18) + DiTConVBlock.forward
+    (models/diffusion_transformer.py:98-117); arithmetic order of SURVEY.md 3.3."""
+    p = f"blocks.{i}."
+    film = F.conv1d(tau.unsqueeze(2), sd[p + "time_fusion.film.weight"], sd[p + "time_fusion.film.bias"])
+    gamma, beta = torch.chunk(film, 2, dim=1)
+    x = (gamma * x + beta) * mask
+    x = x * mask
+    hc = c
+    if (p + "block.adaLN_modulation.0.weight") in sd:
+        hc = F.linear(hc, sd[p + "block.adaLN_modulation.0.weight"], sd[p + "block.adaLN_modulation.0.bias"])
+    ada = F.linear(F.silu(hc), sd[p + "block.adaLN_modulation.2.weight"], sd[p + "block.adaLN_modulation.2.bias"])
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = ada.unsqueeze(2).chunk(6, dim=1)
+    if taps is not None:
+        taps["x1"] = x
+    h = layer_norm_c(x) * (1 + sc_a) + sh_a
+    if taps is not None:
+        taps["h1"] = h
+    x = x + g_a * mha(sd, p + "block.attn.", h, mask, n_heads, taps) * mask
+    if taps is not None:
+        taps["x2"] = x
+    h = layer_norm_c(x) * (1 + sc_m) + sh_m
+    if taps is not None:
+        taps["h2"] = h * mask
+    x = x + g_m * ffn(sd, p + "block.mlp.", h, mask, k, taps)
+    if taps is not None:
+        taps["x3"] = x
+    return x
+
+
+# ----------------------------------------------------------------------------- estimator
+def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None):
+    """models/estimator.py:103-138 (Decoder.forward): one vector-field evaluation.
+
+    t: () or (B,), x/mu: (B,M,T), mask: (B,1,T), c: (B,gin).  taps: optional dict that
+    receives named intermediates (used by the GPU per-stage parity tests).
+    """
+    n_layers = 0
+    while f"blocks.{n_layers}.time_fusion.film.weight" in sd:
+        n_layers += 1
+    n_lsc = n_layers // 2
+    C = sd["in_proj.weight"].shape[0]
+    tau = time_mlp(sd, sinusoidal_pos_emb(t, C))
+    cond = cond_proj(sd, mu, k)
+    x = F.conv1d(torch.cat((x, cond), dim=1), sd["in_proj.weight"], sd["in_proj.bias"])
+    if taps is not None:
+        taps["tau"], taps["cond"], taps["h0"] = tau, cond, x
+    skips = []
+    for i in range(n_layers):
+        if i < n_lsc:
+            skips.append(x)
+        else:
+            x = torch.cat((x, skips.pop()), dim=1)
+            x = F.conv1d(x, sd[f"lsc_layers.{i - n_lsc}.weight"], sd[f"lsc_layers.{i - n_lsc}.bias"],
+                         padding=k // 2)
+            if taps is not None:
+                taps[f"lsc{i - n_lsc}"] = x
+        bt = {} if taps is not None else None
+        x = dit_block(sd, i, x, c, tau, mask, n_heads, k, bt)
+        if taps is not None:
+            for kk, vv in bt.items():
+                taps[f"b{i}.{kk}"] = vv
+    out = F.conv1d(x * mask, sd["final_proj.weight"], sd["final_proj.bias"])
+    return out * mask
+
+
+# ----------------------------------------------------------------------------- CFM wrapper
+def cfg_wrapper(sd, t, x, mask, mu, c, fake_speaker, fake_content, cfg_strength, **kw):
+    """models/flow_matching.py:58-67: two estimator calls, u + s*(c - u)."""
+    fs = fake_speaker.repeat(x.size(0), 1)
+    fc = fake_content.repeat(x.size(0), 1, x.size(-1))
+    cond_out = decoder_forward(sd, t, x, mask, mu, c, **kw)
+    uncond_out = decoder_forward(sd, t, x, mask, fc, fs, **kw)
+    return uncond_out + cfg_strength * (cond_out - uncond_out)
+
+
+def linspace_f32(n_timesteps):
+    """t_span of models/flow_matching.py:46."""
+    return torch.linspace(0, 1, n_timesteps + 1)
+
+
+def odeint_fixed(f, y0, t_span, method="euler"):
+    """torchdiffeq 0.2.x fixed-grid solvers restated (call site models/flow_matching.py:54).
+
+    With options=None the integration grid IS t_span.  euler / midpoint / rk4 (torchdiffeq's
+    rk4 is the 3/8-rule "rk4_alt_step_func").  f receives t as a 0-dim tensor.  Returns the
+    final state (the reference takes trajectory[-1], :55).  PARITY UNPINNED against
+    torchdiffeq itself (absent offline); see oracle/__init__.py.
+    """
+    y = y0
+    for i in range(len(t_span) - 1):
+        t0, t1 = t_span[i], t_span[i + 1]
+        dt = t1 - t0
+        if method == "euler":
+            y = y + dt * f(t0, y)
+        elif method == "midpoint":
+            half = 0.5 * dt
+            f0 = f(t0, y)
+            y = y + dt * f(t0 + half, y + f0 * half)
+        elif method == "rk4":
+            k1 = f(t0, y)
+            k2 = f(t0 + dt / 3, y + dt * k1 / 3)
+            k3 = f(t0 + dt * 2 / 3, y + dt * (k2 - k1 / 3))
+            k4 = f(t1, y + dt * (k1 - k2 + k3))
+            y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        else:
+            raise ValueError(f"oracle: unsupported fixed-grid solver {method!r}")
+    return y
+
+
+@torch.inference_mode()
+def cfm_forward(sd, mu, mask, n_timesteps, z, c, solver="euler", cfg_kwargs=None, **kw):
+    """models/flow_matching.py:25-55 (CFMDecoder.forward) with the noise z passed explicitly
+    (z must already include the temperature factor of :45)."""
+    t_span = linspace_f32(n_timesteps)
+    if cfg_kwargs is None:
+        f = lambda t, x: decoder_forward(sd, t, x, mask, mu, c, **kw)
+    else:
+        f = lambda t, x: cfg_wrapper(sd, t, x, mask, mu, c, cfg_kwargs["fake_speaker"],
+                                     cfg_kwargs["fake_content"], cfg_kwargs["cfg_strength"], **kw)
+    return odeint_fixed(f, z, t_span, solver)
+
+
+def compute_loss(sd, x1, mask, mu, c, t_rand, z, sigma_min=1e-4, **kw):
+    """models/flow_matching.py:69-100 with the random draws (t_rand = torch.rand([b,1,1]),
+    z = randn_like(x1)) passed explicitly.  NB the estimator output is masked but u is not
+    (reference quirk kept)."""
+    t = 1 - torch.cos(t_rand * 0.5 * torch.pi)
+    y = (1 - (1 - sigma_min) * t) * z + t * x1
+    u = x1 - (1 - sigma_min) * z
+    pred = decoder_forward(sd, t.squeeze(), y, mask, mu, c, **kw)
+    loss = F.mse_loss(pred, u, reduction="sum") / (torch.sum(mask) * u.size(1))
+    return loss, y
