@@ -1,0 +1,127 @@
+/*
+ * stabletts_hip.h -- C ABI of libstabletts_hip.so: the MI355X (gfx950) native
+ * conditional-flow-matching mel decoder of StableTTS.
+ *
+ * The reference (KdaiP/StableTTS) has no FFI layer; its boundary for this path is the
+ * Python class models/flow_matching.py:11 `CFMDecoder`.  Each entry point below names the
+ * reference interface it replaces.  Conventions:
+ *   - every function returns 0 on success, a negative ST_ERR_* code on failure, and never
+ *     throws across the ABI; st_last_error() returns the message of the last failure.
+ *   - tensor pointers are BORROWED DEVICE pointers (fp32, contiguous, the reference's own
+ *     layouts: (B, C, T) row-major), owned by the caller (torch).  The engine owns its packed
+ *     16-bit weight copies and its workspace.
+ *   - work is enqueued on the caller's HIP stream (`stream` = hipStream_t, e.g.
+ *     torch.cuda.current_stream().cuda_stream) with no implicit device synchronisation.
+ *   - one engine per device per process; an engine is not thread-safe (the reference is
+ *     single-threaded per process: train.py:101-102, webui.py:128).
+ */
+#ifndef STABLETTS_HIP_H
+#define STABLETTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_ABI_VERSION 1
+
+enum {
+    ST_OK = 0,
+    ST_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    ST_ERR_HIP = -2,          /* a HIP runtime call failed */
+    ST_ERR_STATE = -3,        /* e.g. solve before all parameters were loaded */
+    ST_ERR_UNSUPPORTED = -4   /* valid in the reference, not implemented natively (caller may fall back) */
+};
+
+/* MFMA operand type of the dense contractions (accumulation, residual stream, LayerNorm,
+ * softmax statistics and the ODE state are always fp32). */
+enum { ST_OPERAND_BF16 = 0, ST_OPERAND_F16 = 1 };
+
+/* Fixed-grid solvers of torchdiffeq.odeint as used at models/flow_matching.py:54. */
+enum { ST_SOLVER_EULER = 0, ST_SOLVER_MIDPOINT = 1, ST_SOLVER_RK4 = 2 };
+
+/* Constructor arguments of reference CFMDecoder.__init__ (models/flow_matching.py:12). */
+typedef struct st_config {
+    int32_t noise_channels;   /* = cond_channels = out_channels = n_mels (config.py:12: 128) */
+    int32_t hidden_channels;  /* 256 (config.py:23) */
+    int32_t filter_channels;  /* 1024 */
+    int32_t n_heads;          /* 4 */
+    int32_t n_layers;         /* 6 (n_dec_layers) */
+    int32_t kernel_size;      /* 3 */
+    int32_t gin_channels;     /* 256 */
+    int32_t operand_dtype;    /* ST_OPERAND_* */
+} st_config;
+
+typedef struct st_engine st_engine;
+
+/* ABI version of the loaded library (compare with ST_ABI_VERSION). */
+int st_abi_version(void);
+
+/* Replaces CFMDecoder.__init__ / Decoder.__init__ (models/flow_matching.py:12-22,
+ * models/estimator.py:66-96): validates the architecture (same assertions: n_layers even,
+ * hidden % n_heads == 0, even time-embedding dim) and creates an engine on HIP device `device`. */
+int st_create(const st_config* cfg, int device, st_engine** out);
+
+void st_destroy(st_engine* e);
+
+/* Message of the last failure on this engine (e == NULL: last st_create failure). */
+const char* st_last_error(const st_engine* e);
+
+/* Replaces nn.Module.load_state_dict for `decoder.estimator.*` (api.py:49, utils/load.py:31-41):
+ * uploads one tensor by its reference state_dict name, fp32,
+ * reference shapes (Conv1d weights (Cout, Cin, K)).  `data` may be a host or a device pointer. */
+int st_load_param(st_engine* e, const char* name, const float* data, const int64_t* shape, int ndim);
+
+/* Number of state_dict tensors the configured architecture expects (116 for the 31M model). */
+int st_num_params(const st_engine* e);
+
+/* Packs the uploaded fp32 parameters into the engine's 16-bit MFMA operand layouts.  Must be
+ * called after loading (and again after any parameter update). */
+int st_finalize(st_engine* e);
+
+/* Replaces Decoder.forward(t, x, mask, mu, c) (models/estimator.py:103-138): ONE vector-field
+ * evaluation.  t: device fp32, t_len = 1 (inference, 0-dim t) or B (training, flow_matching.py:99).
+ * x, mu, out: (B, n_feats, T); mask: (B, 1, T) float 0/1; c: (B, gin). */
+int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x, const float* mu,
+                         const float* mask, const float* c, float* out, int B, int T, void* stream);
+
+/* Replaces CFMDecoder.forward (models/flow_matching.py:25-55) + cfg_wrapper (:58-67) +
+ * torchdiffeq.odeint fixed-grid stepping (:54): the whole ODE solve.
+ *   z            : initial noise (B, n_feats, T), ALREADY multiplied by the temperature (:45).
+ *   n_steps      : n_timesteps; the grid is linspace(0, 1, n_steps + 1) (:46).
+ *   solver       : ST_SOLVER_*.
+ *   use_cfg != 0 : classifier-free guidance with fake_speaker (gin,), fake_content (n_feats,)
+ *                  and cfg_strength (models/model.py:43-44,102); cond and uncond branches run as
+ *                  one 2B batch.
+ *   out          : trajectory[-1], (B, n_feats, T). */
+int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* z, const float* c,
+                 int n_steps, int solver, int use_cfg, float cfg_strength,
+                 const float* fake_speaker, const float* fake_content,
+                 float* out, int B, int T, void* stream);
+
+/* ---- measurement / test hooks (no reference analogue) ------------------------------------- */
+
+/* Copies a named internal tensor of the LAST st_estimator_forward call to `host_out` as fp32 in
+ * the engine's time-major layout; returns the element count, or <0.  If host_out is
+ * NULL only the count is returned.  Synchronises the device.  Names: "cond", "h0", "b<i>.x1",
+ * "b<i>.h1", "b<i>.q", "b<i>.k", "b<i>.vt", "b<i>.attn", "b<i>.x2", "b<i>.h2", "b<i>.u",
+ * "b<i>.x3", "lsc<j>", "v".  Capture must be enabled first (it snapshots after every stage). */
+int st_debug_capture(st_engine* e, int enable);
+int64_t st_debug_fetch(st_engine* e, const char* name, float* host_out, int64_t capacity);
+
+/* Per-kernel-class timing with HIP events recorded on the launch stream.  Classes are listed by
+ * st_profile_class_name(i), i in [0, st_profile_num_classes()).  st_profile_read synchronises,
+ * returns launches and total milliseconds per class since the last reset, and resets. */
+int st_profile_enable(st_engine* e, int enable);
+int st_profile_num_classes(void);
+const char* st_profile_class_name(int cls);
+int st_profile_read(st_engine* e, int cls, int64_t* launches, double* total_ms, double* flops_per_launch);
+
+/* Bytes of device memory currently held by the engine (weights + workspace). */
+int64_t st_device_bytes(const st_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STABLETTS_HIP_H */

@@ -1,0 +1,188 @@
+"""ctypes binding of libstabletts_hip.so (C ABI: include/stabletts_hip.h).
+
+The library is built in-tree by ``python -m stabletts_amd.build`` (hipcc, gfx950).  There is
+NO fallback: if the shared library is missing or fails to load, importing the native path raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstabletts_hip.so")
+
+ST_OK = 0
+ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_STATE, ST_ERR_UNSUPPORTED = -1, -2, -3, -4
+ST_OPERAND_BF16, ST_OPERAND_F16 = 0, 1
+ST_SOLVER_EULER, ST_SOLVER_MIDPOINT, ST_SOLVER_RK4 = 0, 1, 2
+OPERAND_DTYPES = {"bf16": ST_OPERAND_BF16, "f16": ST_OPERAND_F16, "fp16": ST_OPERAND_F16}
+SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_SOLVER_RK4}
+
+# every symbol include/stabletts_hip.h declares
+EXPORTS = [
+    "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
+    "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_debug_capture", "st_debug_fetch",
+    "st_profile_enable", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
+    "st_device_bytes",
+]
+
+
+class StConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "noise_channels", "hidden_channels", "filter_channels", "n_heads", "n_layers",
+        "kernel_size", "gin_channels", "operand_dtype")]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libstabletts_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once).  torch is imported first so that the HIP runtime the
+    library binds to (SONAME libamdhip64.so.7) is the one torch already loaded: a process must
+    not hold two HIP runtimes, streams and device pointers are shared across the boundary."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so when the wheel bundles it)
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -m stabletts_amd.build` "
+                          "(the native HIP path has no fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    c_void_p, c_int, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.st_abi_version.restype = c_int
+    lib.st_create.argtypes = [ctypes.POINTER(StConfig), c_int, ctypes.POINTER(c_void_p)]
+    lib.st_create.restype = c_int
+    lib.st_destroy.argtypes = [c_void_p]
+    lib.st_destroy.restype = None
+    lib.st_last_error.argtypes = [c_void_p]
+    lib.st_last_error.restype = ctypes.c_char_p
+    lib.st_load_param.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(ctypes.c_int64), c_int]
+    lib.st_load_param.restype = c_int
+    lib.st_num_params.argtypes = [c_void_p]
+    lib.st_num_params.restype = c_int
+    lib.st_finalize.argtypes = [c_void_p]
+    lib.st_finalize.restype = c_int
+    lib.st_estimator_forward.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_int, c_void_p]
+    lib.st_estimator_forward.restype = c_int
+    lib.st_cfm_solve.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.st_cfm_solve.restype = c_int
+    lib.st_debug_capture.argtypes = [c_void_p, c_int]
+    lib.st_debug_capture.restype = c_int
+    lib.st_debug_fetch.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64]
+    lib.st_debug_fetch.restype = ctypes.c_int64
+    lib.st_profile_enable.argtypes = [c_void_p, c_int]
+    lib.st_profile_enable.restype = c_int
+    lib.st_profile_num_classes.restype = c_int
+    lib.st_profile_class_name.argtypes = [c_int]
+    lib.st_profile_class_name.restype = ctypes.c_char_p
+    lib.st_profile_read.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    lib.st_profile_read.restype = c_int
+    lib.st_device_bytes.argtypes = [c_void_p]
+    lib.st_device_bytes.restype = ctypes.c_int64
+    if lib.st_abi_version() != 1:
+        raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+class Engine:
+    """Thin owner of one ``st_engine`` handle."""
+
+    def __init__(self, noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
+                 gin_channels, operand_dtype="bf16", device=0):
+        self.lib = load()
+        if operand_dtype not in OPERAND_DTYPES:
+            raise ValueError(f"operand_dtype must be one of {sorted(OPERAND_DTYPES)}")
+        self.operand_dtype = operand_dtype
+        cfg = StConfig(noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
+                       gin_channels, OPERAND_DTYPES[operand_dtype])
+        h = ctypes.c_void_p()
+        rc = self.lib.st_create(ctypes.byref(cfg), int(device), ctypes.byref(h))
+        if rc != ST_OK:
+            raise NativeError(rc, self.lib.st_last_error(None).decode())
+        self.handle = h
+        self.device = int(device)
+
+    def _check(self, rc):
+        if rc != ST_OK:
+            raise NativeError(rc, self.lib.st_last_error(self.handle).decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.st_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_params(self):
+        return self.lib.st_num_params(self.handle)
+
+    def load_state_dict(self, sd):
+        """sd: name -> torch.Tensor (fp32, any device), reference ``decoder.estimator.*`` names."""
+        for name, t in sd.items():
+            t = t.detach().float().contiguous()
+            shape = (ctypes.c_int64 * t.dim())(*t.shape)
+            self._check(self.lib.st_load_param(self.handle, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()))
+        self._check(self.lib.st_finalize(self.handle))
+
+    def estimator_forward(self, t, x, mu, mask, c, out, stream):
+        B, _, T = x.shape
+        self._check(self.lib.st_estimator_forward(self.handle, t.data_ptr(), int(t.numel()), x.data_ptr(), mu.data_ptr(),
+                                                  mask.data_ptr(), c.data_ptr(), out.data_ptr(), B, T,
+                                                  ctypes.c_void_p(stream)))
+
+    def cfm_solve(self, mu, mask, z, c, n_steps, solver, use_cfg, cfg_strength, fake_speaker, fake_content, out, stream):
+        B, _, T = mu.shape
+        self._check(self.lib.st_cfm_solve(self.handle, mu.data_ptr(), mask.data_ptr(), z.data_ptr(), c.data_ptr(),
+                                          int(n_steps), int(solver), int(bool(use_cfg)), float(cfg_strength),
+                                          fake_speaker.data_ptr() if fake_speaker is not None else None,
+                                          fake_content.data_ptr() if fake_content is not None else None,
+                                          out.data_ptr(), B, T, ctypes.c_void_p(stream)))
+
+    # ---- test / measurement hooks
+    def debug_capture(self, on):
+        self._check(self.lib.st_debug_capture(self.handle, int(on)))
+
+    def debug_fetch(self, name):
+        import numpy as np
+        n = self.lib.st_debug_fetch(self.handle, name.encode(), None, 0)
+        if n < 0:
+            raise NativeError(int(n), self.lib.st_last_error(self.handle).decode())
+        buf = np.empty(int(n), dtype=np.float32)
+        r = self.lib.st_debug_fetch(self.handle, name.encode(), buf.ctypes.data_as(ctypes.c_void_p), int(n))
+        if r < 0:
+            raise NativeError(int(r), self.lib.st_last_error(self.handle).decode())
+        return buf
+
+    def profile_enable(self, on):
+        self._check(self.lib.st_profile_enable(self.handle, int(on)))
+
+    def profile_read(self):
+        """-> {class_name: dict(launches, total_ms, flops_per_launch)} since the last read."""
+        out = {}
+        for i in range(self.lib.st_profile_num_classes()):
+            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            self._check(self.lib.st_profile_read(self.handle, i, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)))
+            out[self.lib.st_profile_class_name(i).decode()] = dict(
+                launches=n.value, total_ms=ms.value, flops_per_launch=fl.value)
+        return out
+
+    def device_bytes(self):
+        return self.lib.st_device_bytes(self.handle)

@@ -1,0 +1,791 @@
+// Host side of libstabletts_hip.so: parameter store, weight packing, workspace arena, the
+// estimator launch sequence and the fixed-grid ODE loop behind the C ABI of
+// include/stabletts_hip.h.  Reference path: models/flow_matching.py:25-67 (CFMDecoder.forward,
+// cfg_wrapper), models/estimator.py:103-138 (Decoder.forward), torchdiffeq fixed-grid solvers.
+#include "../../include/stabletts_hip.h"
+#include "launch.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace st;
+
+namespace {
+
+std::string g_create_error;
+
+enum ProfClass {
+    PC_PREP = 0, PC_PRENET, PC_INPROJ, PC_FILM_LN1, PC_QKV, PC_ATTN, PC_OPROJ, PC_LN2, PC_FFN1, PC_FFN2,
+    PC_LSC, PC_FINAL, PC_ODE, PC_COUNT
+};
+const char* kProfNames[PC_COUNT] = {
+    "prep", "prenet_conv", "in_proj", "film_ln1", "qkv_rope", "attention", "out_proj", "ln2",
+    "ffn_conv1", "ffn_conv2", "lsc_conv", "final_proj", "ode_update"};
+
+struct Param {
+    std::vector<int64_t> shape;
+    float* dev = nullptr;
+    bool loaded = false;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Conv {            // packed 16-bit weights [cout][taps][cin] + fp32 bias
+    void* w = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, taps = 0;
+};
+
+struct Captured { void* dev = nullptr; int64_t n = 0; bool is16 = false; };
+
+struct ProfEvent { int cls; hipEvent_t a, b; double flops; };
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct st_engine {
+    st_config cfg{};
+    int device = 0;
+    int dt = DT_BF16;
+    int M = 0, Mp = 0, C = 0, F = 0, H = 0, L = 0, K = 0, G = 0;
+    std::map<std::string, Param> params;
+    bool finalized = false;
+    std::string err;
+    int64_t weight_bytes = 0;
+
+    // packed weights
+    std::vector<Conv> pre;              // 3 prenet convs
+    Conv inx, inc, fin;                 // in_proj x-part / cond-part, final_proj
+    std::vector<Conv> lsc, qkv, oproj, ffn1, ffn2;
+    std::vector<void*> owned;           // device allocations to free
+
+    float* rope_cos = nullptr; float* rope_sin = nullptr; int rope_T = 0;
+
+    // workspace arena
+    char* ws = nullptr; size_t ws_cap = 0;
+
+    // debug / profile
+    bool capture = false;
+    std::map<std::string, Captured> caps;
+    bool prof = false;
+    std::vector<ProfEvent> evs;
+    std::vector<hipEvent_t> ev_pool;
+    int64_t prof_launches[PC_COUNT] = {0};
+    double prof_ms[PC_COUNT] = {0};
+    double prof_flops[PC_COUNT] = {0};
+
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+};
+
+namespace {
+
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t _err = (call);                                                               \
+        if (_err != hipSuccess)                                                                 \
+            return (e)->fail(ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_err));  \
+    } while (0)
+
+int dev_alloc(st_engine* e, void** p, size_t bytes) {
+    HIPCHK(e, hipMalloc(p, bytes ? bytes : 16));
+    e->owned.push_back(*p);
+    e->weight_bytes += (int64_t)bytes;
+    return ST_OK;
+}
+
+void expect(st_engine* e, const std::string& name, std::vector<int64_t> shape) {
+    Param p;
+    p.shape = std::move(shape);
+    e->params[name] = p;
+}
+
+void build_param_table(st_engine* e) {
+    const int C = e->C, F = e->F, M = e->M, K = e->K, G = e->G;
+    expect(e, "time_mlp.layer.0.weight", {F, C}); expect(e, "time_mlp.layer.0.bias", {F});
+    expect(e, "time_mlp.layer.2.weight", {C, F}); expect(e, "time_mlp.layer.2.bias", {C});
+    expect(e, "in_proj.weight", {C, C + M, 1}); expect(e, "in_proj.bias", {C});
+    for (int i = 0; i < e->L; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        expect(e, p + "time_fusion.film.weight", {2 * C, C, 1}); expect(e, p + "time_fusion.film.bias", {2 * C});
+        for (const char* nm : {"q", "k", "v", "o"}) {
+            expect(e, p + "block.attn.conv_" + nm + ".weight", {C, C, 1});
+            expect(e, p + "block.attn.conv_" + nm + ".bias", {C});
+        }
+        expect(e, p + "block.mlp.conv_1.weight", {F, C, K}); expect(e, p + "block.mlp.conv_1.bias", {F});
+        expect(e, p + "block.mlp.conv_2.weight", {C, F, K}); expect(e, p + "block.mlp.conv_2.bias", {C});
+        if (G != C) {
+            expect(e, p + "block.adaLN_modulation.0.weight", {C, G});
+            expect(e, p + "block.adaLN_modulation.0.bias", {C});
+        }
+        expect(e, p + "block.adaLN_modulation.2.weight", {6 * C, C});
+        expect(e, p + "block.adaLN_modulation.2.bias", {6 * C});
+    }
+    expect(e, "final_proj.weight", {M, C, 1}); expect(e, "final_proj.bias", {M});
+    expect(e, "cond_proj.0.weight", {F, M, K}); expect(e, "cond_proj.0.bias", {F});
+    expect(e, "cond_proj.2.weight", {F, F, K}); expect(e, "cond_proj.2.bias", {F});
+    expect(e, "cond_proj.4.weight", {C, F, K}); expect(e, "cond_proj.4.bias", {C});
+    for (int i = 0; i < e->L / 2; ++i) {
+        expect(e, "lsc_layers." + std::to_string(i) + ".weight", {C, 2 * C, K});
+        expect(e, "lsc_layers." + std::to_string(i) + ".bias", {C});
+    }
+}
+
+const float* P(st_engine* e, const std::string& name) { return e->params.at(name).dev; }
+
+hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
+    return e->dt == DT_BF16 ? launch_conv_gemm_bf16(taps, epi, a, s) : launch_conv_gemm_f16(taps, epi, a, s);
+}
+
+// ---- profiling helpers -----------------------------------------------------------------------
+struct ProfScope {
+    st_engine* e; hipStream_t s; int idx = -1;
+    ProfScope(st_engine* e_, hipStream_t s_, int cls, double flops) : e(e_), s(s_) {
+        if (!e->prof) return;
+        ProfEvent ev; ev.cls = cls; ev.flops = flops;
+        for (hipEvent_t* h : {&ev.a, &ev.b}) {
+            if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
+            else if (hipEventCreate(h) != hipSuccess) return;
+        }
+        hipEventRecord(ev.a, s);
+        e->evs.push_back(ev);
+        idx = (int)e->evs.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(e->evs[idx].b, s); }
+};
+
+void prof_collect(st_engine* e) {
+    for (auto& ev : e->evs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            e->prof_launches[ev.cls] += 1;
+            e->prof_ms[ev.cls] += ms;
+            e->prof_flops[ev.cls] = ev.flops;
+        }
+        e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
+    }
+    e->evs.clear();
+}
+
+// ---- debug capture ---------------------------------------------------------------------------
+void capture(st_engine* e, const std::string& name, const void* dev, int64_t n, bool is16, hipStream_t s) {
+    if (!e->capture) return;
+    Captured& c = e->caps[name];
+    const size_t bytes = (size_t)n * (is16 ? 2 : 4);
+    if (c.dev) { hipFree(c.dev); c.dev = nullptr; }
+    if (hipMalloc(&c.dev, bytes) != hipSuccess) { c.dev = nullptr; return; }
+    c.n = n; c.is16 = is16;
+    hipMemcpyAsync(c.dev, dev, bytes, hipMemcpyDeviceToDevice, s);
+}
+
+// ---- workspace plan --------------------------------------------------------------------------
+struct Plan {
+    int B, T, Tp, N, Pn, n_t;
+    bool cfg;
+    // 16-bit
+    void *mu16, *pre1, *pre2, *cond16, *x16, *h16, *q16, *k16, *vt16, *ao16, *u16, *cur16;
+    void* skip16[8];
+    // fp32
+    float *cpart, *X, *v32, *xstate, *kbuf[4], *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
+    int *n_full, *kv_end;
+};
+
+int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
+    const int C = e->C, F = e->F, Mp = e->Mp, L = e->L;
+    p->B = B; p->T = T; p->cfg = cfg; p->n_t = n_t;
+    p->Tp = (T + 63) / 64 * 64;
+    p->N = cfg ? 2 * B : B;
+    p->Pn = cfg ? B + 1 : B;
+    const size_t N = p->N, Pn = p->Pn, TT = T;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    struct Slot { void** dst; size_t off; };
+    std::vector<Slot> slots;
+    auto want = [&](void** dst, size_t bytes) { slots.push_back({dst, carve(bytes)}); };
+    want(&p->mu16, Pn * TT * Mp * 2);
+    want(&p->pre1, Pn * TT * F * 2);
+    want(&p->pre2, Pn * TT * F * 2);
+    want(&p->cond16, Pn * TT * C * 2);
+    want((void**)&p->cpart, Pn * TT * C * 4);
+    want(&p->x16, (size_t)B * TT * Mp * 2);
+    want((void**)&p->xstate, (size_t)B * TT * Mp * 4);
+    for (int i = 0; i < 4; ++i) want((void**)&p->kbuf[i], (size_t)B * TT * Mp * 4);
+    want((void**)&p->X, N * TT * C * 4);
+    want(&p->h16, N * TT * C * 2);
+    want(&p->q16, N * TT * C * 2);
+    want(&p->k16, N * TT * C * 2);
+    want(&p->vt16, N * (size_t)C * p->Tp * 2);
+    want(&p->ao16, N * TT * C * 2);
+    want(&p->u16, N * TT * F * 2);
+    want(&p->cur16, N * TT * C * 2);
+    for (int i = 0; i < L / 2; ++i) want(&p->skip16[i], N * TT * C * 2);
+    want((void**)&p->v32, N * TT * Mp * 4);
+    want((void**)&p->tvals, (size_t)n_t * 4);
+    want((void**)&p->emb, (size_t)n_t * C * 4);
+    want((void**)&p->th, (size_t)n_t * F * 4);
+    want((void**)&p->tau, (size_t)n_t * C * 4);
+    want((void**)&p->film, (size_t)L * n_t * 2 * C * 4);
+    want((void**)&p->cvec, N * (size_t)e->G * 4);
+    want((void**)&p->ada_tmp, N * (size_t)C * 4);
+    want((void**)&p->ada, (size_t)L * N * 6 * C * 4);
+    want((void**)&p->n_full, (size_t)B * 4);
+    want((void**)&p->kv_end, (size_t)B * 4);
+    if (off > e->ws_cap) {
+        if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
+        HIPCHK(e, hipMalloc((void**)&e->ws, off));
+        e->ws_cap = off;
+    }
+    for (auto& s : slots) *s.dst = e->ws + s.off;
+    return ST_OK;
+}
+
+int ensure_rope(st_engine* e, int T, hipStream_t s) {
+    if (T <= e->rope_T) return ST_OK;
+    // cos/sin cache of RotaryPositionalEmbeddings._build_cache (diffusion_transformer.py:145-171),
+    // d = head_dim/2 = 32 rotary features -> 16 angles theta_j = 10000^(-2j/32), fp32 arithmetic.
+    const int newT = (T + 255) / 256 * 256;
+    std::vector<float> hc((size_t)newT * 16), hs((size_t)newT * 16);
+    for (int j = 0; j < 16; ++j) {
+        const float theta = 1.0f / powf(10000.0f, (float)(2 * j) / 32.0f);
+        for (int t = 0; t < newT; ++t) {
+            const float ang = (float)t * theta;
+            hc[(size_t)t * 16 + j] = cosf(ang);
+            hs[(size_t)t * 16 + j] = sinf(ang);
+        }
+    }
+    if (e->rope_cos) { HIPCHK(e, hipDeviceSynchronize()); hipFree(e->rope_cos); hipFree(e->rope_sin); }
+    HIPCHK(e, hipMalloc((void**)&e->rope_cos, hc.size() * 4));
+    HIPCHK(e, hipMalloc((void**)&e->rope_sin, hs.size() * 4));
+    HIPCHK(e, hipMemcpy(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    e->rope_T = newT;
+    (void)s;
+    return ST_OK;
+}
+
+ConvGemmArgs base_args(const Plan& p, const Conv& cv, int n_items) {
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = cv.w; a.bias = cv.bias; a.cout = cv.cout; a.T = p.T; a.n_items = n_items;
+    a.tiles_f = (p.T + kGemmFramesPerTile - 1) / kGemmFramesPerTile;
+    a.tiles_c = cv.cout / kGemmChannelsPerTile;
+    a.a0_mod = n_items; a.a1_mod = n_items; a.mask_mod = p.B;
+    return a;
+}
+
+inline double conv_flops(const Plan& p, const Conv& cv, int n_items) {
+    return 2.0 * (double)n_items * p.T * cv.cout * cv.cin * cv.taps;
+}
+
+// cond prenet (estimator.py:83-89,118) + the loop-invariant cond half of in_proj (:120-121)
+int run_prenet(st_engine* e, const Plan& p, hipStream_t s) {
+    {
+        ConvGemmArgs a = base_args(p, e->pre[0], p.Pn);
+        a.a0 = p.mu16; a.c0 = e->Mp; a.flags = GF_SILU; a.out16 = p.pre1;
+        ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[0], p.Pn));
+        HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
+    }
+    {
+        ConvGemmArgs a = base_args(p, e->pre[1], p.Pn);
+        a.a0 = p.pre1; a.c0 = e->F; a.flags = GF_SILU; a.out16 = p.pre2;
+        ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[1], p.Pn));
+        HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
+    }
+    {
+        ConvGemmArgs a = base_args(p, e->pre[2], p.Pn);
+        a.a0 = p.pre2; a.c0 = e->F; a.out16 = p.cond16;
+        ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[2], p.Pn));
+        HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+    }
+    capture(e, "cond", p.cond16, (int64_t)p.Pn * p.T * e->C, true, s);
+    {
+        ConvGemmArgs a = base_args(p, e->inc, p.Pn);
+        a.a0 = p.cond16; a.c0 = e->C; a.out32 = p.cpart;
+        ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inc, p.Pn));
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    return ST_OK;
+}
+
+// adaLN-Zero parameters from the speaker vectors (diffusion_transformer.py:92-96,110): loop invariant
+int run_adaln(st_engine* e, const Plan& p, hipStream_t s) {
+    const int C = e->C;
+    ProfScope ps(e, s, PC_PREP, 0);
+    for (int i = 0; i < e->L; ++i) {
+        const std::string pre = "blocks." + std::to_string(i) + ".block.adaLN_modulation.";
+        const float* in = p.cvec; int k = e->G;
+        if (e->G != C) {
+            HIPCHK(e, launch_linear(p.cvec, p.N, e->G, P(e, pre + "0.weight"), P(e, pre + "0.bias"), C, p.ada_tmp, 0, 0, s));
+            in = p.ada_tmp; k = C;
+        }
+        HIPCHK(e, launch_linear(in, p.N, k, P(e, pre + "2.weight"), P(e, pre + "2.bias"), 6 * C,
+                                p.ada + (size_t)i * p.N * 6 * C, 1, 0, s));
+    }
+    return ST_OK;
+}
+
+// time embedding -> MLP -> FiLM (gamma, beta) for every evaluation time (estimator.py:117,31-33)
+int run_time_tables(st_engine* e, const Plan& p, hipStream_t s) {
+    const int C = e->C, F = e->F;
+    ProfScope ps(e, s, PC_PREP, 0);
+    HIPCHK(e, launch_time_embed(p.tvals, p.n_t, C, p.emb, s));
+    HIPCHK(e, launch_linear(p.emb, p.n_t, C, P(e, "time_mlp.layer.0.weight"), P(e, "time_mlp.layer.0.bias"), F, p.th, 0, 1, s));
+    HIPCHK(e, launch_linear(p.th, p.n_t, F, P(e, "time_mlp.layer.2.weight"), P(e, "time_mlp.layer.2.bias"), C, p.tau, 0, 0, s));
+    for (int i = 0; i < e->L; ++i) {
+        const std::string pre = "blocks." + std::to_string(i) + ".time_fusion.film.";
+        HIPCHK(e, launch_linear(p.tau, p.n_t, C, P(e, pre + "weight"), P(e, pre + "bias"), 2 * C,
+                                p.film + (size_t)i * p.n_t * 2 * C, 0, 0, s));
+    }
+    return ST_OK;
+}
+
+// One vector-field evaluation over N items given x16 (B items), cpart, ada, film.  Output p.v32.
+// ev: index into the time tables (scalar t shared by all items) or -1 for per-item t (n_t == B).
+int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStream_t s) {
+    const int C = e->C, F = e->F, L = e->L, N = p.N, T = p.T;
+    const int64_t rowsC = (int64_t)N * T * C;
+    const bool cap = e->capture;
+    {   // in_proj: X = Wx.x + (Wc.cond + b); also the first long-skip (estimator.py:120-121,129)
+        ConvGemmArgs a = base_args(p, e->inx, N);
+        a.a0 = p.x16; a.c0 = e->Mp; a.a0_mod = p.B; a.bias = nullptr;
+        a.add32 = p.cpart; a.add_clamp = p.B;
+        a.out32 = p.X; a.out16 = p.skip16[0];
+        ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inx, N));
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    if (cap) capture(e, "h0", p.X, rowsC, false, s);
+    for (int i = 0; i < L; ++i) {
+        const std::string bn = "b" + std::to_string(i) + ".";
+        const float* ada_i = p.ada + (size_t)i * N * 6 * C;
+        if (i >= L / 2) {   // U-Net long skip merge (estimator.py:131-132)
+            const int j = i - L / 2;
+            ConvGemmArgs a = base_args(p, e->lsc[j], N);
+            a.a0 = p.cur16; a.c0 = C; a.a1 = p.skip16[L - 1 - i]; a.c1 = C;
+            a.out32 = p.X;
+            ProfScope ps(e, s, PC_LSC, conv_flops(p, e->lsc[j], N));
+            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+            if (cap) capture(e, "lsc" + std::to_string(j), p.X, rowsC, false, s);
+        }
+        {   // FiLM, mask, LN1, modulate
+            FilmLnArgs a; memset(&a, 0, sizeof(a));
+            a.X = p.X; a.h16 = p.h16;
+            const float* fb = p.film + (size_t)i * p.n_t * 2 * C;
+            if (ev >= 0) { a.film = fb + (size_t)ev * 2 * C; a.film_stride = 0; a.film_mod = 1; }
+            else         { a.film = fb; a.film_stride = 2 * C; a.film_mod = p.B; }
+            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 0; a.scale_off = C;
+            a.mask = mask; a.mask_mod = p.B; a.mask_out = 0; a.T = T; a.rows = N * T;
+            ProfScope ps(e, s, PC_FILM_LN1, 0);
+            HIPCHK(e, launch_film_ln(e->dt, a, s));
+        }
+        if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
+        {   // q, k, v projections + RoPE (diffusion_transformer.py:59-61,74-75)
+            ConvGemmArgs a = base_args(p, e->qkv[i], N);
+            a.a0 = p.h16; a.c0 = C;
+            a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+            a.Tp = p.Tp; a.n_heads = e->H;
+            a.qscale = 1.4426950408889634f / sqrtf((float)(C / e->H));
+            ProfScope ps(e, s, PC_QKV, conv_flops(p, e->qkv[i], N));
+            HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
+        }
+        if (cap) {
+            capture(e, bn + "q", p.q16, rowsC, true, s); capture(e, bn + "k", p.k16, rowsC, true, s);
+            capture(e, bn + "vt", p.vt16, (int64_t)N * C * p.Tp, true, s);
+        }
+        {
+            AttnArgs a; memset(&a, 0, sizeof(a));
+            a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.mask = mask; a.mask_mod = p.B;
+            a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
+            ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
+            HIPCHK(e, launch_attention(e->dt, a, s));
+        }
+        if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
+        {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111)
+            ConvGemmArgs a = base_args(p, e->oproj[i], N);
+            a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
+            ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
+            HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
+        }
+        if (cap) capture(e, bn + "x2", p.X, rowsC, false, s);
+        {   // LN2 + modulate, masked (FFN input, diffusion_transformer.py:112,26)
+            FilmLnArgs a; memset(&a, 0, sizeof(a));
+            a.X = p.X; a.h16 = p.h16; a.film = nullptr; a.film_mod = 1;
+            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
+            a.mask = mask; a.mask_mod = p.B; a.mask_out = 1; a.T = T; a.rows = N * T;
+            ProfScope ps(e, s, PC_LN2, 0);
+            HIPCHK(e, launch_film_ln(e->dt, a, s));
+        }
+        if (cap) capture(e, bn + "h2", p.h16, rowsC, true, s);
+        {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
+            ConvGemmArgs a = base_args(p, e->ffn1[i], N);
+            a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
+            ProfScope ps(e, s, PC_FFN1, conv_flops(p, e->ffn1[i], N));
+            HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
+        }
+        if (cap) capture(e, bn + "u", p.u16, (int64_t)N * T * F, true, s);
+        {   // FFN conv_2, mask, gate, residual (diffusion_transformer.py:29-30,112)
+            ConvGemmArgs a = base_args(p, e->ffn2[i], N);
+            a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
+            a.out16 = (i + 1 < L / 2) ? p.skip16[i + 1] : p.cur16;
+            ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
+            HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
+        }
+        if (cap) capture(e, bn + "x3", p.X, rowsC, false, s);
+    }
+    {   // final projection (estimator.py:136-138); block output is already zero on padded frames
+        ConvGemmArgs a = base_args(p, e->fin, N);
+        a.a0 = p.cur16; a.c0 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
+        ProfScope ps(e, s, PC_FINAL, conv_flops(p, e->fin, N));
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    if (cap) capture(e, "v", p.v32, (int64_t)N * T * e->Mp, false, s);
+    return ST_OK;
+}
+
+int check_ready(st_engine* e, int B, int T) {
+    if (!e) return ST_ERR_INVALID;
+    if (!e->finalized) return e->fail(ST_ERR_STATE, "st_finalize() has not been called after loading parameters");
+    if (B < 1 || T < 1) return e->fail(ST_ERR_INVALID, "B and T must be >= 1");
+    if ((int64_t)2 * B * T * e->F >= (int64_t)1 << 31) return e->fail(ST_ERR_INVALID, "B*T too large for 32-bit row indexing");
+    return ST_OK;
+}
+
+// torch.linspace(0, 1, n + 1) in fp32 (CPU kernel: symmetric fill from both ends)
+std::vector<float> linspace01(int n) {
+    const int steps = n + 1;
+    std::vector<float> t(steps);
+    const float step = (1.0f - 0.0f) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i) t[i] = i < half ? 0.0f + step * (float)i : 1.0f - step * (float)(steps - i - 1);
+    return t;
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int st_abi_version(void) { return ST_ABI_VERSION; }
+
+int st_create(const st_config* cfg, int device, st_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return ST_ERR_INVALID; }
+    auto bad = [&](const char* m) { g_create_error = m; return ST_ERR_INVALID; };
+    // the reference's own assertions
+    if (cfg->n_layers % 2 != 0 || cfg->n_layers < 2 || cfg->n_layers > 16)
+        return bad("n_layers must be even (estimator.py:92) and in [2, 16]");
+    if (cfg->hidden_channels % 2 != 0) return bad("SinusoidalPosEmb requires dim to be even (estimator.py:39)");
+    if (cfg->n_heads < 1 || cfg->hidden_channels % cfg->n_heads != 0)
+        return bad("channels % n_heads != 0 (diffusion_transformer.py:35)");
+    // limits of this native build
+    if (cfg->hidden_channels != 256) { g_create_error = "native kernels are built for hidden_channels == 256"; return ST_ERR_UNSUPPORTED; }
+    if (cfg->hidden_channels / cfg->n_heads != 64) { g_create_error = "native kernels are built for head_dim == 64"; return ST_ERR_UNSUPPORTED; }
+    if (cfg->kernel_size != 3) { g_create_error = "native kernels are built for kernel_size == 3"; return ST_ERR_UNSUPPORTED; }
+    if (cfg->filter_channels % 128 != 0 || cfg->filter_channels < 128) { g_create_error = "filter_channels must be a multiple of 128"; return ST_ERR_UNSUPPORTED; }
+    if (cfg->noise_channels < 1 || cfg->noise_channels > 1024) return bad("noise_channels out of range");
+    if (cfg->gin_channels < 4 || cfg->gin_channels % 4 != 0) return bad("gin_channels must be a positive multiple of 4");
+    if (cfg->operand_dtype != ST_OPERAND_BF16 && cfg->operand_dtype != ST_OPERAND_F16) return bad("operand_dtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        g_create_error = "no such HIP device";
+        return ST_ERR_HIP;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ST_ERR_HIP; }
+    st_engine* e = new st_engine();
+    e->cfg = *cfg; e->device = device;
+    e->dt = cfg->operand_dtype == ST_OPERAND_BF16 ? DT_BF16 : DT_F16;
+    e->M = cfg->noise_channels; e->Mp = (e->M + 127) / 128 * 128;
+    e->C = cfg->hidden_channels; e->F = cfg->filter_channels; e->H = cfg->n_heads; e->L = cfg->n_layers;
+    e->K = cfg->kernel_size; e->G = cfg->gin_channels;
+    build_param_table(e);
+    *out = e;
+    return ST_OK;
+}
+
+void st_destroy(st_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    for (auto& kv : e->params) if (kv.second.dev) hipFree(kv.second.dev);
+    for (void* p : e->owned) hipFree(p);
+    for (auto& kv : e->caps) if (kv.second.dev) hipFree(kv.second.dev);
+    prof_collect(e);
+    for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
+    if (e->ws) hipFree(e->ws);
+    if (e->rope_cos) hipFree(e->rope_cos);
+    if (e->rope_sin) hipFree(e->rope_sin);
+    delete e;
+}
+
+const char* st_last_error(const st_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int st_num_params(const st_engine* e) { return e ? (int)e->params.size() : ST_ERR_INVALID; }
+
+int st_load_param(st_engine* e, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!e) return ST_ERR_INVALID;
+    if (!name || !data || !shape) return e->fail(ST_ERR_INVALID, "null argument");
+    auto it = e->params.find(name);
+    if (it == e->params.end()) return e->fail(ST_ERR_INVALID, std::string("unexpected parameter name: ") + name);
+    Param& p = it->second;
+    bool ok = (int)p.shape.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = p.shape[i] == shape[i];
+    if (!ok) return e->fail(ST_ERR_INVALID, std::string("shape mismatch for ") + name);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!p.dev) HIPCHK(e, hipMalloc((void**)&p.dev, (size_t)p.numel() * 4));
+    HIPCHK(e, hipMemcpy(p.dev, data, (size_t)p.numel() * 4, hipMemcpyDefault));
+    p.loaded = true;
+    e->finalized = false;
+    return ST_OK;
+}
+
+int st_finalize(st_engine* e) {
+    if (!e) return ST_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    for (auto& kv : e->params)
+        if (!kv.second.loaded) return e->fail(ST_ERR_STATE, "parameter not loaded: " + kv.first);
+    HIPCHK(e, hipDeviceSynchronize());
+    for (void* p : e->owned) hipFree(p);
+    e->owned.clear(); e->weight_bytes = 0;
+    const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
+    hipStream_t s = nullptr;
+    // generic packer: (cout, cin_total, taps) source slice -> Conv with padded dims
+    auto pack = [&](Conv& cv, const std::string& wname, const float* bias_src, int cout, int cout_p, int cin_total,
+                    int taps, int ci_off, int ci_cnt, int cin_p) -> int {
+        cv.cout = cout_p; cv.cin = cin_p; cv.taps = taps;
+        const size_t wbytes = (size_t)cout_p * taps * cin_p * 2;
+        int rc = dev_alloc(e, &cv.w, wbytes); if (rc) return rc;
+        HIPCHK(e, hipMemsetAsync(cv.w, 0, wbytes, s));
+        HIPCHK(e, launch_pack_weight(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cin_p, s));
+        rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4); if (rc) return rc;
+        HIPCHK(e, hipMemsetAsync(cv.bias, 0, (size_t)cout_p * 4, s));
+        if (bias_src) HIPCHK(e, hipMemcpyAsync(cv.bias, bias_src, (size_t)cout * 4, hipMemcpyDeviceToDevice, s));
+        return ST_OK;
+    };
+    int rc;
+    e->pre.assign(3, Conv());
+    if ((rc = pack(e->pre[0], "cond_proj.0.weight", P(e, "cond_proj.0.bias"), F, F, M, K, 0, M, Mp))) return rc;
+    if ((rc = pack(e->pre[1], "cond_proj.2.weight", P(e, "cond_proj.2.bias"), F, F, F, K, 0, F, F))) return rc;
+    if ((rc = pack(e->pre[2], "cond_proj.4.weight", P(e, "cond_proj.4.bias"), C, C, F, K, 0, F, F))) return rc;
+    // in_proj input channel order [x(M) ; cond(C)] (estimator.py:120)
+    if ((rc = pack(e->inx, "in_proj.weight", nullptr, C, C, C + M, 1, 0, M, Mp))) return rc;
+    if ((rc = pack(e->inc, "in_proj.weight", P(e, "in_proj.bias"), C, C, C + M, 1, M, C, C))) return rc;
+    if ((rc = pack(e->fin, "final_proj.weight", P(e, "final_proj.bias"), M, Mp, C, 1, 0, C, C))) return rc;
+    e->lsc.assign(L / 2, Conv());
+    for (int i = 0; i < L / 2; ++i) {
+        const std::string n = "lsc_layers." + std::to_string(i);
+        if ((rc = pack(e->lsc[i], n + ".weight", P(e, n + ".bias"), C, C, 2 * C, K, 0, 2 * C, 2 * C))) return rc;
+    }
+    e->qkv.assign(L, Conv()); e->oproj.assign(L, Conv()); e->ffn1.assign(L, Conv()); e->ffn2.assign(L, Conv());
+    for (int i = 0; i < L; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".block.";
+        Conv& q = e->qkv[i];
+        q.cout = 3 * C; q.cin = C; q.taps = 1;
+        if ((rc = dev_alloc(e, &q.w, (size_t)3 * C * C * 2))) return rc;
+        if ((rc = dev_alloc(e, (void**)&q.bias, (size_t)3 * C * 4))) return rc;
+        int r = 0;
+        for (const char* nm : {"q", "k", "v"}) {
+            const std::string n = b + "attn.conv_" + nm;
+            HIPCHK(e, launch_pack_weight(e->dt, P(e, n + ".weight"), C, C, 1, 0, C, q.w, r * C, C, s));
+            HIPCHK(e, hipMemcpyAsync(q.bias + (size_t)r * C, P(e, n + ".bias"), (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+            ++r;
+        }
+        if ((rc = pack(e->oproj[i], b + "attn.conv_o.weight", P(e, b + "attn.conv_o.bias"), C, C, C, 1, 0, C, C))) return rc;
+        if ((rc = pack(e->ffn1[i], b + "mlp.conv_1.weight", P(e, b + "mlp.conv_1.bias"), F, F, C, K, 0, C, C))) return rc;
+        if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F))) return rc;
+    }
+    HIPCHK(e, hipDeviceSynchronize());
+    e->finalized = true;
+    return ST_OK;
+}
+
+int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x, const float* mu,
+                         const float* mask, const float* c, float* out, int B, int T, void* stream) {
+    int rc = check_ready(e, B, T); if (rc) return rc;
+    if (!t || !x || !mu || !mask || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+    if (t_len != 1 && t_len != B) return e->fail(ST_ERR_INVALID, "t must have 1 or B elements");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    Plan p;
+    if ((rc = make_plan(e, B, T, false, t_len, &p))) return rc;
+    if ((rc = ensure_rope(e, T, s))) return rc;
+    {
+        ProfScope ps(e, s, PC_PREP, 0);
+        HIPCHK(e, launch_mask_prep(mask, B, T, p.n_full, p.kv_end, s));
+        HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
+        HIPCHK(e, launch_to_time_major(e->dt, x, B, e->M, T, e->Mp, nullptr, p.x16, s));
+        HIPCHK(e, hipMemcpyAsync(p.cvec, c, (size_t)B * e->G * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(e, hipMemcpyAsync(p.tvals, t, (size_t)t_len * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if ((rc = run_prenet(e, p, s))) return rc;
+    if ((rc = run_adaln(e, p, s))) return rc;
+    if ((rc = run_time_tables(e, p, s))) return rc;
+    if ((rc = run_estimator(e, p, mask, t_len == 1 ? 0 : -1, s))) return rc;
+    {
+        ProfScope ps(e, s, PC_PREP, 0);
+        HIPCHK(e, launch_from_time_major(p.v32, B, e->M, T, e->Mp, out, s));
+    }
+    return ST_OK;
+}
+
+int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* z, const float* c,
+                 int n_steps, int solver, int use_cfg, float cfg_strength,
+                 const float* fake_speaker, const float* fake_content,
+                 float* out, int B, int T, void* stream) {
+    int rc = check_ready(e, B, T); if (rc) return rc;
+    if (!mu || !mask || !z || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+    if (n_steps < 1 || n_steps > 4096) return e->fail(ST_ERR_INVALID, "n_steps out of range");
+    if (solver != ST_SOLVER_EULER && solver != ST_SOLVER_MIDPOINT && solver != ST_SOLVER_RK4)
+        return e->fail(ST_ERR_UNSUPPORTED, "solver not implemented natively (euler, midpoint, rk4 are)");
+    if (use_cfg && (!fake_speaker || !fake_content)) return e->fail(ST_ERR_INVALID, "CFG needs fake_speaker and fake_content");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int stages = solver == ST_SOLVER_EULER ? 1 : (solver == ST_SOLVER_MIDPOINT ? 2 : 4);
+    const int n_t = n_steps * stages;
+    Plan p;
+    if ((rc = make_plan(e, B, T, use_cfg != 0, n_t, &p))) return rc;
+    if ((rc = ensure_rope(e, T, s))) return rc;
+
+    // evaluation times, fp32 arithmetic as torchdiffeq does on the fp32 t_span (flow_matching.py:46)
+    const std::vector<float> grid = linspace01(n_steps);
+    std::vector<float> tv((size_t)n_t), dts((size_t)n_steps);
+    for (int i = 0; i < n_steps; ++i) {
+        const float t0 = grid[i], t1 = grid[i + 1], dt = t1 - t0;
+        dts[i] = dt;
+        if (stages == 1) tv[i] = t0;
+        else if (stages == 2) { tv[2 * i] = t0; tv[2 * i + 1] = t0 + 0.5f * dt; }
+        else { tv[4 * i] = t0; tv[4 * i + 1] = t0 + dt / 3.0f; tv[4 * i + 2] = t0 + dt * 2.0f / 3.0f; tv[4 * i + 3] = t1; }
+    }
+    const int64_t per_item = (int64_t)T * e->Mp;
+    const int64_t nstate = (int64_t)B * per_item;
+    {
+        ProfScope ps(e, s, PC_PREP, 0);
+        HIPCHK(e, hipMemcpyAsync(p.tvals, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(e, hipStreamSynchronize(s));   // tv is a stack-lifetime host buffer
+        HIPCHK(e, launch_mask_prep(mask, B, T, p.n_full, p.kv_end, s));
+        HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
+        HIPCHK(e, launch_to_time_major(e->dt, z, B, e->M, T, e->Mp, p.xstate, p.x16, s));
+        HIPCHK(e, hipMemcpyAsync(p.cvec, c, (size_t)B * e->G * 4, hipMemcpyDeviceToDevice, s));
+        if (use_cfg) {
+            // uncond branch inputs (flow_matching.py:59-60): fake_content over ALL frames, fake_speaker per item
+            HIPCHK(e, launch_fill_rows16(e->dt, fake_content, e->M, e->Mp, T,
+                                         (char*)p.mu16 + (size_t)B * per_item * 2, s));
+            for (int b = 0; b < B; ++b)
+                HIPCHK(e, hipMemcpyAsync(p.cvec + (size_t)(B + b) * e->G, fake_speaker, (size_t)e->G * 4,
+                                         hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if ((rc = run_prenet(e, p, s))) return rc;
+    if ((rc = run_adaln(e, p, s))) return rc;
+    if ((rc = run_time_tables(e, p, s))) return rc;
+
+    for (int i = 0; i < n_steps; ++i) {
+        const float dt = dts[i];
+        if (solver == ST_SOLVER_EULER) {
+            if ((rc = run_estimator(e, p, mask, i, s))) return rc;
+            ProfScope ps(e, s, PC_ODE, 0);
+            HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, nullptr, p.xstate, p.x16, dt, s));
+        } else if (solver == ST_SOLVER_MIDPOINT) {
+            if ((rc = run_estimator(e, p, mask, 2 * i, s))) return rc;
+            {
+                ProfScope ps(e, s, PC_ODE, 0);
+                HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, p.kbuf[0], nullptr, nullptr, 0.f, s));
+                const float* ks[1] = {p.kbuf[0]}; const float cf[1] = {0.5f * dt};
+                HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 1, nstate, nullptr, p.x16, s));
+            }
+            if ((rc = run_estimator(e, p, mask, 2 * i + 1, s))) return rc;
+            ProfScope ps(e, s, PC_ODE, 0);
+            HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, nullptr, p.xstate, p.x16, dt, s));
+        } else {   // rk4 = torchdiffeq's 3/8 rule
+            for (int st = 0; st < 4; ++st) {
+                if ((rc = run_estimator(e, p, mask, 4 * i + st, s))) return rc;
+                ProfScope ps(e, s, PC_ODE, 0);
+                HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, p.kbuf[st], nullptr, nullptr, 0.f, s));
+                if (st == 0) {
+                    const float* ks[1] = {p.kbuf[0]}; const float cf[1] = {dt / 3.0f};
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 1, nstate, nullptr, p.x16, s));
+                } else if (st == 1) {
+                    const float* ks[2] = {p.kbuf[1], p.kbuf[0]}; const float cf[2] = {dt, -dt / 3.0f};
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 2, nstate, nullptr, p.x16, s));
+                } else if (st == 2) {
+                    const float* ks[3] = {p.kbuf[0], p.kbuf[1], p.kbuf[2]}; const float cf[3] = {dt, -dt, dt};
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 3, nstate, nullptr, p.x16, s));
+                } else {
+                    const float* ks[4] = {p.kbuf[0], p.kbuf[1], p.kbuf[2], p.kbuf[3]};
+                    const float cf[4] = {dt * 0.125f, dt * 0.375f, dt * 0.375f, dt * 0.125f};
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 4, nstate, p.xstate, p.x16, s));
+                }
+            }
+        }
+    }
+    {
+        ProfScope ps(e, s, PC_PREP, 0);
+        HIPCHK(e, launch_from_time_major(p.xstate, B, e->M, T, e->Mp, out, s));
+    }
+    return ST_OK;
+}
+
+int st_debug_capture(st_engine* e, int enable) {
+    if (!e) return ST_ERR_INVALID;
+    e->capture = enable != 0;
+    if (!enable) {
+        hipSetDevice(e->device);
+        hipDeviceSynchronize();
+        for (auto& kv : e->caps) if (kv.second.dev) hipFree(kv.second.dev);
+        e->caps.clear();
+    }
+    return ST_OK;
+}
+
+int64_t st_debug_fetch(st_engine* e, const char* name, float* host_out, int64_t capacity) {
+    if (!e || !name) return ST_ERR_INVALID;
+    auto it = e->caps.find(name);
+    if (it == e->caps.end() || !it->second.dev) { e->err = std::string("no captured tensor named ") + name; return ST_ERR_INVALID; }
+    Captured& c = it->second;
+    if (!host_out) return c.n;
+    if (capacity < c.n) { e->err = "capacity too small"; return ST_ERR_INVALID; }
+    if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ST_ERR_HIP;
+    if (!c.is16) {
+        if (hipMemcpy(host_out, c.dev, (size_t)c.n * 4, hipMemcpyDeviceToHost) != hipSuccess) return ST_ERR_HIP;
+        return c.n;
+    }
+    float* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, (size_t)c.n * 4) != hipSuccess) return ST_ERR_HIP;
+    hipError_t r = launch_cvt16_to_f32(e->dt, c.dev, tmp, c.n, nullptr);
+    if (r == hipSuccess) r = hipMemcpy(host_out, tmp, (size_t)c.n * 4, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    return r == hipSuccess ? c.n : (int64_t)ST_ERR_HIP;
+}
+
+int st_profile_enable(st_engine* e, int enable) {
+    if (!e) return ST_ERR_INVALID;
+    hipSetDevice(e->device);
+    prof_collect(e);
+    e->prof = enable != 0;
+    for (int i = 0; i < PC_COUNT; ++i) { e->prof_launches[i] = 0; e->prof_ms[i] = 0; e->prof_flops[i] = 0; }
+    return ST_OK;
+}
+
+int st_profile_num_classes(void) { return PC_COUNT; }
+
+const char* st_profile_class_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+
+int st_profile_read(st_engine* e, int cls, int64_t* launches, double* total_ms, double* flops_per_launch) {
+    if (!e || cls < 0 || cls >= PC_COUNT) return ST_ERR_INVALID;
+    hipSetDevice(e->device);
+    prof_collect(e);
+    if (launches) *launches = e->prof_launches[cls];
+    if (total_ms) *total_ms = e->prof_ms[cls];
+    if (flops_per_launch) *flops_per_launch = e->prof_flops[cls];
+    e->prof_launches[cls] = 0; e->prof_ms[cls] = 0;
+    return ST_OK;
+}
+
+int64_t st_device_bytes(const st_engine* e) {
+    if (!e) return ST_ERR_INVALID;
+    int64_t n = e->weight_bytes + (int64_t)e->ws_cap;
+    for (auto& kv : e->params) if (kv.second.dev) n += kv.second.numel() * 4;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// Host-visible launcher interface between engine.cpp and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace st {
+
+enum { DT_BF16 = 0, DT_F16 = 1 };
+
+// ---------------------------------------------------------------- implicit-GEMM convolution
+// out[ch][frame] = bias[ch] + sum_{tap j, ci} W[ch][j][ci] * act[frame + j - TAPS/2][ci]
+// Activations are TIME-MAJOR 16-bit tensors [item][T][C]; the K dimension may span two source
+// tensors (channel concat without materialising torch.cat: estimator.py:120,131).
+enum { EPI_ACT16 = 0, EPI_F32 = 1, EPI_RESGATE = 2, EPI_QKV = 3 };
+enum { GF_SILU = 1, GF_MASK = 2 };
+
+struct ConvGemmArgs {
+    const void* a0; const void* a1;   // activation sources [items][T][c0], [items][T][c1]
+    int c0, c1;                       // channels per source (multiples of 64; c1 may be 0)
+    int a0_mod, a1_mod;               // activation item of output item n is n % mod
+    const void* w;                    // packed weights [cout][TAPS][c0 + c1], 16-bit
+    const float* bias;                // [cout] or nullptr
+    int cout, T, n_items;
+    int tiles_f, tiles_c;             // frame tiles per item, channel tiles
+    const float* mask; int mask_mod;  // [mask_mod][T] float 0/1, item n -> n % mask_mod
+    int flags;                        // GF_*
+    void* out16; float* out32;        // [items][T][cout]
+    const float* add32; int add_clamp;  // EPI_F32: + add32[min(n, add_clamp)][t][ch]
+    const float* gate; int gate_stride; // EPI_RESGATE: out32 += gate[n*gate_stride + ch]*((acc+b)*mask)
+    // EPI_QKV (cout = 3*C, head_dim 64): q,k -> [item][H][T][64], vT -> [item][H][64][Tp]
+    void* q; void* k; void* vt;
+    const float* rope_cos; const float* rope_sin;   // [T][16]
+    int Tp; float qscale; int n_heads;
+};
+
+hipError_t launch_conv_gemm_bf16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
+hipError_t launch_conv_gemm_f16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
+constexpr int kGemmFramesPerTile = 128;
+constexpr int kGemmChannelsPerTile = 128;
+
+// ---------------------------------------------------------------- attention
+struct AttnArgs {
+    const void* q; const void* k; const void* vt; void* out;   // out: [item][T][H*64] 16-bit
+    const float* mask; int mask_mod;       // key validity [mask_mod][T]
+    const int* kv_end; const int* n_full;  // per mask row: last valid key + 1, leading valid prefix length
+    int T, Tp, H, n_items;
+};
+hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- FiLM + LayerNorm + adaLN modulate
+struct FilmLnArgs {
+    float* X;                   // residual stream [rows][256] fp32 (updated in place when film != nullptr)
+    void* h16;                  // modulated LayerNorm output [rows][256] 16-bit
+    const float* film; int film_stride; int film_mod;   // gamma = film[(n%mod)*stride + ch], beta = +256; or nullptr
+    const float* ada; int ada_stride;                   // shift = ada[n*stride + shift_off + ch], scale = + scale_off
+    int shift_off, scale_off;
+    const float* mask; int mask_mod;
+    int mask_out;               // multiply h by the mask (FFN input, diffusion_transformer.py:26)
+    int T, rows;
+};
+hipError_t launch_film_ln(int dtype, const FilmLnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- small fp32 helpers
+hipError_t launch_time_embed(const float* t, int n_t, int dim, float* emb, hipStream_t s);
+// out[n][o] = act_out(bias[o] + sum_i W[o][i] * act_in(in[n][i]))
+hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
+                         float* out, int silu_in, int silu_out, hipStream_t s);
+hipError_t launch_mask_prep(const float* mask, int B, int T, int* n_full, int* kv_end, hipStream_t s);
+
+// (B, C, T) fp32 -> time-major (B, T, Cp): fp32 and/or 16-bit, channels >= C zero-filled; scale applied
+hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T, int Cp,
+                                float* out32, void* out16, hipStream_t s);
+// time-major (B, T, Cp) fp32 -> (B, C, T) fp32
+hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s);
+// dst16[t][c] = vec[c] for all t (uncond prenet input: fake_content broadcast, flow_matching.py:60)
+hipError_t launch_fill_rows16(int dtype, const float* vec, int C, int Cp, int T, void* out16, hipStream_t s);
+
+// v: [N2][T][Cp] estimator outputs. If use_cfg: vv = v[B+b] + s*(v[b] - v[B+b]) else vv = v[b].
+// kout (optional) = vv ; if xio: xio += dt*vv and x16 = xio (Euler step fused).
+hipError_t launch_cfg_combine(int dtype, const float* v, int B, int64_t per_item, int use_cfg, float s,
+                              float* kout, float* xio, void* x16, float dt, hipStream_t stream);
+// y = x + sum_i coef[i]*k[i] (i < nk <= 4); writes y32 and/or y16
+hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, const float* coef, int nk,
+                          int64_t n, float* y32, void* y16, hipStream_t s);
+
+// weight packing: src fp32 (cout, cin_total, K) -> dst16 [cout_p][K][cin_p] taking source channels
+// [ci_off, ci_off + ci_cnt); everything else zero.  dst row offset `row_off` (QKV concat).
+hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_total, int K, int ci_off,
+                              int ci_cnt, void* dst, int row_off, int cin_p, hipStream_t s);
+hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);
+
+}  // namespace st

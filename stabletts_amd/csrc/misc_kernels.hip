@@ -1,0 +1,310 @@
+// Memory-bound glue kernels of the CFM decoder path (gfx950): FiLM + LayerNorm + adaLN modulate,
+// layout changes at the drop-in boundary, time embedding, small fp32 linears, CFG combine and
+// ODE state updates, weight packing.  All fp32 arithmetic; 16-byte vector accesses.
+#include "common.h"
+#include "launch.h"
+
+namespace st {
+
+// ------------------------------------------------------------------------------------------
+// FiLM (estimator.py:31-33,16) + "* mask" + LayerNorm(C=256, eps 1e-5, no affine) + modulate
+// (diffusion_transformer.py:111-112,119-121).  One wave per frame: lane holds 4 channels.
+template <class P>
+__global__ __launch_bounds__(256) void film_ln_kernel(const FilmLnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+        const int n = row / a.T, t = row - n * a.T;
+        const float m = a.mask ? a.mask[(size_t)(n % a.mask_mod) * a.T + t] : 1.0f;
+        float4 x = *(const float4*)(a.X + (size_t)row * 256 + lane * 4);
+        if (a.film) {
+            const float* f = a.film + (size_t)(n % a.film_mod) * a.film_stride + lane * 4;
+            const float4 ga = *(const float4*)f;
+            const float4 be = *(const float4*)(f + 256);
+            x.x = (ga.x * x.x + be.x) * m; x.y = (ga.y * x.y + be.y) * m;
+            x.z = (ga.z * x.z + be.z) * m; x.w = (ga.w * x.w + be.w) * m;
+            *(float4*)(a.X + (size_t)row * 256 + lane * 4) = x;
+        }
+        const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / 256.0f);
+        const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float* ad = a.ada + (size_t)n * a.ada_stride + lane * 4;
+        const float4 sh = *(const float4*)(ad + a.shift_off);
+        const float4 sc = *(const float4*)(ad + a.scale_off);
+        float h0 = d0 * rstd * (1.0f + sc.x) + sh.x;
+        float h1 = d1 * rstd * (1.0f + sc.y) + sh.y;
+        float h2 = d2 * rstd * (1.0f + sc.z) + sh.z;
+        float h3 = d3 * rstd * (1.0f + sc.w) + sh.w;
+        if (a.mask_out) { h0 *= m; h1 *= m; h2 *= m; h3 *= m; }
+        *(uint2*)((unsigned char*)a.h16 + ((size_t)row * 256 + lane * 4) * 2) = pack4<P>(h0, h1, h2, h3);
+    }
+}
+
+hipError_t launch_film_ln(int dtype, const FilmLnArgs& a, hipStream_t s) {
+    int grid = (a.rows + 3) / 4;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (grid < 1) grid = 1;
+    if (dtype == DT_BF16) hipLaunchKernelGGL((film_ln_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL((film_ln_kernel<OpF16>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// SinusoidalPosEmb (estimator.py:41-49): emb[i] = sin(1000 t f_i), emb[half+i] = cos(...),
+// f_i = exp(-i ln(1e4)/(half-1)).
+__global__ void time_embed_kernel(const float* t, int n_t, int dim, float* emb) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_t * half) return;
+    const int n = idx / half, i = idx - n * half;
+    const float e = logf(10000.0f) / (float)(half - 1);
+    const float f = expf((float)i * -e);
+    const float arg = 1000.0f * t[n] * f;
+    emb[(size_t)n * dim + i] = sinf(arg);
+    emb[(size_t)n * dim + half + i] = cosf(arg);
+}
+
+hipError_t launch_time_embed(const float* t, int n_t, int dim, float* emb, hipStream_t s) {
+    const int total = n_t * (dim / 2);
+    hipLaunchKernelGGL(time_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, n_t, dim, emb);
+    return hipGetLastError();
+}
+
+// small dense layer, one wave per output element; k % 4 == 0
+__global__ __launch_bounds__(256) void linear_kernel(const float* in, int n, int k, const float* W, const float* bias,
+                                                     int o, float* out, int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)n * o) return;
+    const int ni = (int)(wid / o), oi = (int)(wid - (long long)ni * o);
+    const float* x = in + (size_t)ni * k;
+    const float* w = W + (size_t)oi * k;
+    float acc = 0.f;
+    for (int i = lane * 4; i < k; i += 256) {
+        float4 xv = *(const float4*)(x + i);
+        const float4 wv = *(const float4*)(w + i);
+        if (silu_in) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
+        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[oi] : 0.f);
+        if (silu_out) v = silu_f(v);
+        out[(size_t)ni * o + oi] = v;
+    }
+}
+
+hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
+                         float* out, int silu_in, int silu_out, hipStream_t s) {
+    const long long waves = (long long)n * o;
+    const int grid = (int)((waves + 3) / 4);
+    hipLaunchKernelGGL(linear_kernel, dim3(grid), dim3(256), 0, s, in, n, k, W, bias, o, out, silu_in, silu_out);
+    return hipGetLastError();
+}
+
+// per mask row: n_full = length of the leading run of non-zeros, kv_end = last non-zero + 1
+__global__ __launch_bounds__(256) void mask_prep_kernel(const float* mask, int T, int* n_full, int* kv_end) {
+    __shared__ int s_first_zero, s_last_nz;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) { s_first_zero = T; s_last_nz = -1; }
+    __syncthreads();
+    int fz = T, ln = -1;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const bool nz = mask[(size_t)b * T + t] != 0.0f;
+        if (!nz && t < fz) fz = t;
+        if (nz && t > ln) ln = t;
+    }
+    atomicMin(&s_first_zero, fz);
+    atomicMax(&s_last_nz, ln);
+    __syncthreads();
+    if (threadIdx.x == 0) { n_full[b] = s_first_zero; kv_end[b] = s_last_nz + 1; }
+}
+
+hipError_t launch_mask_prep(const float* mask, int B, int T, int* n_full, int* kv_end, hipStream_t s) {
+    hipLaunchKernelGGL(mask_prep_kernel, dim3(B), dim3(256), 0, s, mask, T, n_full, kv_end);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// boundary layout changes: (B, C, T) <-> time-major (B, T, Cp), 32x32 tiles through LDS
+template <class P>
+__global__ __launch_bounds__(256) void to_time_major_kernel(const float* in, int C, int T, int Cp,
+                                                            float* out32, typename P::elem* out16) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, t = t0 + tx;
+        float v = 0.f;
+        if (c < C && t < T) v = in[((size_t)b * C + c) * T + t];
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + i * 8, c = c0 + tx;
+        if (t < T && c < Cp) {
+            const float v = tile[tx][ty + i * 8];
+            const size_t o = ((size_t)b * T + t) * Cp + c;
+            if (out32) out32[o] = v;
+            if (out16) out16[o] = to16<P>(v);
+        }
+    }
+}
+
+hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T, int Cp,
+                                float* out32, void* out16, hipStream_t s) {
+    dim3 grid((T + 31) / 32, (Cp + 31) / 32, B);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((to_time_major_kernel<OpBF16>), grid, dim3(256), 0, s, in, C, T, Cp, out32, (__bf16*)out16);
+    else
+        hipLaunchKernelGGL((to_time_major_kernel<OpF16>), grid, dim3(256), 0, s, in, C, T, Cp, out32, (_Float16*)out16);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void from_time_major_kernel(const float* in, int C, int T, int Cp, float* out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + i * 8, c = c0 + tx;
+        float v = 0.f;
+        if (t < T && c < Cp) v = in[((size_t)b * T + t) * Cp + c];
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, t = t0 + tx;
+        if (c < C && t < T) out[((size_t)b * C + c) * T + t] = tile[tx][ty + i * 8];
+    }
+}
+
+hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s) {
+    dim3 grid((T + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(from_time_major_kernel, grid, dim3(256), 0, s, in, C, T, Cp, out);
+    return hipGetLastError();
+}
+
+template <class P>
+__global__ void fill_rows16_kernel(const float* vec, int C, int Cp, int T, typename P::elem* out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)T * Cp) return;
+    const int c = (int)(idx % Cp);
+    out[idx] = to16<P>(c < C ? vec[c] : 0.f);
+}
+
+hipError_t launch_fill_rows16(int dtype, const float* vec, int C, int Cp, int T, void* out16, hipStream_t s) {
+    const size_t total = (size_t)T * Cp;
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((fill_rows16_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, vec, C, Cp, T, (__bf16*)out16);
+    else                  hipLaunchKernelGGL((fill_rows16_kernel<OpF16>), dim3(grid), dim3(256), 0, s, vec, C, Cp, T, (_Float16*)out16);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// CFG combine (flow_matching.py:66) + optional fused Euler update (torchdiffeq euler step)
+template <class P>
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* v, int64_t half, int use_cfg, float s,
+                                                          float* kout, float* xio, typename P::elem* x16, float dt) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= half) return;
+    float4 vc = *(const float4*)(v + i);
+    if (use_cfg) {
+        const float4 vu = *(const float4*)(v + half + i);
+        vc.x = vu.x + s * (vc.x - vu.x); vc.y = vu.y + s * (vc.y - vu.y);
+        vc.z = vu.z + s * (vc.z - vu.z); vc.w = vu.w + s * (vc.w - vu.w);
+    }
+    if (kout) *(float4*)(kout + i) = vc;
+    if (xio) {
+        float4 x = *(const float4*)(xio + i);
+        x.x += dt * vc.x; x.y += dt * vc.y; x.z += dt * vc.z; x.w += dt * vc.w;
+        *(float4*)(xio + i) = x;
+        if (x16) *(uint2*)(x16 + i) = pack4<P>(x.x, x.y, x.z, x.w);
+    }
+}
+
+hipError_t launch_cfg_combine(int dtype, const float* v, int B, int64_t per_item, int use_cfg, float s,
+                              float* kout, float* xio, void* x16, float dt, hipStream_t stream) {
+    const int64_t half = (int64_t)B * per_item;   // multiple of 4
+    const int grid = (int)((half / 4 + 255) / 256);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((cfg_combine_kernel<OpBF16>), dim3(grid), dim3(256), 0, stream, v, half, use_cfg, s, kout, xio, (__bf16*)x16, dt);
+    else
+        hipLaunchKernelGGL((cfg_combine_kernel<OpF16>), dim3(grid), dim3(256), 0, stream, v, half, use_cfg, s, kout, xio, (_Float16*)x16, dt);
+    return hipGetLastError();
+}
+
+struct LinCombArgs { const float* x; const float* k[4]; float coef[4]; int nk; int64_t n; float* y32; void* y16; };
+
+template <class P>
+__global__ __launch_bounds__(256) void lincomb_kernel(const LinCombArgs a) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= a.n) return;
+    float4 y = *(const float4*)(a.x + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < a.nk) {
+            const float4 kv = *(const float4*)(a.k[j] + i);
+            const float c = a.coef[j];
+            y.x += c * kv.x; y.y += c * kv.y; y.z += c * kv.z; y.w += c * kv.w;
+        }
+    }
+    if (a.y32) *(float4*)(a.y32 + i) = y;
+    if (a.y16) *(uint2*)((typename P::elem*)a.y16 + i) = pack4<P>(y.x, y.y, y.z, y.w);
+}
+
+hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, const float* coef, int nk,
+                          int64_t n, float* y32, void* y16, hipStream_t s) {
+    LinCombArgs a;
+    a.x = x; a.nk = nk; a.n = n; a.y32 = y32; a.y16 = y16;
+    for (int j = 0; j < 4; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.coef[j] = j < nk ? coef[j] : 0.f; }
+    const int grid = (int)((n / 4 + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((lincomb_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL((lincomb_kernel<OpF16>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: (cout, cin_total, K) fp32 -> [row_off + co][K][cin_p] 16-bit
+template <class P>
+__global__ void pack_weight_kernel(const float* src, int cout, int cin_total, int K, int ci_off, int ci_cnt,
+                                   typename P::elem* dst, int row_off, int cin_p) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)cout * K * cin_p;
+    if (idx >= total) return;
+    const int ci = (int)(idx % cin_p);
+    const int j = (int)((idx / cin_p) % K);
+    const int co = (int)(idx / ((size_t)cin_p * K));
+    float v = 0.f;
+    if (ci < ci_cnt) v = src[((size_t)co * cin_total + ci_off + ci) * K + j];
+    dst[((size_t)(row_off + co) * K + j) * cin_p + ci] = to16<P>(v);
+}
+
+hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_total, int K, int ci_off,
+                              int ci_cnt, void* dst, int row_off, int cin_p, hipStream_t s) {
+    const size_t total = (size_t)cout * K * cin_p;
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((pack_weight_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (__bf16*)dst, row_off, cin_p);
+    else
+        hipLaunchKernelGGL((pack_weight_kernel<OpF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (_Float16*)dst, row_off, cin_p);
+    return hipGetLastError();
+}
+
+template <class P>
+__global__ void cvt16_kernel(const typename P::elem* src, float* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s) {
+    const int grid = (int)((n + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((cvt16_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, dst, n);
+    else                  hipLaunchKernelGGL((cvt16_kernel<OpF16>), dim3(grid), dim3(256), 0, s, (const _Float16*)src, dst, n);
+    return hipGetLastError();
+}
+
+}  // namespace st

@@ -1,0 +1,169 @@
+"""Parameter container + native forward for the vector-field estimator.
+
+Mirrors the module tree of the reference ``Decoder`` (models/estimator.py:65-96) and
+``DiTConVBlock`` (models/diffusion_transformer.py:82-96) so that ``state_dict()`` has exactly the
+116 ``decoder.estimator.*`` names/shapes of released checkpoints and
+DDP / AdamW / load_state_dict see ordinary ``nn.Parameter``s.  The modules hold parameters only;
+all arithmetic runs in libstabletts_hip.so (hand-written gfx950 kernels) -- there is no PyTorch
+fallback for the forward pass.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _ParamsOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the computation runs in the native HIP engine")
+
+
+class FiLMLayer(_ParamsOnly):
+    """models/estimator.py:20-33."""
+    def __init__(self, in_channels, cond_channels):
+        super().__init__()
+        self.film = nn.Conv1d(cond_channels, in_channels * 2, 1)
+
+
+class MultiHeadAttention(_ParamsOnly):
+    """models/diffusion_transformer.py:32-56 (parameters and init only)."""
+    def __init__(self, channels, out_channels, n_heads):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.conv_q = nn.Conv1d(channels, channels, 1)
+        self.conv_k = nn.Conv1d(channels, channels, 1)
+        self.conv_v = nn.Conv1d(channels, channels, 1)
+        self.conv_o = nn.Conv1d(channels, out_channels, 1)
+        for m in (self.conv_q, self.conv_k, self.conv_v):
+            nn.init.xavier_uniform_(m.weight)
+
+
+class FFN(_ParamsOnly):
+    """models/diffusion_transformer.py:10-23."""
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size):
+        super().__init__()
+        self.conv_1 = nn.Conv1d(in_channels, filter_channels, kernel_size, padding=kernel_size // 2)
+        self.conv_2 = nn.Conv1d(filter_channels, out_channels, kernel_size, padding=kernel_size // 2)
+
+
+class DiTConVBlock(_ParamsOnly):
+    """models/diffusion_transformer.py:82-96; LayerNorms have no parameters."""
+    def __init__(self, hidden_channels, filter_channels, num_heads, kernel_size, gin_channels):
+        super().__init__()
+        self.attn = MultiHeadAttention(hidden_channels, hidden_channels, num_heads)
+        self.mlp = FFN(hidden_channels, hidden_channels, filter_channels, kernel_size)
+        self.adaLN_modulation = nn.Sequential(
+            nn.Linear(gin_channels, hidden_channels) if gin_channels != hidden_channels else nn.Identity(),
+            nn.SiLU(),
+            nn.Linear(hidden_channels, 6 * hidden_channels, bias=True))
+
+
+class DitWrapper(_ParamsOnly):
+    """models/estimator.py:8-18."""
+    def __init__(self, hidden_channels, filter_channels, num_heads, kernel_size, gin_channels, time_channels):
+        super().__init__()
+        self.time_fusion = FiLMLayer(hidden_channels, time_channels)
+        self.block = DiTConVBlock(hidden_channels, filter_channels, num_heads, kernel_size, gin_channels)
+
+
+class TimestepEmbedding(_ParamsOnly):
+    """models/estimator.py:51-62."""
+    def __init__(self, in_channels, out_channels, filter_channels):
+        super().__init__()
+        self.layer = nn.Sequential(nn.Linear(in_channels, filter_channels), nn.SiLU(inplace=True),
+                                   nn.Linear(filter_channels, out_channels))
+
+
+class Decoder(nn.Module):
+    """Same constructor as the reference Decoder (models/estimator.py:66); forward is native.
+
+    forward(t, x, mask, mu, c) -> (B, out_channels, T): one vector-field evaluation
+    (models/estimator.py:103-138), inference only (no autograd graph is recorded).
+    """
+
+    def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels,
+                 dropout=0.1, n_layers=1, n_heads=4, kernel_size=3, gin_channels=0, use_lsc=True,
+                 operand_dtype="bf16"):
+        super().__init__()
+        assert hidden_channels % 2 == 0, "SinusoidalPosEmb requires dim to be even"
+        if not use_lsc:
+            raise NotImplementedError("native estimator is built with the U-Net long-skip connections (use_lsc=True)")
+        assert n_layers % 2 == 0
+        if not (noise_channels == cond_channels == out_channels):
+            raise NotImplementedError("native estimator expects noise == cond == out channels (n_mels)")
+        self.noise_channels, self.cond_channels = noise_channels, cond_channels
+        self.hidden_channels, self.out_channels = hidden_channels, out_channels
+        self.filter_channels, self.n_layers, self.n_heads = filter_channels, n_layers, n_heads
+        self.kernel_size, self.gin_channels, self.use_lsc = kernel_size, gin_channels, use_lsc
+        self.operand_dtype = operand_dtype
+
+        self.time_mlp = TimestepEmbedding(hidden_channels, hidden_channels, filter_channels)
+        self.in_proj = nn.Conv1d(hidden_channels + noise_channels, hidden_channels, 1)
+        self.blocks = nn.ModuleList([DitWrapper(hidden_channels, filter_channels, n_heads, kernel_size,
+                                                gin_channels, hidden_channels) for _ in range(n_layers)])
+        self.final_proj = nn.Conv1d(hidden_channels, out_channels, 1)
+        self.cond_proj = nn.Sequential(
+            nn.Conv1d(cond_channels, filter_channels, kernel_size, padding=kernel_size // 2), nn.SiLU(inplace=True),
+            nn.Conv1d(filter_channels, filter_channels, kernel_size, padding=kernel_size // 2), nn.SiLU(inplace=True),
+            nn.Conv1d(filter_channels, hidden_channels, kernel_size, padding=kernel_size // 2))
+        self.n_lsc_layers = n_layers // 2
+        self.lsc_layers = nn.ModuleList([nn.Conv1d(2 * hidden_channels, hidden_channels, kernel_size,
+                                                   padding=kernel_size // 2) for _ in range(self.n_lsc_layers)])
+        self.initialize_weights()
+        self._engine = None
+        self._engine_key = None
+
+    def initialize_weights(self):
+        """adaLN-Zero (models/estimator.py:98-101)."""
+        for block in self.blocks:
+            nn.init.constant_(block.block.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(block.block.adaLN_modulation[-1].bias, 0)
+
+    def __getstate__(self):
+        st = self.__dict__.copy()      # the ctypes engine handle is per-process, never copied/pickled
+        st["_engine"] = None
+        st["_engine_key"] = None
+        return st
+
+    # ------------------------------------------------------------------ native engine plumbing
+    def engine(self):
+        """The st_engine bound to the device of the parameters, with weights in sync."""
+        p0 = next(self.parameters())
+        if p0.device.type != "cuda":
+            raise RuntimeError("stabletts_amd: the estimator runs only on a HIP device (move the module with "
+                               ".to('cuda')); there is no CPU fallback")
+        dev = p0.device.index if p0.device.index is not None else torch.cuda.current_device()
+        if self._engine is None or self._engine.device != dev or self._engine.operand_dtype != self.operand_dtype:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = _lib.Engine(self.noise_channels, self.hidden_channels, self.filter_channels, self.n_heads,
+                                       self.n_layers, self.kernel_size, self.gin_channels, self.operand_dtype, dev)
+            self._engine_key = None
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key != self._engine_key:
+            with torch.no_grad():
+                torch.cuda.synchronize(dev)
+                self._engine.load_state_dict(self.state_dict())
+            self._engine_key = key
+        return self._engine
+
+    @staticmethod
+    def _prep(t, dev):
+        return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+    @torch.no_grad()
+    def forward(self, t, x, mask, mu, c):
+        eng = self.engine()
+        dev = x.device
+        B, M, T = x.shape
+        t = self._prep(t.reshape(-1) if torch.is_tensor(t) else torch.tensor([float(t)]), dev)
+        if t.numel() not in (1, B):
+            raise ValueError("t must be a scalar or have one entry per batch item")
+        x, mu, c = self._prep(x, dev), self._prep(mu, dev), self._prep(c, dev)
+        mask = self._prep(mask, dev)
+        if mu.shape != x.shape or mask.shape != (B, 1, T) or c.shape != (B, self.gin_channels):
+            raise ValueError("shape mismatch: x/mu (B,M,T), mask (B,1,T), c (B,gin)")
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            eng.estimator_forward(t, x, mu, mask, c, out, torch.cuda.current_stream(dev).cuda_stream)
+        return out

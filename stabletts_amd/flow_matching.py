@@ -1,0 +1,90 @@
+"""Drop-in replacement for the reference's ``models/flow_matching.py``.
+
+``CFMDecoder`` keeps the reference constructor (models/flow_matching.py:12), the ``forward``
+signature (:25) and the ``.estimator`` attribute / checkpoint key layout, but the whole ODE solve --
+noise -> n_timesteps x (cond + uncond estimator evaluation, CFG combine, solver update) -> mel --
+runs as hand-written gfx950 kernels behind ``st_cfm_solve`` (include/stabletts_hip.h).
+
+Differences from the reference, all additive:
+  * ``forward(..., z=None)``: optional explicit noise (already temperature-scaled semantics are kept:
+    the shim multiplies by ``temperature`` exactly like :45) so parity tests can fix the noise.
+  * ``solver``: the fixed-grid methods 'euler', 'midpoint', 'rk4' are native.  torchdiffeq's adaptive
+    methods (``None``/'dopri5', 'bosh3', ...) are not implemented natively and raise
+    NotImplementedError (torchdiffeq is not a dependency of this package).
+  * ``operand_dtype``: MFMA operand type, 'bf16' (default) or 'f16'; accumulation / residual stream /
+    LayerNorm / softmax statistics / ODE state stay fp32.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .estimator import Decoder
+
+
+class CFMDecoder(nn.Module):
+    def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="bf16"):
+        super().__init__()
+        self.noise_channels = noise_channels
+        self.cond_channels = cond_channels
+        self.hidden_channels = hidden_channels
+        self.out_channels = out_channels
+        self.filter_channels = filter_channels
+        self.gin_channels = gin_channels
+        self.sigma_min = 1e-4
+        self.estimator = Decoder(noise_channels, cond_channels, hidden_channels, out_channels, filter_channels,
+                                 p_dropout, n_layers, n_heads, kernel_size, gin_channels,
+                                 operand_dtype=operand_dtype)
+
+    @torch.inference_mode()
+    def forward(self, mu, mask, n_timesteps, temperature=1.0, c=None, solver=None, cfg_kwargs=None, z=None):
+        """Same contract as models/flow_matching.py:25-55; returns trajectory[-1], (B, n_feats, T)."""
+        if solver not in _lib.SOLVERS:
+            raise NotImplementedError(
+                f"solver={solver!r}: only the fixed-grid torchdiffeq methods {sorted(_lib.SOLVERS)} are native "
+                "(the reference default None means adaptive dopri5)")
+        if c is None:
+            raise ValueError("c (speaker embedding, (B, gin_channels)) is required")
+        eng = self.estimator.engine()
+        dev = mu.device
+        prep = self.estimator._prep
+        mu = prep(mu, dev)
+        B, M, T = mu.shape
+        mask = prep(mask, dev)
+        c = prep(c, dev)
+        if z is None:
+            z = torch.randn_like(mu) * temperature
+        else:
+            z = prep(z, dev) * temperature
+        if mask.shape != (B, 1, T) or z.shape != mu.shape or c.shape != (B, self.gin_channels):
+            raise ValueError("shape mismatch: mu/z (B,M,T), mask (B,1,T), c (B,gin)")
+        use_cfg = cfg_kwargs is not None
+        fs = fc = None
+        strength = 0.0
+        if use_cfg:
+            fs = prep(cfg_kwargs["fake_speaker"], dev).reshape(-1)
+            fc = prep(cfg_kwargs["fake_content"], dev).reshape(-1)
+            strength = float(cfg_kwargs["cfg_strength"])
+            if fs.numel() != self.gin_channels or fc.numel() != M:
+                raise ValueError("fake_speaker must be (1, gin) and fake_content (1, n_feats, 1)")
+        out = torch.empty_like(mu)
+        with torch.cuda.device(dev):
+            eng.cfm_solve(mu, mask, z, c, int(n_timesteps), _lib.SOLVERS[solver], use_cfg, strength, fs, fc, out,
+                          torch.cuda.current_stream(dev).cuda_stream)
+        return out
+
+    def cfg_wrapper(self, t, x, mask, mu, c, cfg_kwargs):
+        """models/flow_matching.py:58-67, both branches evaluated natively."""
+        fake_speaker = cfg_kwargs['fake_speaker'].repeat(x.size(0), 1)
+        fake_content = cfg_kwargs['fake_content'].repeat(x.size(0), 1, x.size(-1))
+        s = cfg_kwargs['cfg_strength']
+        cond = self.estimator(t, x, mask, mu, c)
+        uncond = self.estimator(t, x, mask, fake_content, fake_speaker)
+        return uncond + s * (cond - uncond)
+
+    def compute_loss(self, x1, mask, mu, c):
+        """models/flow_matching.py:69-100.  The backward pass of the estimator is not native yet
+        (SURVEY.md section 8f-1): training needs autograd through the estimator, which this
+        inference engine does not record."""
+        raise NotImplementedError("compute_loss: native backward kernels are not implemented yet "
+                                  "(inference path only); see DESIGN.md 'what comes next'")

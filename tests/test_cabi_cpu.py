@@ -1,0 +1,94 @@
+"""C-ABI library: loads on a CPU-only box, exports every symbol include/stabletts_hip.h declares,
+validates configurations like the reference constructor does, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from stabletts_amd.build import build
+    build(verbose=False)
+    from stabletts_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "stabletts_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(st_[a-z_0-9]+)\s*\(", hdr))
+    from stabletts_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.st_abi_version() == 1
+
+
+def _create(lib, **over):
+    from stabletts_amd._lib import StConfig
+    base = dict(noise_channels=128, hidden_channels=256, filter_channels=1024, n_heads=4, n_layers=6,
+                kernel_size=3, gin_channels=256, operand_dtype=0)
+    base.update(over)
+    cfg = StConfig(**base)
+    h = ctypes.c_void_p()
+    rc = lib.st_create(ctypes.byref(cfg), 0, ctypes.byref(h))
+    return rc, h, lib.st_last_error(None).decode()
+
+
+def test_reference_assertions_are_mirrored(lib):
+    rc, _, msg = _create(lib, n_layers=5)
+    assert rc == -1 and "estimator.py:92" in msg
+    rc, _, msg = _create(lib, n_heads=3)
+    assert rc == -1 and "diffusion_transformer.py:35" in msg
+    rc, _, msg = _create(lib, hidden_channels=512, n_heads=8)
+    assert rc == -4 and "hidden_channels" in msg          # valid in the reference, not built natively
+    rc, _, msg = _create(lib, kernel_size=5)
+    assert rc == -4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box behaviour")
+def test_no_gpu_fails_loudly(lib):
+    rc, _, msg = _create(lib)
+    assert rc == -2 and "device" in msg
+    from stabletts_amd.flow_matching import CFMDecoder
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256)
+    mu = torch.zeros(1, 128, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(mu, torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), "euler")
+
+
+def test_shim_mirrors_reference_interface():
+    import inspect
+    from stabletts_amd.flow_matching import CFMDecoder
+    import oracle
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256)
+    sd = dec.estimator.state_dict()
+    ref = oracle.make_state_dict(1234)
+    assert set(sd) == set(ref) and all(sd[k].shape == ref[k].shape for k in ref)
+    assert dec.sigma_min == 1e-4
+    params = list(inspect.signature(dec.forward).parameters)
+    assert params[:7] == ["mu", "mask", "n_timesteps", "temperature", "c", "solver", "cfg_kwargs"]
+    # adaLN-Zero init like the reference (estimator.py:98-101)
+    assert float(sd["blocks.0.block.adaLN_modulation.2.weight"].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        dec(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), None)
+    with pytest.raises(AssertionError):
+        CFMDecoder(128, 128, 256, 128, 1024, 4, 5, 3, 0.1, 256)       # n_layers % 2 (estimator.py:92)
+
+
+def test_install_registers_dropin_module():
+    import sys
+    import stabletts_amd
+    saved = sys.modules.pop("models.flow_matching", None)
+    try:
+        m = stabletts_amd.install()
+        assert sys.modules["models.flow_matching"] is m and hasattr(m, "CFMDecoder")
+    finally:
+        sys.modules.pop("models.flow_matching", None)
+        if saved is not None:
+            sys.modules["models.flow_matching"] = saved
