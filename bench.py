@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: mel-frames/sec of the CFM decoder ODE solve (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE pass of the hot path over one batch: CFMDecoder.forward on BASELINE config 2
+(31M decoder, B=32 utterances x T=1000 frames synthetic mu/mask, n_timesteps=10 Euler, CFG 3.0,
+bf16 MFMA operands), inputs already resident in HBM, explicit noise z.  With N GPUs every rank
+solves its own 32-utterance batch (utterances are independent units: no data-path collective,
+weak scaling); value = frames solved by all ranks / max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel class (largest total time, measured live with HIP events on the
+                  launch stream during the timed steps): algorithmic FLOPs per launch / mean launch
+                  time vs the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline -- the oracle (fp32 PyTorch CPU restatement of the reference) timed on this host's
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md chip-level table
+B_PER_GPU, T_FRAMES, N_STEPS, CFG = 32, 1000, 10, 3.0
+
+
+def algorithmic_flops_per_frame(T, n_evals, B):
+    """F_alg(frame) = E*body + prenet*(1 + 1/B)."""
+    body = 2.0 * (12320768 + 3072 * T)
+    prenet = 2.0 * 4325376
+    return n_evals * body + prenet * (1.0 + 1.0 / B)
+
+
+def cpu_baseline(sd, cfg_params, budget_s=20.0):
+    """Oracle Euler+CFG loop on a bounded sample (B=2 utterances x T=1000): as many of the n_timesteps
+    steps as fit in ~budget_s seconds of CPU work (>= 2), extrapolated linearly to the full solve (every
+    step costs the same two estimator evaluations).  Threads: torch's default for this host."""
+    import oracle
+    from oracle.inputs import make_inputs
+    threads = torch.get_num_threads()
+    fs, fc = cfg_params
+    Bs = 2
+    inp = make_inputs(Bs, T_FRAMES, seed=0)
+    x = inp["z"]
+    t_span = oracle.linspace_f32(N_STEPS)
+    done, t_used = 0, 0.0
+    with torch.inference_mode():
+        t0 = time.perf_counter()   # warm-up evaluation pair (not counted)
+        oracle.cfg_wrapper(sd, t_span[0], x, inp["mask"], inp["mu"], inp["c"], fs, fc, CFG)
+        warm = time.perf_counter() - t0
+        for i in range(N_STEPS):
+            t0 = time.perf_counter()
+            v = oracle.cfg_wrapper(sd, t_span[i], x, inp["mask"], inp["mu"], inp["c"], fs, fc, CFG)
+            x = x + (t_span[i + 1] - t_span[i]) * v
+            t_used += time.perf_counter() - t0
+            done += 1
+            if done >= 2 and t_used + warm >= budget_s:
+                break
+    per_solve = t_used / done * N_STEPS
+    return dict(value=Bs * T_FRAMES / per_solve, unit="mel-frames/sec", cores=threads, kind="port",
+                sample=f"oracle (fp32 torch-CPU restatement of the reference; prenet recomputed every evaluation as "
+                       f"the reference does), B={Bs} x T={T_FRAMES}, cfg={CFG}: {done} of {N_STEPS} euler steps timed "
+                       f"({t_used:.2f} s), scaled to {N_STEPS}; {threads} torch threads, os.cpu_count()={os.cpu_count()}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the native path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+
+    import oracle
+    from oracle.inputs import make_inputs
+    from stabletts_amd.flow_matching import CFMDecoder
+    from stabletts_amd import sharding
+
+    print(f"[bench] rank {rank}/{world} cpu_count={os.cpu_count()} affinity={len(os.sched_getaffinity(0))} "
+          f"torch_threads={torch.get_num_threads()}", file=sys.stderr, flush=True)
+    sd = oracle.make_state_dict(1234)
+    fs, fc = oracle.make_cfg_params(4321)
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=args.dtype)
+    dec.estimator.load_state_dict(sd)
+    dec = dec.to(dev)
+
+    # utterance sharding: world*32 utterances of T frames, dealt as length-sorted batches (no collective)
+    lengths = [T_FRAMES] * (B_PER_GPU * world)
+    my_batches = sharding.shard_for_rank(lengths, B_PER_GPU, world, rank)
+    assert len(my_batches) == 1 and len(my_batches[0]) == B_PER_GPU
+    inp = make_inputs(B_PER_GPU, T_FRAMES, seed=rank)
+    g = {k: v.to(dev) for k, v in inp.items() if k != "lengths"}
+    kw = dict(fake_speaker=fs.to(dev), fake_content=fc.to(dev), cfg_strength=CFG)
+
+    def step():
+        return dec(g["mu"], g["mask"], N_STEPS, 1.0, g["c"], "euler", kw, z=g["z"])
+
+    eng = dec.estimator.engine()
+    for _ in range(args.warmup):
+        step()
+    heavy = ["ffn_conv1", "ffn_conv2", "attention", "qkv_rope", "lsc_conv", "out_proj"]
+    eng.profile_enable(True, heavy)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+
+    frames_total = world * B_PER_GPU * T_FRAMES * args.steps
+    value = frames_total / elapsed
+    if rank == 0:
+        dom = max(heavy, key=lambda k: prof[k]["total_ms"])
+        p = prof[dom]
+        avg_s = p["total_ms"] / max(p["launches"], 1) * 1e-3
+        achieved = p["flops_per_launch"] / avg_s / 1e12
+        n_evals = 2 * N_STEPS
+        falg = algorithmic_flops_per_frame(T_FRAMES, n_evals, B_PER_GPU)
+        line = {
+            "metric": "mel-frames/sec (whole node), 31M DiT, n_timesteps=10+CFG",
+            "value": value, "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 31M CFM decoder (hidden 256, filter 1024, 4 heads, 6 DiT blocks, "
+                                   "n_mels 128), batch 32 x T=1000 synthetic mu/mask per GPU, n_timesteps=10 euler, "
+                                   "cfg=3.0, seeded random weights (adaLN re-randomised)",
+                       "global_batch": world * B_PER_GPU, "seq_len": T_FRAMES,
+                       "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": f"conv_gemm_kernel [{dom}]", "achieved": achieved,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "traffic": None,
+                         "launches": p["launches"], "avg_launch_us": avg_s * 1e6,
+                         "flops_per_launch": p["flops_per_launch"]},
+            "whole_solve_tflops": falg * B_PER_GPU * T_FRAMES / (elapsed / args.steps) / 1e12 * world,
+            "kernel_classes_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, (fs, fc))
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

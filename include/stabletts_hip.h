@@ -114,6 +114,8 @@ int64_t st_debug_fetch(st_engine* e, const char* name, float* host_out, int64_t 
  * st_profile_class_name(i), i in [0, st_profile_num_classes()).  st_profile_read synchronises,
  * returns launches and total milliseconds per class since the last reset, and resets. */
 int st_profile_enable(st_engine* e, int enable);
+/* Restrict event recording to the classes whose bit is set in class_mask (default: all). */
+int st_profile_select(st_engine* e, uint64_t class_mask);
 int st_profile_num_classes(void);
 const char* st_profile_class_name(int cls);
 int st_profile_read(st_engine* e, int cls, int64_t* launches, double* total_ms, double* flops_per_launch);

@@ -20,7 +20,7 @@ SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_S
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
     "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_debug_capture", "st_debug_fetch",
-    "st_profile_enable", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
+    "st_profile_enable", "st_profile_select", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes",
 ]
 
@@ -84,6 +84,8 @@ def load():
     lib.st_debug_fetch.restype = ctypes.c_int64
     lib.st_profile_enable.argtypes = [c_void_p, c_int]
     lib.st_profile_enable.restype = c_int
+    lib.st_profile_select.argtypes = [c_void_p, ctypes.c_uint64]
+    lib.st_profile_select.restype = c_int
     lib.st_profile_num_classes.restype = c_int
     lib.st_profile_class_name.argtypes = [c_int]
     lib.st_profile_class_name.restype = ctypes.c_char_p
@@ -171,7 +173,15 @@ class Engine:
             raise NativeError(int(r), self.lib.st_last_error(self.handle).decode())
         return buf
 
-    def profile_enable(self, on):
+    def profile_enable(self, on, classes=None):
+        """classes: optional iterable of class names to restrict event recording to."""
+        mask = (1 << 64) - 1
+        if classes is not None:
+            names = [self.lib.st_profile_class_name(i).decode() for i in range(self.lib.st_profile_num_classes())]
+            mask = 0
+            for c in classes:
+                mask |= 1 << names.index(c)
+        self._check(self.lib.st_profile_select(self.handle, mask))
         self._check(self.lib.st_profile_enable(self.handle, int(on)))
 
     def profile_read(self):

@@ -72,6 +72,7 @@ struct st_engine {
     bool capture = false;
     std::map<std::string, Captured> caps;
     bool prof = false;
+    uint64_t prof_mask = ~0ull;
     std::vector<ProfEvent> evs;
     std::vector<hipEvent_t> ev_pool;
     int64_t prof_launches[PC_COUNT] = {0};
@@ -144,7 +145,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
 struct ProfScope {
     st_engine* e; hipStream_t s; int idx = -1;
     ProfScope(st_engine* e_, hipStream_t s_, int cls, double flops) : e(e_), s(s_) {
-        if (!e->prof) return;
+        if (!e->prof || !((e->prof_mask >> cls) & 1ull)) return;
         ProfEvent ev; ev.cls = cls; ev.flops = flops;
         for (hipEvent_t* h : {&ev.a, &ev.b}) {
             if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
@@ -763,6 +764,12 @@ int st_profile_enable(st_engine* e, int enable) {
     prof_collect(e);
     e->prof = enable != 0;
     for (int i = 0; i < PC_COUNT; ++i) { e->prof_launches[i] = 0; e->prof_ms[i] = 0; e->prof_flops[i] = 0; }
+    return ST_OK;
+}
+
+int st_profile_select(st_engine* e, uint64_t class_mask) {
+    if (!e) return ST_ERR_INVALID;
+    e->prof_mask = class_mask;
     return ST_OK;
 }
 
