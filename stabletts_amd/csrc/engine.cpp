@@ -64,6 +64,7 @@ struct st_engine {
     std::vector<void*> owned;           // device allocations to free
 
     float* rope_cos = nullptr; float* rope_sin = nullptr; int rope_T = 0;
+    void* zeros = nullptr;              // 256 zero bytes: halo source of the LDS-DMA conv path
 
     // workspace arena
     char* ws = nullptr; size_t ws_cap = 0;
@@ -267,13 +268,14 @@ int ensure_rope(st_engine* e, int T, hipStream_t s) {
     return ST_OK;
 }
 
-ConvGemmArgs base_args(const Plan& p, const Conv& cv, int n_items) {
+ConvGemmArgs base_args(const st_engine* e, const Plan& p, const Conv& cv, int n_items) {
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.w = cv.w; a.bias = cv.bias; a.cout = cv.cout; a.T = p.T; a.n_items = n_items;
     a.tiles_f = (p.T + kGemmFramesPerTile - 1) / kGemmFramesPerTile;
     a.tiles_c = cv.cout / kGemmChannelsPerTile;
     a.a0_mod = n_items; a.a1_mod = n_items; a.mask_mod = p.B;
+    a.zeros = e->zeros;
     return a;
 }
 
@@ -284,26 +286,26 @@ inline double conv_flops(const Plan& p, const Conv& cv, int n_items) {
 // cond prenet (estimator.py:83-89,118) + the loop-invariant cond half of in_proj (:120-121)
 int run_prenet(st_engine* e, const Plan& p, hipStream_t s) {
     {
-        ConvGemmArgs a = base_args(p, e->pre[0], p.Pn);
+        ConvGemmArgs a = base_args(e, p, e->pre[0], p.Pn);
         a.a0 = p.mu16; a.c0 = e->Mp; a.flags = GF_SILU; a.out16 = p.pre1;
         ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[0], p.Pn));
         HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
     }
     {
-        ConvGemmArgs a = base_args(p, e->pre[1], p.Pn);
+        ConvGemmArgs a = base_args(e, p, e->pre[1], p.Pn);
         a.a0 = p.pre1; a.c0 = e->F; a.flags = GF_SILU; a.out16 = p.pre2;
         ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[1], p.Pn));
         HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
     }
     {
-        ConvGemmArgs a = base_args(p, e->pre[2], p.Pn);
+        ConvGemmArgs a = base_args(e, p, e->pre[2], p.Pn);
         a.a0 = p.pre2; a.c0 = e->F; a.out16 = p.cond16;
         ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[2], p.Pn));
         HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
     }
     capture(e, "cond", p.cond16, (int64_t)p.Pn * p.T * e->C, true, s);
     {
-        ConvGemmArgs a = base_args(p, e->inc, p.Pn);
+        ConvGemmArgs a = base_args(e, p, e->inc, p.Pn);
         a.a0 = p.cond16; a.c0 = e->C; a.out32 = p.cpart;
         ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inc, p.Pn));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
@@ -350,7 +352,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
     const int64_t rowsC = (int64_t)N * T * C;
     const bool cap = e->capture;
     {   // in_proj: X = Wx.x + (Wc.cond + b); also the first long-skip (estimator.py:120-121,129)
-        ConvGemmArgs a = base_args(p, e->inx, N);
+        ConvGemmArgs a = base_args(e, p, e->inx, N);
         a.a0 = p.x16; a.c0 = e->Mp; a.a0_mod = p.B; a.bias = nullptr;
         a.add32 = p.cpart; a.add_clamp = p.B;
         a.out32 = p.X; a.out16 = p.skip16[0];
@@ -363,7 +365,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         const float* ada_i = p.ada + (size_t)i * N * 6 * C;
         if (i >= L / 2) {   // U-Net long skip merge (estimator.py:131-132)
             const int j = i - L / 2;
-            ConvGemmArgs a = base_args(p, e->lsc[j], N);
+            ConvGemmArgs a = base_args(e, p, e->lsc[j], N);
             a.a0 = p.cur16; a.c0 = C; a.a1 = p.skip16[L - 1 - i]; a.c1 = C;
             a.out32 = p.X;
             ProfScope ps(e, s, PC_LSC, conv_flops(p, e->lsc[j], N));
@@ -383,7 +385,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         }
         if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
         {   // q, k, v projections + RoPE (diffusion_transformer.py:59-61,74-75)
-            ConvGemmArgs a = base_args(p, e->qkv[i], N);
+            ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
             a.a0 = p.h16; a.c0 = C;
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
             a.Tp = p.Tp; a.n_heads = e->H;
@@ -404,7 +406,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         }
         if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
         {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111)
-            ConvGemmArgs a = base_args(p, e->oproj[i], N);
+            ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
@@ -420,14 +422,14 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         }
         if (cap) capture(e, bn + "h2", p.h16, rowsC, true, s);
         {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
-            ConvGemmArgs a = base_args(p, e->ffn1[i], N);
+            ConvGemmArgs a = base_args(e, p, e->ffn1[i], N);
             a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
             ProfScope ps(e, s, PC_FFN1, conv_flops(p, e->ffn1[i], N));
             HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
         }
         if (cap) capture(e, bn + "u", p.u16, (int64_t)N * T * F, true, s);
         {   // FFN conv_2, mask, gate, residual (diffusion_transformer.py:29-30,112)
-            ConvGemmArgs a = base_args(p, e->ffn2[i], N);
+            ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
             a.out16 = (i + 1 < L / 2) ? p.skip16[i + 1] : p.cur16;
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
@@ -436,7 +438,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         if (cap) capture(e, bn + "x3", p.X, rowsC, false, s);
     }
     {   // final projection (estimator.py:136-138); block output is already zero on padded frames
-        ConvGemmArgs a = base_args(p, e->fin, N);
+        ConvGemmArgs a = base_args(e, p, e->fin, N);
         a.a0 = p.cur16; a.c0 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
         ProfScope ps(e, s, PC_FINAL, conv_flops(p, e->fin, N));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
@@ -500,6 +502,11 @@ int st_create(const st_config* cfg, int device, st_engine** out) {
     e->C = cfg->hidden_channels; e->F = cfg->filter_channels; e->H = cfg->n_heads; e->L = cfg->n_layers;
     e->K = cfg->kernel_size; e->G = cfg->gin_channels;
     build_param_table(e);
+    if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
+        g_create_error = "hipMalloc failed";
+        delete e;
+        return ST_ERR_HIP;
+    }
     *out = e;
     return ST_OK;
 }
@@ -516,6 +523,7 @@ void st_destroy(st_engine* e) {
     if (e->ws) hipFree(e->ws);
     if (e->rope_cos) hipFree(e->rope_cos);
     if (e->rope_sin) hipFree(e->rope_sin);
+    if (e->zeros) hipFree(e->zeros);
     delete e;
 }
 

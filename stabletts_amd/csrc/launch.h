@@ -31,6 +31,7 @@ struct ConvGemmArgs {
     void* q; void* k; void* vt;
     const float* rope_cos; const float* rope_sin;   // [T][16]
     int Tp; float qscale; int n_heads;
+    const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
 };
 
 hipError_t launch_conv_gemm_bf16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
