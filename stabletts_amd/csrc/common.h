@@ -49,6 +49,12 @@ __device__ __forceinline__ typename P::vec8 as_vec8(uint4 v) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
+// SiLU on the hardware transcendental units (v_exp_f32 + v_rcp_f32, ~1 ulp each): used where the
+// result is rounded to a 16-bit MFMA operand anyway.  exp2 overflow (x << 0) gives rcp(inf) = 0.
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

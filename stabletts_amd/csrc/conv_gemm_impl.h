@@ -51,7 +51,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[kBC / kWC / 32][kB
                     v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w;
                 }
                 if constexpr (EPI == EPI_ACT16) {
-                    if (g.flags & GF_SILU) { v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3); }
+                    if (g.flags & GF_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
                     if (g.flags & GF_MASK) { v0 *= m; v1 *= m; v2 *= m; v3 *= m; }
                     if (tv) *(uint2*)((unsigned char*)g.out16 + (grow * g.cout + ch) * 2) = pack4<P>(v0, v1, v2, v3);
                 } else if constexpr (EPI == EPI_F32) {
@@ -123,7 +123,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[kBC / kWC / 32][kB
                 // V is stored transposed [head][d][Tp] (keys contiguous) for the PV MFMA operand;
                 // frames in [T, Tp) are written as zeros so attention can load whole 64-key tiles.
                 if (t < g.Tp) {
-                    typename P::elem* dst = (typename P::elem*)g.vt + ((size_t)n * H + head) * 64 * g.Tp + t;
+                    // key order inside each group of 16: bits 2 and 3 swapped (PV operand order, attention.hip)
+                    const int tpos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+                    typename P::elem* dst = (typename P::elem*)g.vt + ((size_t)n * H + head) * 64 * g.Tp + tpos;
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll

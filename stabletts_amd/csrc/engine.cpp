@@ -193,6 +193,7 @@ struct Plan {
     // fp32
     float *cpart, *X, *v32, *xstate, *kbuf[4], *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
     int *n_full, *kv_end;
+    float* kbias;
 };
 
 int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
@@ -235,6 +236,7 @@ int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
     want((void**)&p->ada, (size_t)L * N * 6 * C * 4);
     want((void**)&p->n_full, (size_t)B * 4);
     want((void**)&p->kv_end, (size_t)B * 4);
+    want((void**)&p->kbias, (size_t)B * p->Tp * 4);
     if (off > e->ws_cap) {
         if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
         HIPCHK(e, hipMalloc((void**)&e->ws, off));
@@ -399,7 +401,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         }
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
-            a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.mask = mask; a.mask_mod = p.B;
+            a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.kbias = p.kbias; a.mask_mod = p.B; a.zeros = e->zeros;
             a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
             ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
             HIPCHK(e, launch_attention(e->dt, a, s));
@@ -620,7 +622,7 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
     if ((rc = ensure_rope(e, T, s))) return rc;
     {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_mask_prep(mask, B, T, p.n_full, p.kv_end, s));
+        HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
         HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
         HIPCHK(e, launch_to_time_major(e->dt, x, B, e->M, T, e->Mp, nullptr, p.x16, s));
         HIPCHK(e, hipMemcpyAsync(p.cvec, c, (size_t)B * e->G * 4, hipMemcpyDeviceToDevice, s));
@@ -671,7 +673,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, hipMemcpyAsync(p.tvals, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, s));
         HIPCHK(e, hipStreamSynchronize(s));   // tv is a stack-lifetime host buffer
-        HIPCHK(e, launch_mask_prep(mask, B, T, p.n_full, p.kv_end, s));
+        HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
         HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
         HIPCHK(e, launch_to_time_major(e->dt, z, B, e->M, T, e->Mp, p.xstate, p.x16, s));
         HIPCHK(e, hipMemcpyAsync(p.cvec, c, (size_t)B * e->G * 4, hipMemcpyDeviceToDevice, s));

@@ -42,9 +42,10 @@ constexpr int kGemmChannelsPerTile = 128;
 // ---------------------------------------------------------------- attention
 struct AttnArgs {
     const void* q; const void* k; const void* vt; void* out;   // out: [item][T][H*64] 16-bit
-    const float* mask; int mask_mod;       // key validity [mask_mod][T]
+    const float* kbias; int mask_mod;      // additive key bias [mask_mod][Tp]: 0 valid, -1e30 masked / >= T
     const int* kv_end; const int* n_full;  // per mask row: last valid key + 1, leading valid prefix length
     int T, Tp, H, n_items;
+    const void* zeros;                     // >= 16 zero bytes in global memory (out-of-range K rows)
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 
@@ -66,7 +67,7 @@ hipError_t launch_time_embed(const float* t, int n_t, int dim, float* emb, hipSt
 // out[n][o] = act_out(bias[o] + sum_i W[o][i] * act_in(in[n][i]))
 hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
                          float* out, int silu_in, int silu_out, hipStream_t s);
-hipError_t launch_mask_prep(const float* mask, int B, int T, int* n_full, int* kv_end, hipStream_t s);
+hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, hipStream_t s);
 
 // (B, C, T) fp32 -> time-major (B, T, Cp): fp32 and/or 16-bit, channels >= C zero-filled; scale applied
 hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T, int Cp,

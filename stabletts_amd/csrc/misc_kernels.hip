@@ -102,17 +102,22 @@ hipError_t launch_linear(const float* in, int n, int k, const float* W, const fl
     return hipGetLastError();
 }
 
-// per mask row: n_full = length of the leading run of non-zeros, kv_end = last non-zero + 1
-__global__ __launch_bounds__(256) void mask_prep_kernel(const float* mask, int T, int* n_full, int* kv_end) {
+// per mask row: n_full = length of the leading run of non-zeros, kv_end = last non-zero + 1,
+// kbias[t] = 0 for valid keys, -1e30 for masked keys and for t in [T, Tp)
+__global__ __launch_bounds__(256) void mask_prep_kernel(const float* mask, int T, int Tp, int* n_full, int* kv_end,
+                                                        float* kbias) {
     __shared__ int s_first_zero, s_last_nz;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) { s_first_zero = T; s_last_nz = -1; }
     __syncthreads();
     int fz = T, ln = -1;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const bool nz = mask[(size_t)b * T + t] != 0.0f;
-        if (!nz && t < fz) fz = t;
-        if (nz && t > ln) ln = t;
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+        const bool nz = (t < T) && (mask[(size_t)b * T + t] != 0.0f);
+        kbias[(size_t)b * Tp + t] = nz ? 0.0f : -1e30f;
+        if (t < T) {
+            if (!nz && t < fz) fz = t;
+            if (nz && t > ln) ln = t;
+        }
     }
     atomicMin(&s_first_zero, fz);
     atomicMax(&s_last_nz, ln);
@@ -120,8 +125,8 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const float* mask, int T
     if (threadIdx.x == 0) { n_full[b] = s_first_zero; kv_end[b] = s_last_nz + 1; }
 }
 
-hipError_t launch_mask_prep(const float* mask, int B, int T, int* n_full, int* kv_end, hipStream_t s) {
-    hipLaunchKernelGGL(mask_prep_kernel, dim3(B), dim3(256), 0, s, mask, T, n_full, kv_end);
+hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, hipStream_t s) {
+    hipLaunchKernelGGL(mask_prep_kernel, dim3(B), dim3(256), 0, s, mask, T, Tp, n_full, kv_end, kbias);
     return hipGetLastError();
 }
 

@@ -65,7 +65,9 @@ def stage_check(dtype, B, T, lengths, seed, sd, t_val=0.37):
         cmp(b + "h1", eng.debug_fetch(b + "h1"), tm(taps[b + "h1"]))
         cmp(b + "q", eng.debug_fetch(b + "q"), (taps[b + "q"] * qs).numpy())
         cmp(b + "k", eng.debug_fetch(b + "k"), taps[b + "k"].numpy())
-        vt = eng.debug_fetch(b + "vt").reshape(B, 4, 64, Tp)[..., :T]
+        tt = np.arange(Tp)
+        pos = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)      # key order inside each group of 16
+        vt = eng.debug_fetch(b + "vt").reshape(B, 4, 64, Tp)[..., pos][..., :T]
         res[b + "vt"] = rel(vt, taps[b + "v"].numpy().transpose(0, 1, 3, 2))
         cmp(b + "attn", eng.debug_fetch(b + "attn"), tm(taps[b + "attn"]), only_valid=True)
         cmp(b + "x2", eng.debug_fetch(b + "x2"), tm(taps[b + "x2"]))
