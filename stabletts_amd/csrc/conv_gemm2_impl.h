@@ -1,0 +1,476 @@
+// Implicit-GEMM Conv1d (k = 1 or 3) for gfx950, second generation: LDS-DMA staged K loop (as
+// conv_gemm_impl.h) + an LDS-staged, fully coalesced epilogue that can carry the NEXT LayerNorm.
+//
+// Tile shapes (template): BC output channels x BF frames, WC x WF waves, wave tile (BC/WC) x (BF/WF)
+// built from 32x32x16 MFMA fragments.  Shipping configurations:
+//     T128 : 128 ch x 128 fr, 4 waves (2x2) of 64x64      -- 2 blocks/CU
+//     RC   : 256 ch x 128 fr, 8 waves (4x2) of 64x64      -- "row complete": a block owns all 256
+//            hidden channels of its frames, so the epilogue can apply FiLM + LayerNorm + adaLN modulate
+//            (the prologue of the next op in the reference: estimator.py:16, diffusion_transformer.py:111-112)
+//            and write the 16-bit MFMA operand of the next GEMM directly.
+// Epilogue: each wave parks its accumulator tile in LDS as [frame][channel] fp32 (conflict-free 16-B
+// stores, row pitch BC+4), then the block walks the tile one FRAME PER WAVE with lane = 4 channels: bias /
+// SiLU / mask / gate / residual / RoPE / FiLM / LayerNorm all run on contiguous 1 KB rows, and every
+// global access is a full-row coalesced 16-B (fp32) or 8-B (16-bit) per-lane transfer.
+#pragma once
+#include "common.h"
+#include "launch.h"
+#include <cstdlib>
+
+namespace st {
+
+typedef __attribute__((address_space(3))) void lds_void2_t;
+typedef __attribute__((address_space(1))) const void global_cvoid2_t;
+
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((global_cvoid2_t*)gsrc, (lds_void2_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BC, int BF, int WC, int WF, int TAPS>
+struct G2Cfg {
+    static constexpr int NW = WC * WF, NT = 64 * NW;
+    static constexpr int TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32;
+    static constexpr int AROWS = BF + TAPS - 1;
+    static constexpr int A_BYTES = AROWS * 128, W_BYTES = BC * 128;
+    static constexpr int PITCH = BC + 4;                       // fp32 words per staged frame row
+    static constexpr int STAGE_BYTES = TF * PITCH * 4;
+    static constexpr int LOOP_BYTES = 2 * A_BYTES + 2 * W_BYTES;
+    static constexpr int LDS_BYTES = LOOP_BYTES > STAGE_BYTES ? LOOP_BYTES : STAGE_BYTES;
+    static_assert((BC / 8) % NW == 0 && (BF / 8) % NW == 0, "DMA pieces must split evenly over the waves");
+};
+
+// ---- per-row epilogue ------------------------------------------------------------------------
+// Per-lane constants of a block: everything that depends only on (item, channel) is loaded ONCE, outside
+// the frame loop (stores in the loop would otherwise force the compiler to reload them every frame).
+struct G2Consts { float4 bias, gate, ga, be, sh, sc; };
+
+template <int EPI, bool LN>
+__device__ __forceinline__ G2Consts g2_consts(const ConvGemmArgs& g, int n, int ch) {
+    G2Consts k;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.bias = g.bias ? *(const float4*)(g.bias + ch) : z;
+    k.gate = z; k.ga = make_float4(1.f, 1.f, 1.f, 1.f); k.be = z; k.sh = z; k.sc = z;
+    if constexpr (EPI == EPI_RESGATE) k.gate = *(const float4*)(g.gate + (size_t)n * g.gate_stride + ch);
+    if constexpr (LN) {
+        if (g.ln_h16) {
+            if (g.ln_film) {
+                const float* f = g.ln_film + (size_t)(n % g.ln_film_mod) * g.ln_film_stride + ch;
+                k.ga = *(const float4*)f; k.be = *(const float4*)(f + 256);
+            }
+            const float* ad = g.ln_ada + (size_t)n * g.ln_ada_stride + ch;
+            k.sh = *(const float4*)(ad + g.ln_shift_off); k.sc = *(const float4*)(ad + g.ln_scale_off);
+        }
+    }
+    return k;
+}
+
+// Handles 4 consecutive channels [ch, ch+4) of frame t of item n.  v = accumulator values, m = mask value of
+// the frame, xin = preloaded residual row (EPI_RESGATE) or addend row (EPI_F32 with add32).  LN = the wave
+// holds one complete 256-channel row, so FiLM + LayerNorm + modulate of the next op can be applied.
+template <class P, int EPI, bool LN>
+__device__ __forceinline__ void g2_apply(const ConvGemmArgs& g, const G2Consts& k, int n, int t, int ch, float4 v,
+                                         float m, float4 xin) {
+    const size_t grow = (size_t)n * g.T + t;
+    v.x += k.bias.x; v.y += k.bias.y; v.z += k.bias.z; v.w += k.bias.w;
+    if constexpr (EPI == EPI_ACT16) {
+        if (g.flags & GF_SILU) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+        if (g.flags & GF_MASK) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+        *(uint2*)((unsigned char*)g.out16 + (grow * g.cout + ch) * 2) = pack4<P>(v.x, v.y, v.z, v.w);
+    } else {
+        if constexpr (EPI == EPI_F32) {
+            v.x += xin.x; v.y += xin.y; v.z += xin.z; v.w += xin.w;
+            if (g.flags & GF_MASK) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+        } else {   // EPI_RESGATE: x + gate * ((acc + b) * mask)
+            v.x = xin.x + k.gate.x * (v.x * m); v.y = xin.y + k.gate.y * (v.y * m);
+            v.z = xin.z + k.gate.z * (v.z * m); v.w = xin.w + k.gate.w * (v.w * m);
+        }
+        if (g.out16) *(uint2*)((unsigned char*)g.out16 + (grow * g.cout + ch) * 2) = pack4<P>(v.x, v.y, v.z, v.w);
+        if constexpr (LN) {
+            if (g.ln_h16) {
+                // the next op's prologue: FiLM (estimator.py:31-33,16), LayerNorm, adaLN modulate
+                if (g.ln_film) {
+                    v.x = (k.ga.x * v.x + k.be.x) * m; v.y = (k.ga.y * v.y + k.be.y) * m;
+                    v.z = (k.ga.z * v.z + k.be.z) * m; v.w = (k.ga.w * v.w + k.be.w) * m;
+                }
+                if (g.out32) *(float4*)(g.out32 + grow * g.cout + ch) = v;
+                const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                float h0 = d0 * rstd * (1.0f + k.sc.x) + k.sh.x, h1 = d1 * rstd * (1.0f + k.sc.y) + k.sh.y;
+                float h2 = d2 * rstd * (1.0f + k.sc.z) + k.sh.z, h3 = d3 * rstd * (1.0f + k.sc.w) + k.sh.w;
+                if (g.ln_mask_out) { h0 *= m; h1 *= m; h2 *= m; h3 *= m; }
+                *(uint2*)((unsigned char*)g.ln_h16 + (grow * 256 + ch) * 2) = pack4<P>(h0, h1, h2, h3);
+                return;
+            }
+        }
+        if (g.out32) *(float4*)(g.out32 + grow * g.cout + ch) = v;
+    }
+}
+
+// LDS-staged epilogue shared by the gen-2 kernels.  fvalid = number of valid frame columns of the tile
+// (BF, or BF-2 for the 3-buffer k=3 kernel whose activation tile includes its own halo).
+template <class P, int EPI, int BC, int BF, int WC, int WF>
+__device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], float* stage, const ConvGemmArgs& g,
+                                            int n, int t0, int fvalid, int cbase, int wave, int lane) {
+    constexpr int NW = WC * WF, TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32, PITCH = BC + 4;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int T = g.T;
+    static_assert(EPI != EPI_QKV, "the QKV epilogue lives in conv_gemm_impl.h");
+    static_assert(BC == 128 || BC == 256, "row walker handles 128 or 256 channels");
+    constexpr bool LN = (BC == 256);
+    constexpr int RPW = LN ? TF / NW : TF / (2 * NW);        // wave-rows (1 or 2 frames each) per wave per pass
+    const int chl = LN ? lane * 4 : l31 * 4;                 // this lane's channel quad inside the block tile
+    const G2Consts kc = g2_consts<EPI, LN>(g, n, cbase + chl);
+    const float* mrow = g.mask ? g.mask + (size_t)(n % g.mask_mod) * T : nullptr;
+    const int an = n < g.add_clamp ? n : g.add_clamp;
+#pragma unroll 1
+    for (int p = 0; p < WF; ++p) {
+        if (wf == p) {
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FF; ++b)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int fl = b * 32 + l31;
+                        const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
+                        *(float4*)(stage + fl * PITCH + ch) = make_float4(acc[a][b][4 * q4 + 0], acc[a][b][4 * q4 + 1],
+                                                                          acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]);
+                    }
+        }
+        __syncthreads();
+        const int tbase = t0 + p * TF;
+        // all global inputs of this wave's rows are requested first (memory latency overlaps across rows) ...
+        float mk[RPW]; float4 xin[RPW]; int fr[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int f = LN ? (wave + u * NW) : ((wave + u * NW) * 2 + hi);
+            const int t = tbase + f;
+            fr[u] = f;
+            const bool ok = (t < T) && (p * TF + f < fvalid);
+            mk[u] = (ok && mrow) ? mrow[t] : (ok ? 1.0f : 0.0f);
+            xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)(g.out32 + ((size_t)n * T + t) * g.cout + cbase + chl);
+                if constexpr (EPI == EPI_F32) { if (g.add32) xin[u] = *(const float4*)(g.add32 + ((size_t)an * T + t) * g.cout + cbase + chl); }
+            }
+        }
+        // ... then each row is finished from LDS
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int t = tbase + fr[u];
+            const float4 v = *(const float4*)(stage + fr[u] * PITCH + chl);
+            const bool ok = (t < T) && (p * TF + fr[u] < fvalid);
+            if (LN) { if (ok) g2_apply<P, EPI, true>(g, kc, n, t, cbase + chl, v, mk[u], xin[u]); }   // wave-uniform branch
+            else    { if (ok) g2_apply<P, EPI, false>(g, kc, n, t, cbase + chl, v, mk[u], xin[u]); }
+        }
+        __syncthreads();
+    }
+}
+
+template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF>
+__global__ __launch_bounds__(64 * WC * WF, (64 * WC * WF) == 256 ? 2 : 2)
+void conv_gemm2_kernel(const ConvGemmArgs g) {
+    using vec8 = typename P::vec8;
+    using K = G2Cfg<BC, BF, WC, WF, TAPS>;
+    constexpr int NW = K::NW, NT = K::NT, FC = K::FC, FF = K::FF, TC = K::TC, TF = K::TF;
+    constexpr int A_BYTES = K::A_BYTES, W_BYTES = K::W_BYTES, PITCH = K::PITCH;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Ws = smem + 2 * A_BYTES;
+    float* stage = (float*)smem;
+
+    const int total = g.n_items * g.tiles_f * g.tiles_c;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int tc = lin % g.tiles_c;
+    const int rest = lin / g.tiles_c;
+    const int tf = rest % g.tiles_f;
+    const int n = rest / g.tiles_f;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int cbase = tc * BC, t0 = tf * BF;
+    const int cin = g.c0 + g.c1;
+    const int nch = cin >> 6;
+    const int T = g.T;
+
+    const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
+    const unsigned char* a1 = g.c1 ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;
+    const unsigned char* wsrc = (const unsigned char*)g.w;
+    const unsigned char* zeros = (const unsigned char*)g.zeros;
+
+    const int prow = lane >> 3;
+    auto issueW = [&](int c, int j, int buf) {
+#pragma unroll
+        for (int k = 0; k < (BC / 8) / NW; ++k) {
+            const int piece = wave * ((BC / 8) / NW) + k;
+            const int row = piece * 8 + prow;
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned char* src = wsrc + ((size_t)((cbase + row) * TAPS + j) * cin + (c << 6)) * 2 + seg * 16;
+            glds16b(src, Ws + buf * W_BYTES + piece * 1024);
+        }
+    };
+    auto issueA = [&](int c, int buf) {
+        const int ch0 = c << 6;
+        const unsigned char* srcb; int cs, coff;
+        if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
+        else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
+#pragma unroll
+        for (int k = 0; k < (BF / 8) / NW; ++k) {
+            const int piece = wave * ((BF / 8) / NW) + k;
+            const int row = piece * 8 + prow;
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const int t = t0 + row - (TAPS / 2);
+            const unsigned char* src = (t >= 0 && t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
+            glds16b(src, As + buf * A_BYTES + piece * 1024);
+        }
+        if constexpr (TAPS == 3) {
+            if (wave == 0 && lane < 16) {          // halo rows BF, BF+1
+                const int row = BF + prow;
+                const int seg = (lane & 7) ^ ((row >> 1) & 7);
+                const int t = t0 + row - 1;
+                const unsigned char* src = (t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
+                glds16b(src, As + buf * A_BYTES + (BF / 8) * 1024);
+            }
+        }
+    };
+
+    f32x16_t acc[FC][FF];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FF; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    int wrow_off[FC], wswz[FC];
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+        const int row = wc * TC + a * 32 + l31;
+        wrow_off[a] = row * 128; wswz[a] = (row >> 1) & 7;
+    }
+    auto compute = [&](int abuf, int wbuf, int j) {
+        const unsigned char* Ab = As + abuf * A_BYTES;
+        const unsigned char* Wb = Ws + wbuf * W_BYTES;
+        int arow_off[FF], aswz[FF];
+#pragma unroll
+        for (int b = 0; b < FF; ++b) {
+            const int row = wf * TF + b * 32 + l31 + j;
+            arow_off[b] = row * 128; aswz[b] = (row >> 1) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            vec8 wfr[FC], afr[FF];
+            const int seg = ks * 2 + hi;
+#pragma unroll
+            for (int a = 0; a < FC; ++a) wfr[a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
+#pragma unroll
+            for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+        }
+    };
+
+    issueA(0, 0); issueW(0, 0, 0);
+    __syncthreads();
+    int it = 0;
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) {
+            const bool last = (c == nch - 1) && (j == TAPS - 1);
+            if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
+            if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
+            compute(c & 1, it & 1, j);
+            __syncthreads();
+            ++it;
+        }
+    }
+
+    g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BF, cbase, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// k = 3 convolution, 128 channels x 126 frames per block, THREE weight buffers: the LDS-DMA of stage g+2 is
+// issued at the top of stage g and only a COUNTED s_waitcnt (never vmcnt(0)) + raw s_barrier separate the
+// stages, so the DMA of a whole stage stays in flight across each barrier.  The activation tile is exactly
+// 128 rows = frames t0-1 .. t0+126 (126 valid output frames + its own halo), which makes the footprint
+// 2*16 KB (A) + 3*16 KB (W) = 80 KB: two blocks per CU.  Frame columns 126,127 of the accumulator read two
+// rows past the A tile (harmless garbage inside the block's own LDS) and are discarded by the epilogue.
+template <class P, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g) {
+    using vec8 = typename P::vec8;
+    constexpr int BC = 128, BF = 128, BFV = 126, WC = 2, WF = 2, TC = 64, TF = 64, FC = 2, FF = 2;
+    constexpr int A_BYTES = 128 * 128, W_BYTES = 128 * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                    // 2 buffers
+    unsigned char* Ws = smem + 2 * A_BYTES;      // 3 buffers
+
+    const int total = g.n_items * g.tiles_f * g.tiles_c;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int tc = lin % g.tiles_c;
+    const int rest = lin / g.tiles_c;
+    const int tf = rest % g.tiles_f;
+    const int n = rest / g.tiles_f;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int cbase = tc * BC, t0 = tf * BFV;
+    const int cin = g.c0 + g.c1;
+    const int nch = cin >> 6;
+    const int nst = nch * 3;
+    const int T = g.T;
+
+    const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
+    const unsigned char* a1 = g.c1 ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;
+    const unsigned char* wsrc = (const unsigned char*)g.w;
+    const unsigned char* zeros = (const unsigned char*)g.zeros;
+
+    const int prow = lane >> 3;
+    auto issueW = [&](int c, int j, int buf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int piece = wave * 4 + k;
+            const int row = piece * 8 + prow;
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned char* src = wsrc + ((size_t)((cbase + row) * 3 + j) * cin + (c << 6)) * 2 + seg * 16;
+            glds16b(src, Ws + buf * W_BYTES + piece * 1024);
+        }
+    };
+    auto issueA = [&](int c, int buf) {
+        const int ch0 = c << 6;
+        const unsigned char* srcb; int cs, coff;
+        if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
+        else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int piece = wave * 4 + k;
+            const int row = piece * 8 + prow;
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const int t = t0 + row - 1;
+            const unsigned char* src = (t >= 0 && t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
+            glds16b(src, As + buf * A_BYTES + piece * 1024);
+        }
+    };
+
+    f32x16_t acc[FC][FF];
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int b = 0; b < FF; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    int wrow_off[FC], wswz[FC];
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+        const int row = wc * TC + a * 32 + l31;
+        wrow_off[a] = row * 128; wswz[a] = (row >> 1) & 7;
+    }
+    auto compute = [&](int abuf, int wbuf, int j) {
+        const unsigned char* Ab = As + abuf * A_BYTES;
+        const unsigned char* Wb = Ws + wbuf * W_BYTES;
+        int arow_off[FF], aswz[FF];
+#pragma unroll
+        for (int b = 0; b < FF; ++b) {
+            const int row = wf * TF + b * 32 + l31 + j;      // rows 128,129 (last two frame columns) fall into the next buffer
+            arow_off[b] = row * 128; aswz[b] = (row >> 1) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            vec8 wfr[FC], afr[FF];
+            const int seg = ks * 2 + hi;
+#pragma unroll
+            for (int a = 0; a < FC; ++a) wfr[a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
+#pragma unroll
+            for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+        }
+    };
+    // counted wait: everything except the youngest `keep` LDS-DMA instructions of this wave has landed
+    auto wait_keep = [&](int keep) {
+        if (keep >= 8)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    issueA(0, 0); issueW(0, 0, 0);
+    if (nst > 1) issueW(0, 1, 1);
+    wait_keep(0);
+    __builtin_amdgcn_s_barrier();
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int gi = c * 3 + j;
+            int younger = 0;
+            if (j == 0 && c + 1 < nch) { issueA(c + 1, (c + 1) & 1); younger += 4; }
+            if (gi + 2 < nst) {
+                if (j == 0) issueW(c, 2, 2); else issueW(c + 1, j - 1, j - 1);     // stage g+2 lives in buffer (g+2) % 3
+                younger += 4;
+            }
+            compute(c & 1, j, j);
+            // stage g+1 needs W(g+1) (issued one stage ago) and, at j == 2, A(c+1) (issued at j == 0): both are
+            // older than what this stage issued, except A(c+1) at j == 0 which is not needed before stage (c+1, 0)
+            wait_keep(younger);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
+}
+
+template <class P, int EPI>
+static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
+    constexpr int lds = 5 * 128 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm3_kernel<P, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (!a.zeros || (a.cout % 128) != 0 || ((a.c0 + a.c1) & 63) != 0) return hipErrorInvalidValue;
+    ConvGemmArgs b = a;
+    b.tiles_f = (a.T + 125) / 126;
+    b.tiles_c = a.cout / 128;
+    const int total = b.n_items * b.tiles_f * b.tiles_c;
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL((conv_gemm3_kernel<P, EPI>), dim3(grid), dim3(256), lds, s, b);
+    return hipGetLastError();
+}
+
+template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF>
+static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
+    using K = G2Cfg<BC, BF, WC, WF, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 + a.c1) & 63) != 0) return hipErrorInvalidValue;
+    ConvGemmArgs b = a;
+    b.tiles_f = (a.T + BF - 1) / BF;
+    b.tiles_c = a.cout / BC;
+    const int total = b.n_items * b.tiles_f * b.tiles_c;
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL((conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>), dim3(grid), dim3(K::NT), K::LDS_BYTES, s, b);
+    return hipGetLastError();
+}
+
+}  // namespace st

@@ -1,0 +1,26 @@
+// Instantiation list of the second-generation conv GEMM for one operand type (included by the two
+// conv_gemm2_<dtype>.hip translation units).
+#pragma once
+#include "conv_gemm2_impl.h"
+
+namespace st {
+
+// cfg 0: T128 (128 ch x 128 frames, 4 waves)   cfg 1: RC (256 ch x 128 frames, 8 waves, LayerNorm-capable)
+template <class P>
+static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
+    if (cfg == 0) {
+        if (taps == 3 && epi == EPI_ACT16) return launch_g2<P, 3, EPI_ACT16, 128, 128, 2, 2>(a, s);
+        if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 128, 128, 2, 2>(a, s);
+        if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 128, 128, 2, 2>(a, s);
+        if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 128, 128, 2, 2>(a, s);
+        if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 128, 128, 2, 2>(a, s);
+    } else if (cfg == 1) {
+        if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 256, 128, 4, 2>(a, s);
+        if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 256, 128, 4, 2>(a, s);
+        if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 256, 128, 4, 2>(a, s);
+        if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 256, 128, 4, 2>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace st

@@ -398,8 +398,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
     __builtin_amdgcn_global_load_lds((global_cvoid_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-template <class P, int TAPS, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmArgs g) {
+// OPT (experiments, tools/gemm_bench): 1 = s_setprio around the MFMA cluster, 2 = no LDS-DMA in the loop,
+// 4 = no MFMA, 8 = single activation buffer + 3 blocks/CU (racy: timing only).
+template <class P, int TAPS, int EPI, int OPT = 0>
+__global__ __launch_bounds__(256, (OPT & 8) ? 3 : 2) void conv_gemm_glds_kernel(const ConvGemmArgs g) {
     using vec8 = typename P::vec8;
     constexpr int BC = kBC, BF = kBF, WC = kWC, WF = kWF;
     constexpr int AROWS = BF + TAPS - 1;
@@ -409,8 +411,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
     static_assert(BC == 128 && BF == 128 && WC * WF == 4, "tile constants");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ABUFS = (OPT & 8) ? 1 : 2;
     unsigned char* As = smem;
-    unsigned char* Ws = smem + 2 * A_BYTES;
+    unsigned char* Ws = smem + ABUFS * A_BYTES;
 
     const int total = g.n_items * g.tiles_f * g.tiles_c;
     const int per_xcd = gridDim.x >> 3;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const int t = t0 + row - (TAPS / 2);
             const unsigned char* src = (t >= 0 && t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
-            glds16(src, As + buf * A_BYTES + piece * 1024);
+            glds16(src, As + (buf % ABUFS) * A_BYTES + piece * 1024);
         }
         if constexpr (TAPS == 3) {
             // halo rows 128, 129: one partial piece (16 lanes) issued by wave 0
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
                 const int seg = (lane & 7) ^ ((row >> 1) & 7);
                 const int t = t0 + row - 1;
                 const unsigned char* src = (t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
-                glds16(src, As + buf * A_BYTES + 16 * 1024);
+                glds16(src, As + (buf % ABUFS) * A_BYTES + 16 * 1024);
             }
         }
     };
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
         wrow_off[a] = row * 128; wswz[a] = (row >> 1) & 7;
     }
     auto compute = [&](int abuf, int wbuf, int j) {
-        const unsigned char* Ab = As + abuf * A_BYTES;
+        const unsigned char* Ab = As + (abuf % ABUFS) * A_BYTES;
         const unsigned char* Wb = Ws + wbuf * W_BYTES;
         int arow_off[FF], aswz[FF];
 #pragma unroll
@@ -506,10 +509,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
             for (int a = 0; a < FC; ++a) wfr[a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
 #pragma unroll
             for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
+            if constexpr ((OPT & 4) != 0) {
 #pragma unroll
-            for (int a = 0; a < FC; ++a)
+                for (int a = 0; a < FC; ++a) asm volatile("" :: "v"(wfr[a]));
 #pragma unroll
-                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+                for (int b = 0; b < FF; ++b) asm volatile("" :: "v"(afr[b]));
+            } else {
+                if constexpr ((OPT & 1) != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int a = 0; a < FC; ++a)
+#pragma unroll
+                    for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+                if constexpr ((OPT & 1) != 0) __builtin_amdgcn_s_setprio(0);
+            }
         }
     };
 
@@ -520,8 +532,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) {
             const bool last = (c == nch - 1) && (j == TAPS - 1);
-            if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
-            if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
+            if constexpr ((OPT & 2) == 0) {
+                if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
+                if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
+            }
             compute(c & 1, it & 1, j);
             __syncthreads();      // drains the LDS-DMA (vmcnt(0)) and fences the buffer swap
             ++it;
@@ -530,13 +544,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvGemmAr
     conv_epilogue<P, EPI>(acc, g, n, t0, cbase, wc, wf, l31, hi);
 }
 
-template <class P, int TAPS, int EPI>
+template <class P, int TAPS, int EPI, int OPT = 0>
 static hipError_t launch_glds(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int AROWS = kBF + TAPS - 1;
-    constexpr int lds = 2 * AROWS * 128 + 2 * kBC * 128;
+    constexpr int lds = ((OPT & 8) ? 1 : 2) * AROWS * 128 + 2 * kBC * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<P, TAPS, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<P, TAPS, EPI, OPT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_done = true;
@@ -544,7 +558,7 @@ static hipError_t launch_glds(const ConvGemmArgs& a, hipStream_t s) {
     if (!a.zeros) return hipErrorInvalidValue;
     const int total = a.n_items * a.tiles_f * a.tiles_c;
     const int grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL((conv_gemm_glds_kernel<P, TAPS, EPI>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<P, TAPS, EPI, OPT>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

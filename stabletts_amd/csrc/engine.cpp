@@ -138,8 +138,21 @@ void build_param_table(st_engine* e) {
 
 const float* P(st_engine* e, const std::string& name) { return e->params.at(name).dev; }
 
+// ST_GEMM_GEN=1 selects the first-generation kernels + separate FiLM/LayerNorm launches (A/B, debugging)
+bool use_gen2() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("ST_GEMM_GEN"); v = (s && atoi(s) == 1) ? 0 : 1; }
+    return v == 1;
+}
+
 hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
-    return e->dt == DT_BF16 ? launch_conv_gemm_bf16(taps, epi, a, s) : launch_conv_gemm_f16(taps, epi, a, s);
+    const bool bf = e->dt == DT_BF16;
+    if (use_gen2() && epi != EPI_QKV) {
+        // row-complete tiles where the epilogue carries the next FiLM + LayerNorm, 128x128 tiles otherwise
+        const int cfg = a.ln_h16 ? G2_RC : G2_T128;
+        return bf ? launch_conv_gemm2_bf16(cfg, taps, epi, a, s) : launch_conv_gemm2_f16(cfg, taps, epi, a, s);
+    }
+    return bf ? launch_conv_gemm_bf16(taps, epi, a, s) : launch_conv_gemm_f16(taps, epi, a, s);
 }
 
 // ---- profiling helpers -----------------------------------------------------------------------
@@ -349,42 +362,65 @@ int run_time_tables(st_engine* e, const Plan& p, hipStream_t s) {
 
 // One vector-field evaluation over N items given x16 (B items), cpart, ada, film.  Output p.v32.
 // ev: index into the time tables (scalar t shared by all items) or -1 for per-item t (n_t == B).
+// With the second-generation GEMMs (default) every FiLM + LayerNorm + modulate runs inside the epilogue of
+// the GEMM that produces its input (row-complete tiles); ST_GEMM_GEN=1 keeps them as separate launches.
 int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStream_t s) {
     const int C = e->C, F = e->F, L = e->L, N = p.N, T = p.T;
     const int64_t rowsC = (int64_t)N * T * C;
     const bool cap = e->capture;
+    // measured on MI355X (profiles/): fused FiLM+LN epilogues on row-complete tiles are a wash against the faster
+    // 128x128 tiles + separate LayerNorm launches (38.2 vs 38.0 ms/solve), so fusion is opt-in: ST_FUSE_LN=1
+    static const bool fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v && atoi(v) == 1; }();
+    const bool fuse = use_gen2() && fuse_env;
+    auto ada_of = [&](int i) { return p.ada + (size_t)i * N * 6 * C; };
+    // FiLM_i + LN1_i + modulate (start of block i) fused into the producing GEMM
+    auto fuse_ln1 = [&](ConvGemmArgs& a, int i) {
+        const float* fb = p.film + (size_t)i * p.n_t * 2 * C;
+        if (ev >= 0) { a.ln_film = fb + (size_t)ev * 2 * C; a.ln_film_stride = 0; a.ln_film_mod = 1; }
+        else         { a.ln_film = fb; a.ln_film_stride = 2 * C; a.ln_film_mod = p.B; }
+        a.ln_ada = ada_of(i); a.ln_ada_stride = 6 * C; a.ln_shift_off = 0; a.ln_scale_off = C;
+        a.ln_mask_out = 0; a.ln_h16 = p.h16; a.mask = mask;
+    };
+    auto film_ln1 = [&](int i) -> int {      // separate launch (first-generation path)
+        FilmLnArgs a; memset(&a, 0, sizeof(a));
+        a.X = p.X; a.h16 = p.h16;
+        const float* fb = p.film + (size_t)i * p.n_t * 2 * C;
+        if (ev >= 0) { a.film = fb + (size_t)ev * 2 * C; a.film_stride = 0; a.film_mod = 1; }
+        else         { a.film = fb; a.film_stride = 2 * C; a.film_mod = p.B; }
+        a.ada = ada_of(i); a.ada_stride = 6 * C; a.shift_off = 0; a.scale_off = C;
+        a.mask = mask; a.mask_mod = p.B; a.mask_out = 0; a.T = T; a.rows = N * T;
+        ProfScope ps(e, s, PC_FILM_LN1, 0);
+        HIPCHK(e, launch_film_ln(e->dt, a, s));
+        return ST_OK;
+    };
+    int rc;
     {   // in_proj: X = Wx.x + (Wc.cond + b); also the first long-skip (estimator.py:120-121,129)
         ConvGemmArgs a = base_args(e, p, e->inx, N);
         a.a0 = p.x16; a.c0 = e->Mp; a.a0_mod = p.B; a.bias = nullptr;
         a.add32 = p.cpart; a.add_clamp = p.B;
         a.out32 = p.X; a.out16 = p.skip16[0];
+        if (fuse) fuse_ln1(a, 0);
         ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inx, N));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
-    if (cap) capture(e, "h0", p.X, rowsC, false, s);
+    if (cap) {
+        if (fuse) capture(e, "h0", p.skip16[0], rowsC, true, s);
+        else capture(e, "h0", p.X, rowsC, false, s);
+    }
     for (int i = 0; i < L; ++i) {
         const std::string bn = "b" + std::to_string(i) + ".";
-        const float* ada_i = p.ada + (size_t)i * N * 6 * C;
+        const float* ada_i = ada_of(i);
         if (i >= L / 2) {   // U-Net long skip merge (estimator.py:131-132)
             const int j = i - L / 2;
             ConvGemmArgs a = base_args(e, p, e->lsc[j], N);
             a.a0 = p.cur16; a.c0 = C; a.a1 = p.skip16[L - 1 - i]; a.c1 = C;
             a.out32 = p.X;
+            if (fuse) fuse_ln1(a, i);
             ProfScope ps(e, s, PC_LSC, conv_flops(p, e->lsc[j], N));
             HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
-            if (cap) capture(e, "lsc" + std::to_string(j), p.X, rowsC, false, s);
+            if (cap && !fuse) capture(e, "lsc" + std::to_string(j), p.X, rowsC, false, s);
         }
-        {   // FiLM, mask, LN1, modulate
-            FilmLnArgs a; memset(&a, 0, sizeof(a));
-            a.X = p.X; a.h16 = p.h16;
-            const float* fb = p.film + (size_t)i * p.n_t * 2 * C;
-            if (ev >= 0) { a.film = fb + (size_t)ev * 2 * C; a.film_stride = 0; a.film_mod = 1; }
-            else         { a.film = fb; a.film_stride = 2 * C; a.film_mod = p.B; }
-            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 0; a.scale_off = C;
-            a.mask = mask; a.mask_mod = p.B; a.mask_out = 0; a.T = T; a.rows = N * T;
-            ProfScope ps(e, s, PC_FILM_LN1, 0);
-            HIPCHK(e, launch_film_ln(e->dt, a, s));
-        }
+        if (!fuse && (rc = film_ln1(i))) return rc;      // FiLM, mask, LN1, modulate
         if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
         {   // q, k, v projections + RoPE (diffusion_transformer.py:59-61,74-75)
             ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
@@ -407,14 +443,18 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
         if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
-        {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111)
+        {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111) [+ LN2, modulate, mask]
             ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
+            if (fuse) {
+                a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
+                a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
+            }
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
         if (cap) capture(e, bn + "x2", p.X, rowsC, false, s);
-        {   // LN2 + modulate, masked (FFN input, diffusion_transformer.py:112,26)
+        if (!fuse) {   // LN2 + modulate, masked (FFN input, diffusion_transformer.py:112,26)
             FilmLnArgs a; memset(&a, 0, sizeof(a));
             a.X = p.X; a.h16 = p.h16; a.film = nullptr; a.film_mod = 1;
             a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
@@ -430,14 +470,19 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
         }
         if (cap) capture(e, bn + "u", p.u16, (int64_t)N * T * F, true, s);
-        {   // FFN conv_2, mask, gate, residual (diffusion_transformer.py:29-30,112)
+        void* copy16 = (i + 1 < L / 2) ? p.skip16[i + 1] : p.cur16;
+        {   // FFN conv_2, mask, gate, residual (diffusion_transformer.py:29-30,112) [+ FiLM/LN1 of block i+1]
             ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
-            a.out16 = (i + 1 < L / 2) ? p.skip16[i + 1] : p.cur16;
+            a.out16 = copy16;
+            if (fuse && i + 1 < L / 2) fuse_ln1(a, i + 1);     // blocks >= L/2 start with the long-skip conv instead
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
             HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }
-        if (cap) capture(e, bn + "x3", p.X, rowsC, false, s);
+        if (cap) {
+            if (fuse && i + 1 < L / 2) capture(e, bn + "x3", copy16, rowsC, true, s);   // X already holds the FiLM'd value
+            else capture(e, bn + "x3", p.X, rowsC, false, s);
+        }
     }
     {   // final projection (estimator.py:136-138); block output is already zero on padded frames
         ConvGemmArgs a = base_args(e, p, e->fin, N);

@@ -32,10 +32,21 @@ struct ConvGemmArgs {
     const float* rope_cos; const float* rope_sin;   // [T][16]
     int Tp; float qscale; int n_heads;
     const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
+    // fused prologue of the NEXT op (row-complete tiles, cout == 256): FiLM -> *mask -> LayerNorm -> modulate.
+    // When ln_h16 != nullptr, out32 receives the post-FiLM residual stream and ln_h16 the 16-bit operand.
+    void* ln_h16;
+    const float* ln_film; int ln_film_stride; int ln_film_mod;     // gamma = film[(n%mod)*stride + ch], beta = +256
+    const float* ln_ada; int ln_ada_stride; int ln_shift_off; int ln_scale_off;
+    int ln_mask_out;
 };
 
 hipError_t launch_conv_gemm_bf16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 hipError_t launch_conv_gemm_f16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
+// second generation (conv_gemm2_impl.h): cfg 0 = 128x128 tile, cfg 1 = row-complete 256x128 tile (cout % 256 == 0,
+// may carry the fused FiLM + LayerNorm + modulate of the next op through the ln_* fields)
+enum { G2_T128 = 0, G2_RC = 1 };
+hipError_t launch_conv_gemm2_bf16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
+hipError_t launch_conv_gemm2_f16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 

@@ -74,58 +74,41 @@ static void run_shape(const char* name, int items, int T, int c0, int c1, int co
     }
     { void* z; CK(hipMalloc(&z, 256)); CK(hipMemset(z, 0, 256)); a.zeros = z; }
     const double flops = 2.0 * rows * cout * (double)cin * TAPS;
-    // correctness: variants must agree bitwise
+    // correctness: LDS-DMA kernel vs the register-staged reference variant (bitwise: same accumulation order)
     CK(hipMemset(a.out16, 0, out16_bytes)); CK(hipMemset(a.out32, 0, out32_bytes));
     CK((launch_var<OpBF16, TAPS, EPI, 0>(a, nullptr))); CK(hipDeviceSynchronize());
     auto r16 = fetch(EPI == EPI_QKV ? a.q : a.out16, EPI == EPI_QKV ? rows * (cout / 3) * 2 : out16_bytes);
     auto r32 = fetch(a.out32, out32_bytes);
     CK(hipMemset(a.out16, 0, out16_bytes)); CK(hipMemset(a.out32, 0, out32_bytes));
-    CK((launch_var<OpBF16, TAPS, EPI, 1>(a, nullptr))); CK(hipDeviceSynchronize());
-    auto s16 = fetch(EPI == EPI_QKV ? a.q : a.out16, EPI == EPI_QKV ? rows * (cout / 3) * 2 : out16_bytes);
-    auto s32 = fetch(a.out32, out32_bytes);
-    const bool same = (r16 == s16) && (r32 == s32);
-    CK(hipMemset(a.out16, 0, out16_bytes)); CK(hipMemset(a.out32, 0, out32_bytes));
-    CK((launch_glds<OpBF16, TAPS, EPI>(a, nullptr))); CK(hipDeviceSynchronize());
+    CK((launch_glds<OpBF16, TAPS, EPI, 0>(a, nullptr))); CK(hipDeviceSynchronize());
     auto g16 = fetch(EPI == EPI_QKV ? a.q : a.out16, EPI == EPI_QKV ? rows * (cout / 3) * 2 : out16_bytes);
     auto g32 = fetch(a.out32, out32_bytes);
-    const bool same_glds = (r16 == g16) && (r32 == g32);
-    {
-        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        float bestg = 1e9f;
+    const bool same = (r16 == g16) && (r32 == g32);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](auto launch) {
+        float best = 1e9f;
         for (int r = 0; r < 3; ++r) {
-            for (int i = 0; i < 2; ++i) CK((launch_glds<OpBF16, TAPS, EPI>(a, nullptr)));
+            for (int i = 0; i < 2; ++i) CK(launch());
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < reps; ++i) CK((launch_glds<OpBF16, TAPS, EPI>(a, nullptr)));
+            for (int i = 0; i < reps; ++i) CK(launch());
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); bestg = fminf(bestg, ms / reps);
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = fminf(best, ms / reps);
         }
-        printf("%-8s GLDS  K=%4dx%d N=%4d  min %8.1f us  %7.1f TF/s  %s\n", name, cin, TAPS, cout, bestg * 1e3,
-               flops / (bestg * 1e-3) / 1e12, same_glds ? "bitwise==var0" : "MISMATCH vs var0");
-    }
-    // interleaved timing rounds (guide rule 24); variants 2-4 are ablations (wrong results, timing only)
-    constexpr int NV = 10;
-    float best[NV], sum[NV];
-    for (int v = 0; v < NV; ++v) { best[v] = 1e9f; sum[v] = 0; }
-    const int rounds = 3;
-    for (int r = 0; r < rounds; ++r) {
-        float t[NV];
-        t[0] = time_variant<TAPS, EPI, 0>(a, reps);
-        t[1] = time_variant<TAPS, EPI, 1>(a, reps);
-        t[2] = time_variant<TAPS, EPI, 2>(a, reps);
-        t[3] = time_variant<TAPS, EPI, 3>(a, reps);
-        t[4] = time_variant<TAPS, EPI, 4>(a, reps);
-        t[5] = time_variant<TAPS, EPI, 5>(a, reps);
-        t[6] = time_variant<TAPS, EPI, 6>(a, reps);
-        t[7] = time_variant<TAPS, EPI, 7>(a, reps);
-        t[8] = time_variant<TAPS, EPI, 8>(a, reps);
-        t[9] = time_variant<TAPS, EPI, 9>(a, reps);
-        for (int v = 0; v < NV; ++v) { best[v] = fminf(best[v], t[v]); sum[v] += t[v]; }
-    }
-    const char* note[NV] = {"", same ? "bitwise==var0" : "MISMATCH vs var0", "ablate: no loads/stores", "ablate: no MFMA", "ablate: no loads/stores/barrier", "layout exp: tile-contiguous W + chunk-major A (dist 1)", "layout exp + dist 2", "mem-only: W tiles only", "mem-only: A tiles only", "mem-only: loads, no LDS stores"};
-    for (int v = 0; v < NV; ++v)
-        printf("%-8s var%d  K=%4dx%d N=%4d  min %8.1f us  mean %8.1f us  %7.1f TF/s (min)  %s\n", name, v, cin, TAPS, cout,
-               best[v] * 1e3, sum[v] / rounds * 1e3, flops / (best[v] * 1e-3) / 1e12, note[v]);
+        return best;
+    };
+    struct { const char* note; float ms; } res[] = {
+        {"glds (shipping)", timeit([&] { return launch_glds<OpBF16, TAPS, EPI, 0>(a, nullptr); })},
+        {"glds + setprio", timeit([&] { return launch_glds<OpBF16, TAPS, EPI, 1>(a, nullptr); })},
+        {"ablate: compute only (no LDS-DMA)", timeit([&] { return launch_glds<OpBF16, TAPS, EPI, 2>(a, nullptr); })},
+        {"ablate: LDS-DMA + ds_read only (no MFMA)", timeit([&] { return launch_glds<OpBF16, TAPS, EPI, 4>(a, nullptr); })},
+        {"exp: 1 A buffer, 3 blocks/CU (racy)", timeit([&] { return launch_glds<OpBF16, TAPS, EPI, 8>(a, nullptr); })},
+        {"exp: 3 blocks/CU + setprio (racy)", timeit([&] { return launch_glds<OpBF16, TAPS, EPI, 9>(a, nullptr); })},
+        {"register-staged (old)", timeit([&] { return launch_var<OpBF16, TAPS, EPI, 0>(a, nullptr); })},
+    };
+    for (auto& r : res)
+        printf("%-6s K=%4dx%d N=%4d  %8.1f us  %7.1f TF/s  %s%s\n", name, cin, TAPS, cout, r.ms * 1e3,
+               flops / (r.ms * 1e-3) / 1e12, r.note, (&r == &res[0]) ? (same ? "  [bitwise == old]" : "  [MISMATCH]") : "");
     fflush(stdout);
 }
 
