@@ -88,13 +88,27 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the native path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_SHARE_GPU=1 (test hook): all ranks use the visible devices round-robin, so the N>1 path can be
+    # exercised on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if os.environ.get("BENCH_SHARE_GPU") == "1" else local_rank
+    if dev_index >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} HIP device(s) visible")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+        # The inference path shards independent utterances: there is NO data-path collective.  The only
+        # cross-rank traffic is the measurement protocol (barrier + max of the elapsed time), a few bytes on
+        # the host, so it runs over gloo; RCCL ("nccl" backend) is reserved for paths with a real exchange
+        # step (training gradients).  BENCH_SYNC_BACKEND=nccl forces RCCL for the sync.
+        backend = os.environ.get("BENCH_SYNC_BACKEND", "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import oracle
     from oracle.inputs import make_inputs
@@ -139,7 +153,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out).all()

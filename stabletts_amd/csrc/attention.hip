@@ -29,9 +29,6 @@
 
 namespace st {
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void global_cvoid_t;
-
 template <class P>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     using vec8 = typename P::vec8;
@@ -83,10 +80,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const int key = kt * 64 + row;
             const unsigned char* ksrc = key < T ? kbase + (size_t)key * 128 + seg * 16 : zeros;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)ksrc, (lds_void_t*)(Ks + buf * TILE_BYTES + piece * 1024), 16, 0, 0);
+            glds16b(ksrc, Ks + buf * TILE_BYTES + piece * 1024);
             // V^T row = head dim `row`; 8 consecutive (permuted) keys kt*64 + seg*8 .. +8, always inside Tp
             const unsigned char* vsrc = vbase + ((size_t)row * Tp + kt * 64 + seg * 8) * 2;
-            __builtin_amdgcn_global_load_lds((global_cvoid_t*)vsrc, (lds_void_t*)(Vs + buf * TILE_BYTES + piece * 1024), 16, 0, 0);
+            glds16b(vsrc, Vs + buf * TILE_BYTES + piece * 1024);
         }
     };
 
@@ -106,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     float m_run = -1e30f, l_run = 0.f;
 
     if (ntiles > 0) issueKV(0, 0);
+    ST_DMA_WAIT(0);
     __syncthreads();
 
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -172,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
             for (int g = 0; g < 4; ++g)
                 o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
         }
-        __syncthreads();      // drains the LDS-DMA of tile kt+1 and fences the buffer swap
+        ST_DMA_WAIT(0);       // tile kt+1 (asm-issued LDS-DMA, flying under this tile's MFMAs and exps) has landed
+        __syncthreads();      // fence the buffer swap
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -61,6 +61,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
+
+// LDS-DMA of one 1-KiB piece (64 lanes x 16 B), issued from INLINE ASM on purpose: with the
+// __builtin_amdgcn_global_load_lds form hipcc (ROCm 7.2) treats every later ds_read as possibly aliasing the
+// in-flight DMA and emits `s_waitcnt vmcnt(0)` in front of the first fragment read of the stage -- the DMA
+// just issued is drained before any MFMA starts, i.e. copy and compute never overlap inside a wave (seen in
+// the ISA; measured: DMA-only 113 us + compute-only 97 us -> 142 us).  An asm statement is invisible to that
+// pass; completion is tracked by hand with counted `s_waitcnt vmcnt(N)` in front of the stage barrier.
+// M0 (LDS destination base of the DMA) is saved/restored inside the statement (guide section 5.7).
+#ifndef ST_GLDS_BUILTIN
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
+    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(off) : "memory");
+}
+#define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#else
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((global_cvoid_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+#define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+
 constexpr int kLdsRowBytes = 144;  // 64 x 16-bit channels + 16 B pad: conflict-free ds_read_b128 over 16 rows
 
 }  // namespace st

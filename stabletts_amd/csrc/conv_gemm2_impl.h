@@ -19,13 +19,6 @@
 
 namespace st {
 
-typedef __attribute__((address_space(3))) void lds_void2_t;
-typedef __attribute__((address_space(1))) const void global_cvoid2_t;
-
-__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((global_cvoid2_t*)gsrc, (lds_void2_t*)lds_wave_base, 16, 0, 0);
-}
-
 template <int BC, int BF, int WC, int WF, int TAPS>
 struct G2Cfg {
     static constexpr int NW = WC * WF, NT = 64 * NW;
@@ -281,6 +274,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     };
 
     issueA(0, 0); issueW(0, 0, 0);
+    ST_DMA_WAIT(0);
     __syncthreads();
     int it = 0;
     for (int c = 0; c < nch; ++c) {
@@ -289,8 +283,9 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
             const bool last = (c == nch - 1) && (j == TAPS - 1);
             if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
             if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
-            compute(c & 1, it & 1, j);
-            __syncthreads();
+            compute(c & 1, it & 1, j);      // the DMA issued above flies underneath these MFMAs
+            ST_DMA_WAIT(0);                 // this wave's pieces of the next stage have landed ...
+            __syncthreads();                // ... everyone's have, and everyone is done reading this stage
             ++it;
         }
     }

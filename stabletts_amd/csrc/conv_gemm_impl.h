@@ -391,12 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs g)
 //      LDS slot (row, s')  holds tile segment  s = s' ^ ((row >> 1) & 7)
 // 16 rows that are distinct mod 16 then cover all sixteen 16-byte bank slots -> conflict-free
 // ds_read_b128.  Out-of-range halo frames read a 16-byte zero block in global memory.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void global_cvoid_t;
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((global_cvoid_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
-}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) { glds16b(gsrc, lds_wave_base); }
 
 // OPT (experiments, tools/gemm_bench): 1 = s_setprio around the MFMA cluster, 2 = no LDS-DMA in the loop,
 // 4 = no MFMA, 8 = single activation buffer + 3 blocks/CU (racy: timing only).
@@ -526,6 +521,7 @@ __global__ __launch_bounds__(256, (OPT & 8) ? 3 : 2) void conv_gemm_glds_kernel(
     };
 
     issueA(0, 0); issueW(0, 0, 0);
+    ST_DMA_WAIT(0);
     __syncthreads();
     int it = 0;
     for (int c = 0; c < nch; ++c) {
@@ -537,7 +533,8 @@ __global__ __launch_bounds__(256, (OPT & 8) ? 3 : 2) void conv_gemm_glds_kernel(
                 if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
             }
             compute(c & 1, it & 1, j);
-            __syncthreads();      // drains the LDS-DMA (vmcnt(0)) and fences the buffer swap
+            ST_DMA_WAIT(0);       // the asm-issued LDS-DMA is invisible to hipcc: drain it by hand ...
+            __syncthreads();      // ... then fence the buffer swap
             ++it;
         }
     }

@@ -149,7 +149,8 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
     const bool bf = e->dt == DT_BF16;
     if (use_gen2() && epi != EPI_QKV) {
         // row-complete tiles where the epilogue carries the next FiLM + LayerNorm, 128x128 tiles otherwise
-        const int cfg = a.ln_h16 ? G2_RC : G2_T128;
+        // deep (>= 8 channel chunks) k=3 convs run the 3-buffer pipeline; short K loops gain nothing from it
+        const int cfg = a.ln_h16 ? G2_RC : ((taps == 3 && a.c0 + a.c1 >= 512) ? G2_K3PIPE : G2_T128);
         return bf ? launch_conv_gemm2_bf16(cfg, taps, epi, a, s) : launch_conv_gemm2_f16(cfg, taps, epi, a, s);
     }
     return bf ? launch_conv_gemm_bf16(taps, epi, a, s) : launch_conv_gemm_f16(taps, epi, a, s);
@@ -370,8 +371,12 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
     const bool cap = e->capture;
     // measured on MI355X (profiles/): fused FiLM+LN epilogues on row-complete tiles are a wash against the faster
     // 128x128 tiles + separate LayerNorm launches (38.2 vs 38.0 ms/solve), so fusion is opt-in: ST_FUSE_LN=1
-    static const bool fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v && atoi(v) == 1; }();
-    const bool fuse = use_gen2() && fuse_env;
+    // ST_FUSE_LN (default 0; measured 34.9 / 35.1 / 35.3 ms per solve for 0 / 1 / 2 on MI355X):
+    // 0 = every FiLM/LayerNorm is its own launch, 1 = fused into the long-skip convs and
+    // FFN conv_2 -> next block's LN1), 2 = fused everywhere (also in_proj and out_proj)
+    static const int fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v ? atoi(v) : 0; }();
+    const bool fuse = use_gen2() && fuse_env >= 1;        // lsc + ffn2
+    const bool fuse_all = use_gen2() && fuse_env >= 2;    // + in_proj, out_proj
     auto ada_of = [&](int i) { return p.ada + (size_t)i * N * 6 * C; };
     // FiLM_i + LN1_i + modulate (start of block i) fused into the producing GEMM
     auto fuse_ln1 = [&](ConvGemmArgs& a, int i) {
@@ -399,12 +404,12 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         a.a0 = p.x16; a.c0 = e->Mp; a.a0_mod = p.B; a.bias = nullptr;
         a.add32 = p.cpart; a.add_clamp = p.B;
         a.out32 = p.X; a.out16 = p.skip16[0];
-        if (fuse) fuse_ln1(a, 0);
+        if (fuse_all) fuse_ln1(a, 0);
         ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inx, N));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
     if (cap) {
-        if (fuse) capture(e, "h0", p.skip16[0], rowsC, true, s);
+        if (fuse_all) capture(e, "h0", p.skip16[0], rowsC, true, s);
         else capture(e, "h0", p.X, rowsC, false, s);
     }
     for (int i = 0; i < L; ++i) {
@@ -420,7 +425,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
             if (cap && !fuse) capture(e, "lsc" + std::to_string(j), p.X, rowsC, false, s);
         }
-        if (!fuse && (rc = film_ln1(i))) return rc;      // FiLM, mask, LN1, modulate
+        if (!((i == 0) ? fuse_all : fuse) && (rc = film_ln1(i))) return rc;      // FiLM, mask, LN1, modulate
         if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
         {   // q, k, v projections + RoPE (diffusion_transformer.py:59-61,74-75)
             ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
@@ -446,7 +451,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111) [+ LN2, modulate, mask]
             ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
-            if (fuse) {
+            if (fuse_all) {
                 a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
                 a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
             }
@@ -454,7 +459,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
         if (cap) capture(e, bn + "x2", p.X, rowsC, false, s);
-        if (!fuse) {   // LN2 + modulate, masked (FFN input, diffusion_transformer.py:112,26)
+        if (!fuse_all) {   // LN2 + modulate, masked (FFN input, diffusion_transformer.py:112,26)
             FilmLnArgs a; memset(&a, 0, sizeof(a));
             a.X = p.X; a.h16 = p.h16; a.film = nullptr; a.film_mod = 1;
             a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
