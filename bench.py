@@ -71,6 +71,33 @@ def cpu_baseline(sd, cfg_params, budget_s=20.0):
                        f"({t_used:.2f} s), scaled to {N_STEPS}; {threads} torch threads, os.cpu_count()={os.cpu_count()}")
 
 
+# kernel that implements each profiled class on the default path (for the PMC traffic lookup)
+CLASS_KERNEL = {
+    "ffn_conv1": "conv_gemm2_kernel<st::Op{DT}, 3, 0, 128, 128, 2, 2>",
+    "ffn_conv2": "conv_gemm3_kernel<st::Op{DT}, 2>",
+    "lsc_conv": "conv_gemm3_kernel<st::Op{DT}, 1>",
+    "attention": "attention_kernel<st::Op{DT}>",
+    "qkv_rope": "conv_gemm_glds_kernel<st::Op{DT}, 1, 3, 0>",
+    "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 128, 128, 2, 2>",
+}
+
+
+def pmc_traffic(cls, dtype):
+    """HBM bytes per launch of the class's kernel, from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when not available."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    want = CLASS_KERNEL.get(cls, "").replace("{DT}", "BF16" if dtype == "bf16" else "F16")
+    for name, v in table.items():
+        if want and want in name:
+            return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +208,7 @@ def main():
                        "parallelism": f"utterance-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": f"conv_gemm_kernel [{dom}]", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(dom, args.dtype), "traffic_unit": "HBM bytes per launch (PMC)",
                          "launches": p["launches"], "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": p["flops_per_launch"]},
             "whole_solve_tflops": falg * B_PER_GPU * T_FRAMES / (elapsed / args.steps) / 1e12 * world,
