@@ -21,6 +21,6 @@ are "parity unpinned" against torchdiffeq itself.
 from .weights import DecoderConfig, make_state_dict, make_cfg_params  # noqa: F401
 from .estimator_oracle import (  # noqa: F401
     decoder_forward, cfm_forward, cfg_wrapper, compute_loss, odeint_fixed,
-    sinusoidal_pos_emb, rope, attention, ffn, dit_block, linspace_f32,
+    sinusoidal_pos_emb, rope, attention, ffn, dit_block, linspace_f32, odeint_dopri5,
 )
 from .inputs import make_inputs  # noqa: F401

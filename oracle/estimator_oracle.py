@@ -220,6 +220,89 @@ def odeint_fixed(f, y0, t_span, method="euler"):
     return y
 
 
+# Dormand-Prince 5(4) tableau and controller constants of torchdiffeq 0.2.x (rk_common.py, dopri5.py,
+# misc.py), restated from the published algorithm -- torchdiffeq is not installable offline: PARITY UNPINNED.
+_DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP_BETA = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+_DP_C_SOL = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0]
+_DP_C_ERR = [35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+             -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0]
+_DP_C_MID = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+             187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+def _rms(x):
+    return float(x.abs().pow(2).mean().sqrt())
+
+
+def odeint_dopri5(f, y0, t_end=1.0, rtol=1e-5, atol=1e-5, stats=None):
+    """torchdiffeq's adaptive dopri5 as called at models/flow_matching.py:54 (method=None or 'dopri5',
+    rtol=atol=1e-5), integrating from 0 to t_end and returning the state at t_end.  Intermediate output times
+    only add interpolation, never change the steps, so they are not modelled.  Steps are NOT clipped to t_end:
+    the last step may overshoot and the result is the 4th-order dense-output interpolant at t_end.
+    Time is carried in float64 on the host; f receives it as an fp32 0-dim tensor."""
+    tt = lambda t: torch.tensor(t, dtype=torch.float32)
+    t0 = 0.0
+    f0 = f(tt(t0), y0)
+    nfe = 1
+    # _select_initial_step (order 4)
+    scale = atol + y0.abs() * rtol
+    d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    f1 = f(tt(t0 + h0), y0 + h0 * f0)
+    nfe += 1
+    d2 = _rms((f1 - f0) / scale) / h0
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    dt = min(100 * h0, h1)
+    y, fcur, t = y0, f0, t0
+    steps = rejects = 0
+    while True:
+        t1 = t + dt
+        k = [fcur]
+        for alpha, beta in zip(_DP_ALPHA, _DP_BETA):
+            ti = t1 if alpha == 1.0 else t + alpha * dt
+            yi = y + sum((b * dt) * kj for b, kj in zip(beta, k) if b != 0.0)
+            k.append(f(tt(ti), yi))
+            nfe += 1
+        y1 = yi                                      # c_sol[:-1] == beta[-1] (FSAL): the last stage IS y1
+        err = sum((c * dt) * kj for c, kj in zip(_DP_C_ERR, k) if c != 0.0)
+        tol = atol + rtol * torch.max(y.abs(), y1.abs())
+        ratio = _rms(err / tol)
+        accept = ratio <= 1.0
+        # _optimal_step_size(safety 0.9, ifactor 10, dfactor 0.2, order 5)
+        if ratio == 0.0:
+            dt_next = dt * 10.0
+        else:
+            dfactor = 1.0 if ratio < 1.0 else 0.2
+            dt_next = dt * min(10.0, max(0.9 / ratio ** 0.2, dfactor))
+        steps += 1
+        if accept:
+            if t1 >= t_end:
+                # dense output (_interp_fit / _interp_evaluate) at t_end inside [t, t1]
+                y_mid = y + sum((c * dt) * kj for c, kj in zip(_DP_C_MID, k) if c != 0.0)
+                fa, fb = k[0], k[-1]
+                a = 2 * dt * (fb - fa) - 8 * (y1 + y) + 16 * y_mid
+                b = dt * (5 * fa - 3 * fb) + 18 * y + 14 * y1 - 32 * y_mid
+                c = dt * (fb - 4 * fa) - 11 * y - 5 * y1 + 16 * y_mid
+                d = dt * fa
+                x = (t_end - t) / (t1 - t)
+                out = (((a * x + b) * x + c) * x + d) * x + y
+                if stats is not None:
+                    stats.update(nfe=nfe, steps=steps, rejects=rejects)
+                return out
+            y, fcur, t = y1, k[-1], t1
+        else:
+            rejects += 1
+        dt = dt_next
+
+
 @torch.inference_mode()
 def cfm_forward(sd, mu, mask, n_timesteps, z, c, solver="euler", cfg_kwargs=None, **kw):
     """models/flow_matching.py:25-55 (CFMDecoder.forward) with the noise z passed explicitly
@@ -230,6 +313,8 @@ def cfm_forward(sd, mu, mask, n_timesteps, z, c, solver="euler", cfg_kwargs=None
     else:
         f = lambda t, x: cfg_wrapper(sd, t, x, mask, mu, c, cfg_kwargs["fake_speaker"],
                                      cfg_kwargs["fake_content"], cfg_kwargs["cfg_strength"], **kw)
+    if solver in (None, "dopri5"):
+        return odeint_dopri5(f, z, float(t_span[-1]))
     return odeint_fixed(f, z, t_span, solver)
 
 

@@ -12,14 +12,16 @@ LIB_PATH = os.path.join(HERE, "libstabletts_hip.so")
 ST_OK = 0
 ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_STATE, ST_ERR_UNSUPPORTED = -1, -2, -3, -4
 ST_OPERAND_BF16, ST_OPERAND_F16 = 0, 1
-ST_SOLVER_EULER, ST_SOLVER_MIDPOINT, ST_SOLVER_RK4 = 0, 1, 2
+ST_SOLVER_EULER, ST_SOLVER_MIDPOINT, ST_SOLVER_RK4, ST_SOLVER_DOPRI5 = 0, 1, 2, 3
 OPERAND_DTYPES = {"bf16": ST_OPERAND_BF16, "f16": ST_OPERAND_F16, "fp16": ST_OPERAND_F16}
-SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_SOLVER_RK4}
+# None is torchdiffeq's default method = dopri5 (models/flow_matching.py:54)
+SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_SOLVER_RK4,
+           "dopri5": ST_SOLVER_DOPRI5, None: ST_SOLVER_DOPRI5}
 
 # every symbol include/stabletts_hip.h declares
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
-    "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_debug_capture", "st_debug_fetch",
+    "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
     "st_profile_enable", "st_profile_select", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes",
 ]
@@ -78,6 +80,8 @@ def load():
     lib.st_cfm_solve.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.st_cfm_solve.restype = c_int
+    lib.st_last_solve_stats.argtypes = [c_void_p] + [ctypes.POINTER(ctypes.c_int64)] * 3
+    lib.st_last_solve_stats.restype = c_int
     lib.st_debug_capture.argtypes = [c_void_p, c_int]
     lib.st_debug_capture.restype = c_int
     lib.st_debug_fetch.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64]
@@ -157,6 +161,11 @@ class Engine:
                                           fake_speaker.data_ptr() if fake_speaker is not None else None,
                                           fake_content.data_ptr() if fake_content is not None else None,
                                           out.data_ptr(), B, T, ctypes.c_void_p(stream)))
+
+    def last_solve_stats(self):
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.st_last_solve_stats(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(nfe=a.value, steps=b.value, rejects=c.value)
 
     # ---- test / measurement hooks
     def debug_capture(self, on):

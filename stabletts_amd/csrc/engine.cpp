@@ -5,6 +5,7 @@
 #include "../../include/stabletts_hip.h"
 #include "launch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -79,6 +80,8 @@ struct st_engine {
     int64_t prof_launches[PC_COUNT] = {0};
     double prof_ms[PC_COUNT] = {0};
     double prof_flops[PC_COUNT] = {0};
+
+    int64_t last_nfe = 0, last_steps = 0, last_rejects = 0;   // statistics of the last solve
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
 };
@@ -205,7 +208,7 @@ struct Plan {
     void *mu16, *pre1, *pre2, *cond16, *x16, *h16, *q16, *k16, *vt16, *ao16, *u16, *cur16;
     void* skip16[8];
     // fp32
-    float *cpart, *X, *v32, *xstate, *kbuf[4], *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
+    float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
     int *n_full, *kv_end;
     float* kbias;
 };
@@ -229,7 +232,10 @@ int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
     want((void**)&p->cpart, Pn * TT * C * 4);
     want(&p->x16, (size_t)B * TT * Mp * 2);
     want((void**)&p->xstate, (size_t)B * TT * Mp * 4);
-    for (int i = 0; i < 4; ++i) want((void**)&p->kbuf[i], (size_t)B * TT * Mp * 4);
+    for (int i = 0; i < 7; ++i) want((void**)&p->kbuf[i], (size_t)B * TT * Mp * 4);
+    want((void**)&p->ynew, (size_t)B * TT * Mp * 4);
+    want((void**)&p->ode_partial, (size_t)2 * kOdeNormBlocks * 4);
+    want((void**)&p->ode_out, 16);
     want((void**)&p->X, N * TT * C * 4);
     want(&p->h16, N * TT * C * 2);
     want(&p->q16, N * TT * C * 2);
@@ -499,6 +505,122 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
     return ST_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adaptive Dormand-Prince 5(4): torchdiffeq's `dopri5`, the reference's default solver
+// (models/flow_matching.py:54 with solver=None; rtol = atol = 1e-5 hard-coded there).  Restated from the
+// published algorithm (rk_common.py / dopri5.py / misc.py of torchdiffeq 0.2.x): RMS error norm over the
+// whole state tensor, FSAL, controller safety 0.9 / ifactor 10 / dfactor 0.2, initial step from
+// _select_initial_step, steps NOT clipped to t = 1 and the result taken from the 4th-order dense output.
+// The state, stage derivatives and norms live on the device; time and the controller run on the host
+// (float64), with one 8-byte read-back per step (torchdiffeq synchronises the same way).
+int solve_dopri5(st_engine* e, const Plan& p, const float* mask, int use_cfg, float cfg_strength, hipStream_t s) {
+    static const double ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+    static const double BETA[6][6] = {
+        {1.0 / 5},
+        {3.0 / 40, 9.0 / 40},
+        {44.0 / 45, -56.0 / 15, 32.0 / 9},
+        {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+        {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
+        {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+    static const double CERR[7] = {35.0 / 384 - 1951.0 / 21600, 0.0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                                   -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
+    static const double CMID[7] = {6025192743.0 / 30085553152.0 / 2, 0.0, 51252292925.0 / 65400821598.0 / 2,
+                                   -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
+                                   -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+    const double rtol = 1e-5, atol = 1e-5, t_end = 1.0;
+    const int B = p.B;
+    const int64_t per_item = (int64_t)p.T * e->Mp;
+    const int64_t nstate = (int64_t)B * per_item;
+    const double count = (double)B * e->M * p.T;            // padded channels carry zeros and do not count
+    int rc;
+    // f(t, state in x16) -> kout
+    auto eval = [&](double t, float* kout) -> int {
+        HIPCHK(e, launch_set_scalar(p.tvals, (float)t, s));
+        int r = run_time_tables(e, p, s); if (r) return r;
+        r = run_estimator(e, p, mask, 0, s); if (r) return r;
+        ProfScope ps(e, s, PC_ODE, 0);
+        HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, kout, nullptr, nullptr, 0.f, s));
+        e->last_nfe += 1;
+        return ST_OK;
+    };
+    float host2[2];
+    auto norms = [&](OdeNormArgs a) -> int {
+        a.rtol = (float)rtol; a.atol = (float)atol; a.n = nstate; a.partial = p.ode_partial; a.out = p.ode_out;
+        HIPCHK(e, launch_ode_norm(a, s));
+        HIPCHK(e, hipMemcpyAsync(host2, p.ode_out, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipStreamSynchronize(s));
+        return ST_OK;
+    };
+    float* y = p.xstate; float* y1 = p.ynew;
+    float* k[7];
+    for (int j = 0; j < 7; ++j) k[j] = p.kbuf[j];
+    // f0 = f(0, y0)   (x16 already holds y0)
+    if ((rc = eval(0.0, k[0]))) return rc;
+    // _select_initial_step, order 4
+    OdeNormArgs na; memset(&na, 0, sizeof(na));
+    na.mode = 0; na.y = y; na.b = k[0];
+    if ((rc = norms(na))) return rc;
+    const double d0 = sqrt(host2[0] / count), d1 = sqrt(host2[1] / count);
+    const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    {
+        const float* ks[1] = {k[0]}; const float cf[1] = {(float)h0};
+        HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, 1, nstate, nullptr, p.x16, s));
+    }
+    if ((rc = eval(0.0 + h0, k[1]))) return rc;
+    memset(&na, 0, sizeof(na));
+    na.mode = 1; na.y = y; na.a = k[0]; na.b = k[1];
+    if ((rc = norms(na))) return rc;
+    const double d2 = sqrt(host2[0] / count) / h0;
+    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : pow(0.01 / std::max(d1, d2), 1.0 / 5.0);
+    double dt = std::min(100.0 * h0, h1), t = 0.0;
+    for (int64_t step = 0; step < 100000; ++step) {
+        const double t1 = t + dt;
+        for (int i = 0; i < 6; ++i) {       // stage i+1: y_i = y + dt * sum_j beta[i][j] k_j ; k_{i+1} = f(t_i, y_i)
+            const float* ks[7]; float cf[7]; int nk = 0;
+            for (int j = 0; j <= i; ++j) if (BETA[i][j] != 0.0) { ks[nk] = k[j]; cf[nk] = (float)(BETA[i][j] * dt); ++nk; }
+            {
+                ProfScope ps(e, s, PC_ODE, 0);
+                HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, i == 5 ? y1 : nullptr, p.x16, s));
+            }
+            const double ti = (ALPHA[i] == 1.0) ? t1 : t + ALPHA[i] * dt;
+            if ((rc = eval(ti, k[i + 1]))) return rc;
+        }
+        // the 6th stage IS y1 (c_sol[:-1] == beta[-1], FSAL); error estimate from the seven derivatives
+        memset(&na, 0, sizeof(na));
+        na.mode = 2; na.y = y; na.a = y1; na.nk = 0;
+        for (int j = 0; j < 7; ++j) if (CERR[j] != 0.0) { na.k[na.nk] = k[j]; na.coef[na.nk] = (float)(CERR[j] * dt); ++na.nk; }
+        if ((rc = norms(na))) return rc;
+        const double ratio = sqrt(host2[0] / count);
+        if (!(ratio == ratio)) return e->fail(ST_ERR_INVALID, "dopri5: non-finite error estimate");
+        const bool accept = ratio <= 1.0;
+        double dt_next;
+        if (ratio == 0.0) dt_next = dt * 10.0;
+        else {
+            const double dfactor = ratio < 1.0 ? 1.0 : 0.2;
+            dt_next = dt * std::min(10.0, std::max(0.9 / pow(ratio, 0.2), dfactor));
+        }
+        e->last_steps += 1;
+        if (accept) {
+            if (t1 >= t_end) {      // dense output at t_end inside [t, t1] -> p.ynew
+                const float* ks[7]; float cm[7];
+                for (int j = 0; j < 7; ++j) { ks[j] = k[j]; cm[j] = (float)(CMID[j] * dt); }
+                ProfScope ps(e, s, PC_ODE, 0);
+                // elementwise, so writing p.ynew in place is safe whichever of y / y1 it currently aliases
+                HIPCHK(e, launch_dopri5_interp(y, y1, ks, cm, (float)dt, (float)((t_end - t) / (t1 - t)), nstate, p.ynew, s));
+                return ST_OK;
+            }
+            std::swap(y, y1);                        // y <- y1
+            std::swap(k[0], k[6]);                   // f0 <- k7 (FSAL)
+            t = t1;
+        } else {
+            e->last_rejects += 1;
+        }
+        dt = dt_next;
+        if (!(dt > 0.0) || dt < 1e-12) return e->fail(ST_ERR_INVALID, "dopri5: step size underflow");
+    }
+    return e->fail(ST_ERR_INVALID, "dopri5: too many steps");
+}
+
 int check_ready(st_engine* e, int B, int T) {
     if (!e) return ST_ERR_INVALID;
     if (!e->finalized) return e->fail(ST_ERR_STATE, "st_finalize() has not been called after loading parameters");
@@ -696,13 +818,14 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     int rc = check_ready(e, B, T); if (rc) return rc;
     if (!mu || !mask || !z || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (n_steps < 1 || n_steps > 4096) return e->fail(ST_ERR_INVALID, "n_steps out of range");
-    if (solver != ST_SOLVER_EULER && solver != ST_SOLVER_MIDPOINT && solver != ST_SOLVER_RK4)
-        return e->fail(ST_ERR_UNSUPPORTED, "solver not implemented natively (euler, midpoint, rk4 are)");
+    if (solver != ST_SOLVER_EULER && solver != ST_SOLVER_MIDPOINT && solver != ST_SOLVER_RK4 && solver != ST_SOLVER_DOPRI5)
+        return e->fail(ST_ERR_UNSUPPORTED, "solver not implemented natively (euler, midpoint, rk4, dopri5 are)");
     if (use_cfg && (!fake_speaker || !fake_content)) return e->fail(ST_ERR_INVALID, "CFG needs fake_speaker and fake_content");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
+    const bool adaptive = solver == ST_SOLVER_DOPRI5;
     const int stages = solver == ST_SOLVER_EULER ? 1 : (solver == ST_SOLVER_MIDPOINT ? 2 : 4);
-    const int n_t = n_steps * stages;
+    const int n_t = adaptive ? 1 : n_steps * stages;
     Plan p;
     if ((rc = make_plan(e, B, T, use_cfg != 0, n_t, &p))) return rc;
     if ((rc = ensure_rope(e, T, s))) return rc;
@@ -710,7 +833,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     // evaluation times, fp32 arithmetic as torchdiffeq does on the fp32 t_span (flow_matching.py:46)
     const std::vector<float> grid = linspace01(n_steps);
     std::vector<float> tv((size_t)n_t), dts((size_t)n_steps);
-    for (int i = 0; i < n_steps; ++i) {
+    for (int i = 0; i < n_steps && !adaptive; ++i) {
         const float t0 = grid[i], t1 = grid[i + 1], dt = t1 - t0;
         dts[i] = dt;
         if (stages == 1) tv[i] = t0;
@@ -738,8 +861,12 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     }
     if ((rc = run_prenet(e, p, s))) return rc;
     if ((rc = run_adaln(e, p, s))) return rc;
-    if ((rc = run_time_tables(e, p, s))) return rc;
+    if (!adaptive && (rc = run_time_tables(e, p, s))) return rc;
+    e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive ? 0 : n_steps; e->last_rejects = 0;
 
+    if (adaptive) {
+        if ((rc = solve_dopri5(e, p, mask, use_cfg, cfg_strength, s))) return rc;
+    } else
     for (int i = 0; i < n_steps; ++i) {
         const float dt = dts[i];
         if (solver == ST_SOLVER_EULER) {
@@ -781,8 +908,16 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     }
     {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_from_time_major(p.xstate, B, e->M, T, e->Mp, out, s));
+        HIPCHK(e, launch_from_time_major(adaptive ? p.ynew : p.xstate, B, e->M, T, e->Mp, out, s));
     }
+    return ST_OK;
+}
+
+int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects) {
+    if (!e) return ST_ERR_INVALID;
+    if (nfe) *nfe = e->last_nfe;
+    if (steps) *steps = e->last_steps;
+    if (rejects) *rejects = e->last_rejects;
     return ST_OK;
 }
 

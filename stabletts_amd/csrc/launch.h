@@ -92,7 +92,7 @@ hipError_t launch_fill_rows16(int dtype, const float* vec, int C, int Cp, int T,
 // kout (optional) = vv ; if xio: xio += dt*vv and x16 = xio (Euler step fused).
 hipError_t launch_cfg_combine(int dtype, const float* v, int B, int64_t per_item, int use_cfg, float s,
                               float* kout, float* xio, void* x16, float dt, hipStream_t stream);
-// y = x + sum_i coef[i]*k[i] (i < nk <= 4); writes y32 and/or y16
+// y = x + sum_i coef[i]*k[i] (i < nk <= 7); writes y32 and/or y16
 hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, const float* coef, int nk,
                           int64_t n, float* y32, void* y16, hipStream_t s);
 
@@ -101,5 +101,19 @@ hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, cons
 hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_total, int K, int ci_off,
                               int ci_cnt, void* dst, int row_off, int cin_p, hipStream_t s);
 hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- adaptive dopri5 support (adaptive_ode.hip)
+hipError_t launch_set_scalar(float* dst, float v, hipStream_t s);
+// Deterministic sums of squares over n elements (two-stage reduction, fixed order), result in out[0..1]:
+//   mode 0: out[0] = sum (y/scale)^2, out[1] = sum (f/scale)^2            scale = atol + rtol*|y|      (a=y, b=f)
+//   mode 1: out[0] = sum ((b - a)/scale)^2                                scale = atol + rtol*|y|      (a=f0, b=f1)
+//   mode 2: out[0] = sum (err/tol)^2, err = sum_j coef[j]*k[j], tol = atol + rtol*max(|y|,|y1|)      (a = y1)
+struct OdeNormArgs { const float* y; const float* a; const float* b; const float* k[7]; float coef[7]; int nk;
+                     float rtol, atol; int64_t n; int mode; float* partial; float* out; };
+hipError_t launch_ode_norm(const OdeNormArgs& a, hipStream_t s);
+constexpr int kOdeNormBlocks = 1024;
+// dense output of dopri5 at x = (t - t0)/(t1 - t0): out = a x^4 + b x^3 + c x^2 + d x + y0 (torchdiffeq _interp_fit)
+hipError_t launch_dopri5_interp(const float* y0, const float* y1, const float* const* k, const float* cmid_dt, float dt,
+                                float x, int64_t n, float* out, hipStream_t s);
 
 }  // namespace st

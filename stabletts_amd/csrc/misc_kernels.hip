@@ -242,7 +242,8 @@ hipError_t launch_cfg_combine(int dtype, const float* v, int B, int64_t per_item
     return hipGetLastError();
 }
 
-struct LinCombArgs { const float* x; const float* k[4]; float coef[4]; int nk; int64_t n; float* y32; void* y16; };
+constexpr int kMaxComb = 7;   // dopri5 has 7 stage derivatives
+struct LinCombArgs { const float* x; const float* k[kMaxComb]; float coef[kMaxComb]; int nk; int64_t n; float* y32; void* y16; };
 
 template <class P>
 __global__ __launch_bounds__(256) void lincomb_kernel(const LinCombArgs a) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinCombArgs a) {
     if (i >= a.n) return;
     float4 y = *(const float4*)(a.x + i);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kMaxComb; ++j) {
         if (j < a.nk) {
             const float4 kv = *(const float4*)(a.k[j] + i);
             const float c = a.coef[j];
@@ -265,7 +266,7 @@ hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, cons
                           int64_t n, float* y32, void* y16, hipStream_t s) {
     LinCombArgs a;
     a.x = x; a.nk = nk; a.n = n; a.y32 = y32; a.y16 = y16;
-    for (int j = 0; j < 4; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.coef[j] = j < nk ? coef[j] : 0.f; }
+    for (int j = 0; j < kMaxComb; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.coef[j] = j < nk ? coef[j] : 0.f; }
     const int grid = (int)((n / 4 + 255) / 256);
     if (dtype == DT_BF16) hipLaunchKernelGGL((lincomb_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, a);
     else                  hipLaunchKernelGGL((lincomb_kernel<OpF16>), dim3(grid), dim3(256), 0, s, a);

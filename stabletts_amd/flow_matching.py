@@ -8,9 +8,10 @@ runs as hand-written gfx950 kernels behind ``st_cfm_solve`` (include/stabletts_h
 Differences from the reference, all additive:
   * ``forward(..., z=None)``: optional explicit noise (already temperature-scaled semantics are kept:
     the shim multiplies by ``temperature`` exactly like :45) so parity tests can fix the noise.
-  * ``solver``: the fixed-grid methods 'euler', 'midpoint', 'rk4' are native.  torchdiffeq's adaptive
-    methods (``None``/'dopri5', 'bosh3', ...) are not implemented natively and raise
-    NotImplementedError (torchdiffeq is not a dependency of this package).
+  * ``solver``: 'euler', 'midpoint', 'rk4' (fixed grid) and 'dopri5' / ``None`` (torchdiffeq's default:
+    adaptive Dormand-Prince 5(4), rtol = atol = 1e-5 as at :54) are native; the other torchdiffeq methods
+    ('bosh3', 'fehlberg2', 'adaptive_heun', 'implicit_adams', ...) raise NotImplementedError
+    (torchdiffeq is not a dependency of this package).
   * ``operand_dtype``: MFMA operand type, 'bf16' (default) or 'f16'; accumulation / residual stream /
     LayerNorm / softmax statistics / ODE state stay fp32.
 """
@@ -41,8 +42,8 @@ class CFMDecoder(nn.Module):
         """Same contract as models/flow_matching.py:25-55; returns trajectory[-1], (B, n_feats, T)."""
         if solver not in _lib.SOLVERS:
             raise NotImplementedError(
-                f"solver={solver!r}: only the fixed-grid torchdiffeq methods {sorted(_lib.SOLVERS)} are native "
-                "(the reference default None means adaptive dopri5)")
+                f"solver={solver!r}: native solvers are euler, midpoint, rk4 (fixed grid) and dopri5 "
+                "(adaptive; also selected by the reference default solver=None)")
         if c is None:
             raise ValueError("c (speaker embedding, (B, gin_channels)) is required")
         eng = self.estimator.engine()
