@@ -8,6 +8,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _limit_torch_threads():
+    # The oracle runs small fp32 convolutions; on a many-core host (the MI355X box has 256 logical CPUs) torch's
+    # default of one thread per core makes them several times SLOWER.  16 threads keeps both suites short.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:
+        pass
+
+
+_limit_torch_threads()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

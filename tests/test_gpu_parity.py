@@ -183,15 +183,21 @@ def test_padded_batch_equals_unpadded_up_to_pad_leak(decoders, sd):
     assert _rel(out_b, ref_b) <= NFE_TOL["f16"]
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("B,T,lengths,cfg,seed,solver", [(1, 48, [48], None, 23, "dopri5"), (2, 33, [33, 30], 2.0, 24, None)])
-def test_adaptive_dopri5_vs_oracle(decoders, sd, cfg_params, dt, B, T, lengths, cfg, seed, solver):
+@pytest.fixture(scope="module")
+def dopri5_case(sd, cfg_params):
+    """One oracle dopri5 solve (~430 CFG evaluations on the CPU), shared by both operand types."""
+    inp = make_inputs(2, 33, seed=24, lengths=[33, 30])
+    ref = oracle.cfm_forward(sd, inp["mu"], inp["mask"], 10, inp["z"], inp["c"], "dopri5", _cfg(cfg_params, 2.0, False))
+    return inp, ref
+
+
+@pytest.mark.parametrize("dt,solver", [("bf16", None), ("f16", "dopri5")])
+def test_adaptive_dopri5_vs_oracle(decoders, cfg_params, dopri5_case, dt, solver):
     """The reference default solver (solver=None -> torchdiffeq dopri5, rtol=atol=1e-5, flow_matching.py:54).
     Step acceptance is a discrete decision on a 16-bit-operand vector field, so native and oracle may take
     different steps; both must land within the solve tolerance of each other."""
-    inp = make_inputs(B, T, seed=seed, lengths=lengths)
-    ref = oracle.cfm_forward(sd, inp["mu"], inp["mask"], 10, inp["z"], inp["c"], "dopri5", _cfg(cfg_params, cfg, False))
-    out = _solve(decoders[dt], inp, 10, solver, _cfg(cfg_params, cfg, True), inp["z"])
+    inp, ref = dopri5_case
+    out = _solve(decoders[dt], inp, 10, solver, _cfg(cfg_params, 2.0, True), inp["z"])
     st = decoders[dt].estimator.engine().last_solve_stats()
     assert st["nfe"] >= 14 and st["steps"] >= 2 and st["nfe"] == 2 + 6 * st["steps"]
     assert torch.isfinite(out).all()
