@@ -17,6 +17,10 @@
 #include "launch.h"
 #include <cstdlib>
 
+#ifndef ST_FRAG_PREFETCH
+#define ST_FRAG_PREFETCH 0
+#endif
+
 namespace st {
 
 template <int BC, int BF, int WC, int WF, int TAPS>
@@ -258,6 +262,26 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
             const int row = wf * TF + b * 32 + l31 + j;
             arow_off[b] = row * 128; aswz[b] = (row >> 1) & 7;
         }
+#if ST_FRAG_PREFETCH
+        // fragments run two k-steps ahead of the MFMAs (two register sets), so a wave's own MFMAs cover its LDS latency
+        vec8 wfr[2][FC], afr[2][FF];
+        auto ldf = [&](int ks, int slot) {
+            const int seg = ks * 2 + hi;
+#pragma unroll
+            for (int a = 0; a < FC; ++a) wfr[slot][a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
+#pragma unroll
+            for (int b = 0; b < FF; ++b) afr[slot][b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
+        };
+        ldf(0, 0); ldf(1, 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[ks & 1][a], afr[ks & 1][b], acc[a][b]);
+            if (ks + 2 < 4) ldf(ks + 2, ks & 1);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             vec8 wfr[FC], afr[FF];
@@ -271,6 +295,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #pragma unroll
                 for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
         }
+#endif
     };
 
     issueA(0, 0); issueW(0, 0, 0);
@@ -383,6 +408,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g
             const int row = wf * TF + b * 32 + l31 + j;      // rows 128,129 (last two frame columns) fall into the next buffer
             arow_off[b] = row * 128; aswz[b] = (row >> 1) & 7;
         }
+#if ST_FRAG_PREFETCH
+        // fragments run two k-steps ahead of the MFMAs (two register sets), so a wave's own MFMAs cover its LDS latency
+        vec8 wfr[2][FC], afr[2][FF];
+        auto ldf = [&](int ks, int slot) {
+            const int seg = ks * 2 + hi;
+#pragma unroll
+            for (int a = 0; a < FC; ++a) wfr[slot][a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
+#pragma unroll
+            for (int b = 0; b < FF; ++b) afr[slot][b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
+        };
+        ldf(0, 0); ldf(1, 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[ks & 1][a], afr[ks & 1][b], acc[a][b]);
+            if (ks + 2 < 4) ldf(ks + 2, ks & 1);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             vec8 wfr[FC], afr[FF];
@@ -396,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g
 #pragma unroll
                 for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
         }
+#endif
     };
     // counted wait: everything except the youngest `keep` LDS-DMA instructions of this wave has landed
     auto wait_keep = [&](int keep) {

@@ -19,6 +19,12 @@ static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemm
         if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 256, 128, 4, 2>(a, s);
         if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 256, 128, 4, 2>(a, s);
         if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 256, 128, 4, 2>(a, s);
+    } else if (cfg == 3) {   // 256 ch x 256 frames, 8 waves (2x4) of 128x64: least LDS traffic per MFMA, LayerNorm-capable
+        if (taps == 3 && epi == EPI_ACT16) return launch_g2<P, 3, EPI_ACT16, 256, 256, 2, 4>(a, s);
+        if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 256, 256, 2, 4>(a, s);
+        if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 256, 256, 2, 4>(a, s);
+        if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 256, 256, 2, 4>(a, s);
+        if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 256, 256, 2, 4>(a, s);
     } else if (cfg == 2) {   // 3-buffer k=3 kernel (counted vmcnt), 128 ch x 126 frames
         if (taps == 3 && epi == EPI_ACT16) return launch_g3<P, EPI_ACT16>(a, s);
         if (taps == 3 && epi == EPI_F32) return launch_g3<P, EPI_F32>(a, s);

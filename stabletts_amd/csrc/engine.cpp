@@ -151,9 +151,23 @@ bool use_gen2() {
 hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
     const bool bf = e->dt == DT_BF16;
     if (use_gen2() && epi != EPI_QKV) {
-        // row-complete tiles where the epilogue carries the next FiLM + LayerNorm, 128x128 tiles otherwise
-        // deep (>= 8 channel chunks) k=3 convs run the 3-buffer pipeline; short K loops gain nothing from it
-        const int cfg = a.ln_h16 ? G2_RC : ((taps == 3 && a.c0 + a.c1 >= 512) ? G2_K3PIPE : G2_T128);
+        // 256x256 tiles (half the LDS traffic per MFMA of the 128x128 ones: the K loop is LDS-bound) whenever the
+        // output is a multiple of 256 channels and T fills 256-frame tiles about as well as 128-frame ones; otherwise
+        // row-complete 256x128 tiles where the epilogue carries a LayerNorm, the 3-buffer pipeline for deep k=3
+        // convs, 128x128 tiles for the rest.  ST_GEMM_TILE=0|1|2|3 forces a configuration where it is legal.
+        static const int force = [] { const char* v = getenv("ST_GEMM_TILE"); return v ? atoi(v) : -1; }();
+        const int T = a.T;
+        const bool fills = ((T + 255) / 256) * 256 * 10 <= ((T + 127) / 128) * 128 * 11;
+        int cfg;
+        if (a.cout % 256 == 0 && fills) cfg = G2_BIG;
+        else if (a.ln_h16) cfg = G2_RC;
+        else if (taps == 3 && a.c0 + a.c1 >= 512) cfg = G2_K3PIPE;
+        else cfg = G2_T128;
+        if (force >= 0 && !a.ln_h16) {
+            if (force == G2_BIG && a.cout % 256 == 0) cfg = G2_BIG;
+            else if (force == G2_K3PIPE && taps == 3) cfg = G2_K3PIPE;
+            else if (force == G2_T128) cfg = G2_T128;
+        }
         return bf ? launch_conv_gemm2_bf16(cfg, taps, epi, a, s) : launch_conv_gemm2_f16(cfg, taps, epi, a, s);
     }
     return bf ? launch_conv_gemm_bf16(taps, epi, a, s) : launch_conv_gemm_f16(taps, epi, a, s);
@@ -377,10 +391,10 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
     const bool cap = e->capture;
     // measured on MI355X (profiles/): fused FiLM+LN epilogues on row-complete tiles are a wash against the faster
     // 128x128 tiles + separate LayerNorm launches (38.2 vs 38.0 ms/solve), so fusion is opt-in: ST_FUSE_LN=1
-    // ST_FUSE_LN (default 0; measured 34.9 / 35.1 / 35.3 ms per solve for 0 / 1 / 2 on MI355X):
+    // ST_FUSE_LN (default 2; with the 256x256 row-complete tiles: 34.9 / 34.3 / 34.0 ms per solve for 0 / 1 / 2):
     // 0 = every FiLM/LayerNorm is its own launch, 1 = fused into the long-skip convs and
     // FFN conv_2 -> next block's LN1), 2 = fused everywhere (also in_proj and out_proj)
-    static const int fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v ? atoi(v) : 0; }();
+    static const int fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v ? atoi(v) : 2; }();
     const bool fuse = use_gen2() && fuse_env >= 1;        // lsc + ffn2
     const bool fuse_all = use_gen2() && fuse_env >= 2;    // + in_proj, out_proj
     auto ada_of = [&](int i) { return p.ada + (size_t)i * N * 6 * C; };

@@ -44,7 +44,8 @@ hipError_t launch_conv_gemm_bf16(int taps, int epi, const ConvGemmArgs& a, hipSt
 hipError_t launch_conv_gemm_f16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 // second generation (conv_gemm2_impl.h): cfg 0 = 128x128 tile, cfg 1 = row-complete 256x128 tile (cout % 256 == 0,
 // may carry the fused FiLM + LayerNorm + modulate of the next op through the ln_* fields)
-enum { G2_T128 = 0, G2_RC = 1, G2_K3PIPE = 2 };   // K3PIPE: k=3 only, three weight buffers, counted vmcnt
+enum { G2_T128 = 0, G2_RC = 1, G2_K3PIPE = 2,   // K3PIPE: k=3 only, three weight buffers, counted vmcnt
+       G2_BIG = 3 };                             // 256 x 256 tile, 8 waves of 128 x 64 (cout % 256 == 0)
 hipError_t launch_conv_gemm2_bf16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 hipError_t launch_conv_gemm2_f16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;

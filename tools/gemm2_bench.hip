@@ -113,6 +113,16 @@ static void run_shape(const char* name, int items, int T, int c0, int c1, int co
             printf(" | +LN %7.1f us", t3 * 1e3);
         }
     }
+    if (cout % 256 == 0) {
+        auto l_y = [&] { return launch_g2<OpBF16, TAPS, EPI, 256, 256, 2, 4>(a, nullptr); };
+        const bool oky = cmp(snapshot(l_y));
+        const float ty = timeit(l_y);
+        printf(" | g2-256x256(2x4) %7.1f us %6.1f TF/s %s", ty * 1e3, flops / (ty * 1e-3) / 1e12, oky ? "==" : "MISMATCH");
+        auto l_y2 = [&] { return launch_g2<OpBF16, TAPS, EPI, 256, 256, 4, 2>(a, nullptr); };
+        const bool oky2 = cmp(snapshot(l_y2));
+        const float ty2 = timeit(l_y2);
+        printf(" | g2-256x256(4x2) %7.1f us %6.1f TF/s %s", ty2 * 1e3, flops / (ty2 * 1e-3) / 1e12, oky2 ? "==" : "MISMATCH");
+    }
     if constexpr (TAPS == 3) {
         auto l_g3 = [&] { return launch_g3<OpBF16, EPI>(a, nullptr); };
         const bool ok3 = cmp(snapshot(l_g3));
