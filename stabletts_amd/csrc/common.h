@@ -78,6 +78,14 @@ __device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wav
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(off) : "memory");
 }
+// same transfer with the address split as SGPR base + 32-bit per-lane offset (global saddr form): the per-lane
+// part is loop invariant and precomputed once, the per-stage part is scalar arithmetic
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
+    const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(off) : "memory");
+}
 #define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #else
 __device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {

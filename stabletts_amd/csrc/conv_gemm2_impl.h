@@ -20,6 +20,18 @@
 #ifndef ST_FRAG_PREFETCH
 #define ST_FRAG_PREFETCH 0
 #endif
+#ifndef ST_DMA_SPREAD
+#define ST_DMA_SPREAD 0
+#endif
+#ifndef ST_STAGE_TIMING
+#define ST_STAGE_TIMING 0
+#endif
+#ifndef ST_DMA_FAST
+#define ST_DMA_FAST 1
+#endif
+#ifndef ST_DMA_SPLIT
+#define ST_DMA_SPLIT 0
+#endif
 
 namespace st {
 
@@ -30,7 +42,7 @@ struct G2Cfg {
     static constexpr int AROWS = BF + TAPS - 1;
     static constexpr int A_BYTES = AROWS * 128, W_BYTES = BC * 128;
     static constexpr int PITCH = BC + 4;                       // fp32 words per staged frame row
-    static constexpr int STAGE_BYTES = TF * PITCH * 4;
+    static constexpr int STAGE_BYTES = (NW == 8 ? TF : BF) * PITCH * 4;
     static constexpr int LOOP_BYTES = 2 * A_BYTES + 2 * W_BYTES;
     static constexpr int LDS_BYTES = LOOP_BYTES > STAGE_BYTES ? LOOP_BYTES : STAGE_BYTES;
     static_assert((BC / 8) % NW == 0 && (BF / 8) % NW == 0, "DMA pieces must split evenly over the waves");
@@ -117,36 +129,42 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
     static_assert(EPI != EPI_QKV, "the QKV epilogue lives in conv_gemm_impl.h");
     static_assert(BC == 128 || BC == 256, "row walker handles 128 or 256 channels");
     constexpr bool LN = (BC == 256);
-    constexpr int RPW = LN ? TF / NW : TF / (2 * NW);        // wave-rows (1 or 2 frames each) per wave per pass
+    // frames staged per pass: the 4-wave 128x128 tile goes in ONE pass (fewer barriers, one exposed global-load
+    // latency: out_proj 38 -> 35 us); the 8-wave tiles keep 64-frame passes (128-frame passes need 16 preloaded
+    // residual rows per lane on top of the live accumulators and spill: FFN conv_2 104 -> 113 us)
+    constexpr int PASSF = (NW == 8) ? TF : BF, WFP = PASSF / TF, NPASS = BF / PASSF;
+    static_assert(PASSF % TF == 0 && BF % PASSF == 0, "pass geometry");
+    constexpr int RPW = LN ? PASSF / NW : PASSF / (2 * NW);  // wave-rows (1 or 2 frames each) per wave per pass
     const int chl = LN ? lane * 4 : l31 * 4;                 // this lane's channel quad inside the block tile
     const G2Consts kc = g2_consts<EPI, LN>(g, n, cbase + chl);
     const float* mrow = g.mask ? g.mask + (size_t)(n % g.mask_mod) * T : nullptr;
     const int an = n < g.add_clamp ? n : g.add_clamp;
 #pragma unroll 1
-    for (int p = 0; p < WF; ++p) {
-        if (wf == p) {
+    for (int p = 0; p < NPASS; ++p) {
+        if (wf / WFP == p) {
+            const int fbase = (wf % WFP) * TF;
 #pragma unroll
             for (int a = 0; a < FC; ++a)
 #pragma unroll
                 for (int b = 0; b < FF; ++b)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const int fl = b * 32 + l31;
+                        const int fl = fbase + b * 32 + l31;
                         const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
                         *(float4*)(stage + fl * PITCH + ch) = make_float4(acc[a][b][4 * q4 + 0], acc[a][b][4 * q4 + 1],
                                                                           acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]);
                     }
         }
-        __syncthreads();
-        const int tbase = t0 + p * TF;
-        // all global inputs of this wave's rows are requested first (memory latency overlaps across rows) ...
+        const int tbase = t0 + p * PASSF;
+        // every global input of this wave's rows is requested before the barrier: the latency overlaps the other
+        // waves' staging stores and the barrier wait
         float mk[RPW]; float4 xin[RPW]; int fr[RPW];
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int f = LN ? (wave + u * NW) : ((wave + u * NW) * 2 + hi);
             const int t = tbase + f;
             fr[u] = f;
-            const bool ok = (t < T) && (p * TF + f < fvalid);
+            const bool ok = (t < T) && (p * PASSF + f < fvalid);
             mk[u] = (ok && mrow) ? mrow[t] : (ok ? 1.0f : 0.0f);
             xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
@@ -154,16 +172,17 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
                 if constexpr (EPI == EPI_F32) { if (g.add32) xin[u] = *(const float4*)(g.add32 + ((size_t)an * T + t) * g.cout + cbase + chl); }
             }
         }
+        __syncthreads();
         // ... then each row is finished from LDS
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int t = tbase + fr[u];
             const float4 v = *(const float4*)(stage + fr[u] * PITCH + chl);
-            const bool ok = (t < T) && (p * TF + fr[u] < fvalid);
+            const bool ok = (t < T) && (p * PASSF + fr[u] < fvalid);
             if (LN) { if (ok) g2_apply<P, EPI, true>(g, kc, n, t, cbase + chl, v, mk[u], xin[u]); }   // wave-uniform branch
             else    { if (ok) g2_apply<P, EPI, false>(g, kc, n, t, cbase + chl, v, mk[u], xin[u]); }
         }
-        __syncthreads();
+        if (p + 1 < NPASS) __syncthreads();
     }
 }
 
@@ -204,15 +223,65 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const unsigned char* zeros = (const unsigned char*)g.zeros;
 
     const int prow = lane >> 3;
+    // ST_DMA_SPLIT (8-wave tiles): only waves 0..3 -- one per SIMD -- issue LDS-DMA.  Issuing a piece costs the
+    // issuing wave ~100 cycles (measured with s_memtime: 560 of 2700 ticks per stage when all 8 waves issue in
+    // lockstep and the matrix pipe idles meanwhile); with one loader wave per SIMD its partner wave (4..7)
+    // owns the matrix pipe during the issue phase, and the loader's MFMAs follow.
+    constexpr int NL = (ST_DMA_SPLIT && NW == 8) ? NW / 2 : NW;    // number of DMA-issuing waves
+    constexpr int WPW = (BC / 8) / NL, APW = (BF / 8) / NL;       // 1-KiB DMA pieces per loader wave per tile
+    const bool loader = wave < NL;
+    auto issueW1 = [&](int c, int j, int buf, int k) {
+        const int piece = wave * WPW + k;
+        const int row = piece * 8 + prow;
+        const int seg = (lane & 7) ^ ((row >> 1) & 7);
+        const unsigned char* src = wsrc + ((size_t)((cbase + row) * TAPS + j) * cin + (c << 6)) * 2 + seg * 16;
+        glds16b(src, Ws + buf * W_BYTES + piece * 1024);
+    };
+#if ST_DMA_FAST
+    // Loop-invariant per-lane parts of every DMA source address, computed once: the per-stage part is scalar.
+    // Activation rows outside [0, T) are never transferred; their LDS rows are zeroed once, here.
+    unsigned voffW[WPW], voffA0[APW + 1], voffA1[APW + 1];
+    bool validA[APW + 1];
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) {
+        const int row = (wave * WPW + k) * 8 + prow;
+        voffW[k] = (unsigned)((cbase + row) * TAPS * cin * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int k = 0; k <= APW; ++k) {
+        const int row = (k < APW) ? (wave * APW + k) * 8 + prow : BF + prow;
+        const int t = t0 + row - (TAPS / 2);
+        const unsigned segb = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        validA[k] = loader && (t >= 0 && t < T) && (k < APW || (TAPS == 3 && wave == 0 && lane < 16));
+        voffA0[k] = (unsigned)(t * g.c0 * 2) + segb;
+        voffA1[k] = (unsigned)(t * g.c1 * 2) + segb;
+        const bool mine = loader && ((k < APW) || (TAPS == 3 && wave == 0 && lane < 16));
+        if (mine && !(t >= 0 && t < T)) {
+            const int pc = (k < APW) ? wave * APW + k : BF / 8;
+            *(uint4*)(As + pc * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(As + A_BYTES + pc * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    auto issueW = [&](int c, int j, int buf) {
+        const unsigned char* sb = wsrc + (size_t)(j * cin + (c << 6)) * 2;
+#pragma unroll
+        for (int k = 0; k < WPW; ++k) glds16s(sb, voffW[k], Ws + buf * W_BYTES + (wave * WPW + k) * 1024);
+    };
+    auto issueA = [&](int c, int buf) {
+        const int ch0 = c << 6;
+        const bool first = ch0 < g.c0;
+        const unsigned char* sb = first ? a0 + (size_t)ch0 * 2 : a1 + (size_t)(ch0 - g.c0) * 2;
+#pragma unroll
+        for (int k = 0; k <= APW; ++k) {
+            if (k == APW && TAPS != 3) continue;
+            const int pc = (k < APW) ? wave * APW + k : BF / 8;
+            if (validA[k]) glds16s(sb, first ? voffA0[k] : voffA1[k], As + buf * A_BYTES + pc * 1024);
+        }
+    };
+#else
     auto issueW = [&](int c, int j, int buf) {
 #pragma unroll
-        for (int k = 0; k < (BC / 8) / NW; ++k) {
-            const int piece = wave * ((BC / 8) / NW) + k;
-            const int row = piece * 8 + prow;
-            const int seg = (lane & 7) ^ ((row >> 1) & 7);
-            const unsigned char* src = wsrc + ((size_t)((cbase + row) * TAPS + j) * cin + (c << 6)) * 2 + seg * 16;
-            glds16b(src, Ws + buf * W_BYTES + piece * 1024);
-        }
+        for (int k = 0; k < WPW; ++k) issueW1(c, j, buf, k);
     };
     auto issueA = [&](int c, int buf) {
         const int ch0 = c << 6;
@@ -220,8 +289,8 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
         if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
         else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
 #pragma unroll
-        for (int k = 0; k < (BF / 8) / NW; ++k) {
-            const int piece = wave * ((BF / 8) / NW) + k;
+        for (int k = 0; k < APW; ++k) {
+            const int piece = wave * APW + k;
             const int row = piece * 8 + prow;
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const int t = t0 + row - (TAPS / 2);
@@ -238,6 +307,38 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
             }
         }
     };
+#endif
+    // one slice (k-step ks of 4) of the same transfers, for spreading the DMA issue over the MFMA k-steps
+    auto issueA_slice = [&](int c, int buf, int ks) {
+        const int ch0 = c << 6;
+        const unsigned char* srcb; int cs, coff;
+        if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
+        else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
+#pragma unroll
+        for (int k = 0; k < APW; ++k) {
+            if ((k * 4) / APW != ks) continue;
+            const int piece = wave * APW + k;
+            const int row = piece * 8 + prow;
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const int t = t0 + row - (TAPS / 2);
+            const unsigned char* src = (t >= 0 && t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
+            glds16b(src, As + buf * A_BYTES + piece * 1024);
+        }
+        if constexpr (TAPS == 3) {
+            if (ks == 3 && wave == 0 && lane < 16) {
+                const int row = BF + prow;
+                const int seg = (lane & 7) ^ ((row >> 1) & 7);
+                const int t = t0 + row - 1;
+                const unsigned char* src = (t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
+                glds16b(src, As + buf * A_BYTES + (BF / 8) * 1024);
+            }
+        }
+    };
+    auto issueW_slice = [&](int c, int j, int buf, int ks) {
+#pragma unroll
+        for (int k = 0; k < WPW; ++k)
+            if ((k * 4) / WPW == ks) issueW1(c, j, buf, k);
+    };
 
     f32x16_t acc[FC][FF];
 #pragma unroll
@@ -253,7 +354,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
         const int row = wc * TC + a * 32 + l31;
         wrow_off[a] = row * 128; wswz[a] = (row >> 1) & 7;
     }
-    auto compute = [&](int abuf, int wbuf, int j) {
+    auto compute = [&](int abuf, int wbuf, int j, auto&& pre) {
         const unsigned char* Ab = As + abuf * A_BYTES;
         const unsigned char* Wb = Ws + wbuf * W_BYTES;
         int arow_off[FF], aswz[FF];
@@ -272,18 +373,24 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #pragma unroll
             for (int b = 0; b < FF; ++b) afr[slot][b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
         };
-        ldf(0, 0); ldf(1, 1);
+        // sched_barrier pins the order "issue the reads of k-step ks+1, THEN the MFMAs of k-step ks": left alone,
+        // hipcc shrinks the fragment registers to one set and waits on a ds_read in front of every MFMA pair
+        ldf(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            pre(ks);
+            if (ks + 1 < 4) ldf(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < FC; ++a)
 #pragma unroll
                 for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[ks & 1][a], afr[ks & 1][b], acc[a][b]);
-            if (ks + 2 < 4) ldf(ks + 2, ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            pre(ks);
             vec8 wfr[FC], afr[FF];
             const int seg = ks * 2 + hi;
 #pragma unroll
@@ -298,24 +405,69 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #endif
     };
 
-    issueA(0, 0); issueW(0, 0, 0);
+    if (loader) { issueA(0, 0); issueW(0, 0, 0); }
     ST_DMA_WAIT(0);
     __syncthreads();
+#if ST_STAGE_TIMING
+    unsigned long long tm_issue = 0, tm_compute = 0, tm_dma = 0, tm_barrier = 0, tm_n = 0;
+    unsigned long long tS = __builtin_amdgcn_s_memtime();
+    const unsigned long long tStart = tS;
+#endif
     int it = 0;
     for (int c = 0; c < nch; ++c) {
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) {
             const bool last = (c == nch - 1) && (j == TAPS - 1);
-            if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
-            if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
-            compute(c & 1, it & 1, j);      // the DMA issued above flies underneath these MFMAs
+#if ST_DMA_SPREAD
+            // the LDS-DMA of the next stage is issued in four slices, one per k-step, between the MFMA groups:
+            // a burst of 8 pieces at the top of the stage keeps an in-order wave out of the matrix pipe for
+            // several hundred cycles (MI355X_MICROARCH.md: 100-185 cycles per piece inside a busy phase)
+            const bool doA = (j == 0) && (c + 1 < nch);
+            const int nc = (j == TAPS - 1) ? c + 1 : c, nj = (j == TAPS - 1) ? 0 : j + 1;
+            compute(c & 1, it & 1, j, [&](int ks) {
+                if (loader && doA) issueA_slice(c + 1, (c + 1) & 1, ks);
+                if (loader && !last) issueW_slice(nc, nj, (it + 1) & 1, ks);
+            });
+#else
+            if (loader) {
+                if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
+                if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
+            }
+#if ST_STAGE_TIMING
+            const unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
+            compute(c & 1, it & 1, j, [](int) {});      // the DMA issued above flies underneath these MFMAs
+#endif
+#if ST_STAGE_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tB = __builtin_amdgcn_s_memtime();
+#endif
             ST_DMA_WAIT(0);                 // this wave's pieces of the next stage have landed ...
+#if ST_STAGE_TIMING
+            const unsigned long long tC = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                // ... everyone's have, and everyone is done reading this stage
+#if ST_STAGE_TIMING
+            {
+                const unsigned long long tD = __builtin_amdgcn_s_memtime();
+                tm_issue += tA - tS; tm_compute += tB - tA; tm_dma += tC - tB; tm_barrier += tD - tC; tS = tD; ++tm_n;
+            }
+#endif
             ++it;
         }
     }
 
+#if ST_STAGE_TIMING
+    const unsigned long long tLoop = __builtin_amdgcn_s_memtime();
+#endif
     g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BF, cbase, wave, lane);
+#if ST_STAGE_TIMING
+    if (g.dbg && lane == 0 && (wave == 0 || wave == NW - 1) && lin < 64) {
+        unsigned long long* d = g.dbg + (size_t)(lin * 2 + (wave ? 1 : 0)) * 8;
+        d[0] = tm_issue; d[1] = tm_compute; d[2] = tm_dma; d[3] = tm_barrier; d[4] = tm_n;
+        d[5] = tLoop - tStart; d[6] = __builtin_amdgcn_s_memtime() - tLoop; d[7] = 1;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,11 +477,13 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 // 128 rows = frames t0-1 .. t0+126 (126 valid output frames + its own halo), which makes the footprint
 // 2*16 KB (A) + 3*16 KB (W) = 80 KB: two blocks per CU.  Frame columns 126,127 of the accumulator read two
 // rows past the A tile (harmless garbage inside the block's own LDS) and are discarded by the epilogue.
-template <class P, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g) {
+template <class P, int EPI, int BC, int BF, int WC, int WF>
+__global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvGemmArgs g) {
     using vec8 = typename P::vec8;
-    constexpr int BC = 128, BF = 128, BFV = 126, WC = 2, WF = 2, TC = 64, TF = 64, FC = 2, FF = 2;
-    constexpr int A_BYTES = 128 * 128, W_BYTES = 128 * 128;
+    constexpr int BFV = BF - 2, NW = WC * WF, TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32;
+    constexpr int A_BYTES = BF * 128, W_BYTES = BC * 128;
+    constexpr int WPW = (BC / 8) / NW, APW = (BF / 8) / NW;     // 1-KiB DMA pieces per wave per tile
+    static_assert(WPW == 4 && APW == 4, "the counted waits below assume 4 + 4 pieces per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                    // 2 buffers
     unsigned char* Ws = smem + 2 * A_BYTES;      // 3 buffers
@@ -361,8 +515,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g
     const int prow = lane >> 3;
     auto issueW = [&](int c, int j, int buf) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int piece = wave * 4 + k;
+        for (int k = 0; k < WPW; ++k) {
+            const int piece = wave * WPW + k;
             const int row = piece * 8 + prow;
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const unsigned char* src = wsrc + ((size_t)((cbase + row) * 3 + j) * cin + (c << 6)) * 2 + seg * 16;
@@ -375,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g
         if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
         else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int piece = wave * 4 + k;
+        for (int k = 0; k < APW; ++k) {
+            const int piece = wave * APW + k;
             const int row = piece * 8 + prow;
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const int t = t0 + row - 1;
@@ -418,14 +572,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g
 #pragma unroll
             for (int b = 0; b < FF; ++b) afr[slot][b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
         };
-        ldf(0, 0); ldf(1, 1);
+        // sched_barrier pins the order "issue the reads of k-step ks+1, THEN the MFMAs of k-step ks": left alone,
+        // hipcc shrinks the fragment registers to one set and waits on a ds_read in front of every MFMA pair
+        ldf(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) ldf(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < FC; ++a)
 #pragma unroll
                 for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[ks & 1][a], afr[ks & 1][b], acc[a][b]);
-            if (ks + 2 < 4) ldf(ks + 2, ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #else
 #pragma unroll
@@ -475,22 +633,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm3_kernel(const ConvGemmArgs g
     g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
 }
 
-template <class P, int EPI>
+template <class P, int EPI, int BC = 128, int BF = 128, int WC = 2, int WF = 2>
 static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
-    constexpr int lds = 5 * 128 * 128;
+    constexpr int lds_loop = 2 * BF * 128 + 3 * BC * 128, lds_stage = (WC * WF == 8 ? BF / WF : BF) * (BC + 4) * 4;
+    constexpr int lds = lds_loop > lds_stage ? lds_loop : lds_stage;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm3_kernel<P, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm3_kernel<P, EPI, BC, BF, WC, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (!a.zeros || (a.cout % 128) != 0 || ((a.c0 + a.c1) & 63) != 0) return hipErrorInvalidValue;
+    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 + a.c1) & 63) != 0) return hipErrorInvalidValue;
     ConvGemmArgs b = a;
-    b.tiles_f = (a.T + 125) / 126;
-    b.tiles_c = a.cout / 128;
+    b.tiles_f = (a.T + BF - 3) / (BF - 2);
+    b.tiles_c = a.cout / BC;
     const int total = b.n_items * b.tiles_f * b.tiles_c;
     const int grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL((conv_gemm3_kernel<P, EPI>), dim3(grid), dim3(256), lds, s, b);
+    hipLaunchKernelGGL((conv_gemm3_kernel<P, EPI, BC, BF, WC, WF>), dim3(grid), dim3(64 * WC * WF), lds, s, b);
     return hipGetLastError();
 }
 

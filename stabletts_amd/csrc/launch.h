@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     const float* ln_film; int ln_film_stride; int ln_film_mod;     // gamma = film[(n%mod)*stride + ch], beta = +256
     const float* ln_ada; int ln_ada_stride; int ln_shift_off; int ln_scale_off;
     int ln_mask_out;
+    unsigned long long* dbg;          // diagnostics (ST_STAGE_TIMING builds of tools/gemm2_bench only), else nullptr
 };
 
 hipError_t launch_conv_gemm_bf16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);

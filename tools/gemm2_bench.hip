@@ -113,6 +113,24 @@ static void run_shape(const char* name, int items, int T, int c0, int c1, int co
             printf(" | +LN %7.1f us", t3 * 1e3);
         }
     }
+#if ST_STAGE_TIMING
+    {
+        unsigned long long* dbg; CK(hipMalloc((void**)&dbg, 64 * 2 * 8 * 8)); CK(hipMemset(dbg, 0, 64 * 2 * 8 * 8));
+        ConvGemmArgs b = a; b.dbg = dbg;
+        auto run = [&](const char* tag, auto launch) {
+            CK(hipMemset(dbg, 0, 64 * 2 * 8 * 8)); CK(launch()); CK(launch()); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(64 * 2 * 8); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            double s[7] = {0}; int nb = 0;
+            for (int i = 0; i < 128; ++i) if (h[i * 8 + 7]) { for (int k = 0; k < 7; ++k) s[k] += (double)h[i * 8 + k]; ++nb; }
+            if (!nb) return;
+            const double n = s[4] / nb;
+            printf("\n   [%s timing, %d waves sampled, %.0f stages: per stage (memtime ticks) issue %.0f | ds_read+mfma %.0f | dma wait %.0f | barrier %.0f ; loop total %.0f, epilogue %.0f]",
+                   tag, nb, n, s[0] / s[4], s[1] / s[4], s[2] / s[4], s[3] / s[4], s[5] / nb, s[6] / nb);
+        };
+        run("128x128", [&] { return launch_g2<OpBF16, TAPS, EPI, 128, 128, 2, 2>(b, nullptr); });
+        if (cout % 256 == 0) run("256x256", [&] { return launch_g2<OpBF16, TAPS, EPI, 256, 256, 2, 4>(b, nullptr); });
+    }
+#endif
     if (cout % 256 == 0) {
         auto l_y = [&] { return launch_g2<OpBF16, TAPS, EPI, 256, 256, 2, 4>(a, nullptr); };
         const bool oky = cmp(snapshot(l_y));
@@ -128,6 +146,12 @@ static void run_shape(const char* name, int items, int T, int c0, int c1, int co
         const bool ok3 = cmp(snapshot(l_g3));
         const float t4 = timeit(l_g3);
         printf(" | g3(3-buf) %7.1f us %6.1f TF/s %s", t4 * 1e3, flops / (t4 * 1e-3) / 1e12, ok3 ? "==" : "MISMATCH");
+        if (cout % 256 == 0) {
+            auto l_g3b = [&] { return launch_g3<OpBF16, EPI, 256, 256, 2, 4>(a, nullptr); };
+            const bool ok3b = cmp(snapshot(l_g3b));
+            const float t5 = timeit(l_g3b);
+            printf(" | g3-256x256 %7.1f us %6.1f TF/s %s", t5 * 1e3, flops / (t5 * 1e-3) / 1e12, ok3b ? "==" : "MISMATCH");
+        }
     }
     printf("\n"); fflush(stdout);
 }
