@@ -83,9 +83,27 @@ class CFMDecoder(nn.Module):
         uncond = self.estimator(t, x, mask, fake_content, fake_speaker)
         return uncond + s * (cond - uncond)
 
-    def compute_loss(self, x1, mask, mu, c):
-        """models/flow_matching.py:69-100.  The backward pass of the estimator is not native yet
-        (SURVEY.md section 8f-1): training needs autograd through the estimator, which this
-        inference engine does not record."""
-        raise NotImplementedError("compute_loss: native backward kernels are not implemented yet "
-                                  "(inference path only); see DESIGN.md 'what comes next'")
+    def compute_loss(self, x1, mask, mu, c, t_rand=None, z=None):
+        """models/flow_matching.py:69-100: CFM training loss and the interpolant ``y``.
+
+        The forward arithmetic is native: cosine-warped per-item ``t``, ``y = (1-(1-sigma)t) z + t x1``,
+        ``u = x1 - (1-sigma) z`` (elementwise torch ops on the device), ONE native estimator evaluation with a
+        per-item ``t`` (st_estimator_forward, t_len = B) and the masked-sum MSE -- including the reference's quirk
+        that ``u`` is not masked (:99).  The result carries NO autograd graph: the backward kernels are not built
+        yet, so this serves validation / parity, and calling it while gradients are required
+        raises instead of silently training nothing.  ``t_rand`` (B,1,1) and ``z`` may be passed to fix the draws.
+        """
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.estimator.parameters()):
+            raise NotImplementedError("compute_loss: native backward kernels are not implemented yet; call it under "
+                                      "torch.no_grad() for the (native) forward value, see DESIGN.md 'what comes next'")
+        b = mu.shape[0]
+        if t_rand is None:
+            t_rand = torch.rand([b, 1, 1], device=mu.device, dtype=mu.dtype)
+        t = 1 - torch.cos(t_rand * 0.5 * torch.pi)
+        if z is None:
+            z = torch.randn_like(x1)
+        y = (1 - (1 - self.sigma_min) * t) * z + t * x1
+        u = x1 - (1 - self.sigma_min) * z
+        pred = self.estimator(t.squeeze() if b > 1 else t.reshape(()), y, mask, mu, c)
+        loss = torch.nn.functional.mse_loss(pred, u, reduction="sum") / (torch.sum(mask) * u.size(1))
+        return loss, y

@@ -257,6 +257,22 @@ def test_parameter_update_is_picked_up(sd):
     assert float((b - a).mean()) == pytest.approx(1.0, abs=1e-3)
 
 
+def test_compute_loss_forward_vs_reference_fixture(decoders, golden):
+    """CFMDecoder.compute_loss forward (flow_matching.py:69-100) against the REAL reference's value, same draws."""
+    inp = make_inputs(2, 44, seed=31, lengths=[44, 29])
+    x1 = make_inputs(2, 44, seed=32)["z"]
+    want = float(golden["loss_value"][0])
+    for dt, tol in (("bf16", 3e-3), ("f16", 5e-4)):
+        with torch.no_grad():
+            loss, y = decoders[dt].compute_loss(x1.cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda(),
+                                                t_rand=torch.from_numpy(golden["loss_t_rand"]).cuda(),
+                                                z=torch.from_numpy(golden["loss_z"]).cuda())
+        assert abs(float(loss) - want) <= tol * want, (dt, float(loss), want)
+        assert _rel(y.cpu(), torch.from_numpy(golden["loss_y"])) <= 1e-6
+    with pytest.raises(NotImplementedError):       # training needs the (not yet native) backward pass
+        decoders["bf16"].compute_loss(x1.cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+
+
 def test_error_behaviour(decoders):
     d = decoders["bf16"]
     inp = make_inputs(2, 16, seed=1)
