@@ -211,6 +211,31 @@ def test_adaptive_dopri5_vs_oracle(decoders, cfg_params, dopri5_case, dt, solver
         assert torch.equal(out[pad], inp["z"][pad])      # the field is exactly 0 on padded frames for every stage
 
 
+def test_attention_rescale_branch_with_peaky_scores(sd):
+    """Online-softmax rescale path: with q/k projections scaled 6x the row maxima keep growing across key tiles
+    by more than the deferred-rescale threshold, so the (otherwise rare) rescale branch of attention.hip runs on
+    most tiles.  f16 operands (score rounding error scales with |score|); vs the fp32 oracle with the same weights."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for i in range(6):
+        for nm in ("q", "k"):
+            sd2[f"blocks.{i}.block.attn.conv_{nm}.weight"] *= 6.0
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+    dec.estimator.load_state_dict(sd2)
+    dec = dec.cuda()
+    inp = make_inputs(2, 300, seed=17, lengths=[300, 201])
+    t = torch.tensor(0.6)
+    taps = {}
+    with torch.inference_mode():
+        ref = oracle.decoder_forward(sd2, t, inp["z"], inp["mask"], inp["mu"], inp["c"], taps=taps)
+    # the scores really are peaky: log2-domain row maxima far above the deferral threshold of 6
+    smax = (taps["b0.q"] @ taps["b0.k"].transpose(-1, -2)).amax(-1) * (math.log2(math.e) / 8.0)
+    assert float(smax.median()) > 12.0
+    out = dec.estimator(t, inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+    assert torch.isfinite(out).all()
+    assert _rel(out, ref) <= 4e-3
+
+
 def test_cfg_strength_one_equals_cond_branch(decoders, cfg_params):
     inp = make_inputs(2, 80, seed=4, lengths=[80, 61])
     a = _solve(decoders["f16"], inp, 3, "euler", _cfg(cfg_params, 1.0, True), inp["z"])
