@@ -86,12 +86,12 @@ def cpu_baseline(sd, cfg_params, budget_s=20.0):
 
 # kernel that implements each profiled class on the default path (for the PMC traffic lookup)
 CLASS_KERNEL = {
-    "ffn_conv1": "conv_gemm2_kernel<st::Op{DT}, 3, 0, 128, 128, 2, 2>",
-    "ffn_conv2": "conv_gemm3_kernel<st::Op{DT}, 2>",
-    "lsc_conv": "conv_gemm3_kernel<st::Op{DT}, 1>",
+    "ffn_conv1": "conv_gemm2_kernel<st::Op{DT}, 3, 0, 256, 256, 2, 4>",
+    "ffn_conv2": "conv_gemm2_kernel<st::Op{DT}, 3, 2, 256, 256, 2, 4>",
+    "lsc_conv": "conv_gemm2_kernel<st::Op{DT}, 3, 1, 256, 256, 2, 4>",
     "attention": "attention_kernel<st::Op{DT}>",
     "qkv_rope": "conv_gemm_glds_kernel<st::Op{DT}, 1, 3, 0>",
-    "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 128, 128, 2, 2>",
+    "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4>",
 }
 
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile: rocprofv3 kernel stats + two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command.
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
+TAG=${1:-r01_v4}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
+cd $ROOT
+KS=$(find $OUT/kt -name '*kernel_stats.csv' | head -1)
+FC=$(find $OUT/fetch -name '*counter_collection.csv' | head -1)
+WC=$(find $OUT/write -name '*counter_collection.csv' | head -1)
+python tools/rocprof_summary.py stats $KS > $OUT/kernel_stats.txt
+python tools/rocprof_summary.py pmc $FC $WC $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
+ls $OUT; head -12 $OUT/kernel_stats.txt; head -12 $OUT/pmc_traffic.txt
