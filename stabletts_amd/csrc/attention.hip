@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor32_max(mx);
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
         __syncthreads();      // fence the buffer swap
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xor32_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (query < T) {
         unsigned char* dst = (unsigned char*)a.out + (((size_t)n * T + query) * (H * 64) + h * 64) * 2;

@@ -55,10 +55,26 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// Cross-lane reductions on the VALU (DPP row rotations + gfx950 v_permlane{16,32}_swap): __shfl_xor lowers to
+// ds_bpermute_b32, an LDS-crossbar round trip of ~60+ cycles per step on the dependent chain.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+// value of lane^32 combined with the lane's own: both halves end up with op(v[l], v[l^32])
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum over the 64 lanes, result in every lane (deterministic order)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = dpp_add<0x128>(v); v = dpp_add<0x124>(v); v = dpp_add<0x122>(v); v = dpp_add<0x121>(v);   // row_ror 8,4,2,1
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return xor32_sum(__uint_as_float(a[0]) + __uint_as_float(a[1]));
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;

@@ -73,47 +73,96 @@ __device__ __forceinline__ G2Consts g2_consts(const ConvGemmArgs& g, int n, int 
     return k;
 }
 
-// Handles 4 consecutive channels [ch, ch+4) of frame t of item n.  v = accumulator values, m = mask value of
-// the frame, xin = preloaded residual row (EPI_RESGATE) or addend row (EPI_F32 with add32).  LN = the wave
-// holds one complete 256-channel row, so FiLM + LayerNorm + modulate of the next op can be applied.
-template <class P, int EPI, bool LN>
-__device__ __forceinline__ void g2_apply(const ConvGemmArgs& g, const G2Consts& k, int n, int t, int ch, float4 v,
-                                         float m, float4 xin) {
-    const size_t grow = (size_t)n * g.T + t;
-    v.x += k.bias.x; v.y += k.bias.y; v.z += k.bias.z; v.w += k.bias.w;
+// Finishes R rows at once: row u = 4 consecutive channels [ch, ch+4) of frame t[u] of item n.  v = accumulator
+// values, m = mask value of the frame, xin = preloaded residual row (EPI_RESGATE) or addend row (EPI_F32 with
+// add32), ok = row inside the tensor (only the STORES are predicated: the arithmetic of an invalid row runs on
+// clamped loads and is dropped).  Written phase by phase over all R rows -- every flag test sits outside a row
+// loop -- so each phase is one basic block and hipcc interleaves the rows' dependent chains (LayerNorm
+// reductions, exp/rcp) instead of serialising them behind per-row branches.
+// LN = the wave holds complete 256-channel rows, so FiLM + LayerNorm + modulate of the next op can be applied.
+template <class P, int EPI, bool LN, int R>
+__device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k, int n, const int (&t)[R],
+                                        const bool (&ok)[R], int ch, float4 (&v)[R], const float (&m)[R],
+                                        const float4 (&xin)[R]) {
+    size_t grow[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) grow[u] = (size_t)n * g.T + t[u];
     if constexpr (EPI == EPI_ACT16) {
-        if (g.flags & GF_SILU) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
-        if (g.flags & GF_MASK) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
-        *(uint2*)((unsigned char*)g.out16 + (grow * g.cout + ch) * 2) = pack4<P>(v.x, v.y, v.z, v.w);
+#pragma unroll
+        for (int u = 0; u < R; ++u) { v[u].x += k.bias.x; v[u].y += k.bias.y; v[u].z += k.bias.z; v[u].w += k.bias.w; }
+        if (g.flags & GF_SILU) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) { v[u].x = silu_fast(v[u].x); v[u].y = silu_fast(v[u].y); v[u].z = silu_fast(v[u].z); v[u].w = silu_fast(v[u].w); }
+        }
+        if (g.flags & GF_MASK) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) { v[u].x *= m[u]; v[u].y *= m[u]; v[u].z *= m[u]; v[u].w *= m[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (ok[u]) *(uint2*)((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2) = pack4<P>(v[u].x, v[u].y, v[u].z, v[u].w);
+        return;
     } else {
         if constexpr (EPI == EPI_F32) {
-            v.x += xin.x; v.y += xin.y; v.z += xin.z; v.w += xin.w;
-            if (g.flags & GF_MASK) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+            const bool msk = g.flags & GF_MASK;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const float mm = msk ? m[u] : 1.0f;
+                v[u].x = (v[u].x + k.bias.x + xin[u].x) * mm; v[u].y = (v[u].y + k.bias.y + xin[u].y) * mm;
+                v[u].z = (v[u].z + k.bias.z + xin[u].z) * mm; v[u].w = (v[u].w + k.bias.w + xin[u].w) * mm;
+            }
         } else {   // EPI_RESGATE: x + gate * ((acc + b) * mask)
-            v.x = xin.x + k.gate.x * (v.x * m); v.y = xin.y + k.gate.y * (v.y * m);
-            v.z = xin.z + k.gate.z * (v.z * m); v.w = xin.w + k.gate.w * (v.w * m);
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                v[u].x = xin[u].x + k.gate.x * ((v[u].x + k.bias.x) * m[u]); v[u].y = xin[u].y + k.gate.y * ((v[u].y + k.bias.y) * m[u]);
+                v[u].z = xin[u].z + k.gate.z * ((v[u].z + k.bias.z) * m[u]); v[u].w = xin[u].w + k.gate.w * ((v[u].w + k.bias.w) * m[u]);
+            }
         }
-        if (g.out16) *(uint2*)((unsigned char*)g.out16 + (grow * g.cout + ch) * 2) = pack4<P>(v.x, v.y, v.z, v.w);
+        if (g.out16) {
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (ok[u]) *(uint2*)((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2) = pack4<P>(v[u].x, v[u].y, v[u].z, v[u].w);
+        }
         if constexpr (LN) {
             if (g.ln_h16) {
                 // the next op's prologue: FiLM (estimator.py:31-33,16), LayerNorm, adaLN modulate
                 if (g.ln_film) {
-                    v.x = (k.ga.x * v.x + k.be.x) * m; v.y = (k.ga.y * v.y + k.be.y) * m;
-                    v.z = (k.ga.z * v.z + k.be.z) * m; v.w = (k.ga.w * v.w + k.be.w) * m;
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        v[u].x = (k.ga.x * v[u].x + k.be.x) * m[u]; v[u].y = (k.ga.y * v[u].y + k.be.y) * m[u];
+                        v[u].z = (k.ga.z * v[u].z + k.be.z) * m[u]; v[u].w = (k.ga.w * v[u].w + k.be.w) * m[u];
+                    }
                 }
-                if (g.out32) *(float4*)(g.out32 + grow * g.cout + ch) = v;
-                const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
-                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-                const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                float h0 = d0 * rstd * (1.0f + k.sc.x) + k.sh.x, h1 = d1 * rstd * (1.0f + k.sc.y) + k.sh.y;
-                float h2 = d2 * rstd * (1.0f + k.sc.z) + k.sh.z, h3 = d3 * rstd * (1.0f + k.sc.w) + k.sh.w;
-                if (g.ln_mask_out) { h0 *= m; h1 *= m; h2 *= m; h3 *= m; }
-                *(uint2*)((unsigned char*)g.ln_h16 + (grow * 256 + ch) * 2) = pack4<P>(h0, h1, h2, h3);
+                if (g.out32) {
+#pragma unroll
+                    for (int u = 0; u < R; ++u)
+                        if (ok[u]) *(float4*)(g.out32 + grow[u] * g.cout + ch) = v[u];
+                }
+                float mean[R], rstd[R];
+#pragma unroll
+                for (int u = 0; u < R; ++u) mean[u] = wave_sum(v[u].x + v[u].y + v[u].z + v[u].w) * (1.0f / 256.0f);
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    v[u].x -= mean[u]; v[u].y -= mean[u]; v[u].z -= mean[u]; v[u].w -= mean[u];
+                    rstd[u] = wave_sum(v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w) * (1.0f / 256.0f);
+                }
+                const bool mout = g.ln_mask_out;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const float rs = 1.0f / sqrtf(rstd[u] + 1e-5f);
+                    const float mm = mout ? m[u] : 1.0f;
+                    const float h0 = (v[u].x * rs * (1.0f + k.sc.x) + k.sh.x) * mm, h1 = (v[u].y * rs * (1.0f + k.sc.y) + k.sh.y) * mm;
+                    const float h2 = (v[u].z * rs * (1.0f + k.sc.z) + k.sh.z) * mm, h3 = (v[u].w * rs * (1.0f + k.sc.w) + k.sh.w) * mm;
+                    if (ok[u]) *(uint2*)((unsigned char*)g.ln_h16 + (grow[u] * 256 + ch) * 2) = pack4<P>(h0, h1, h2, h3);
+                }
                 return;
             }
         }
-        if (g.out32) *(float4*)(g.out32 + grow * g.cout + ch) = v;
+        if (g.out32) {
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (ok[u]) *(float4*)(g.out32 + grow[u] * g.cout + ch) = v[u];
+        }
     }
 }
 
@@ -158,29 +207,32 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
         const int tbase = t0 + p * PASSF;
         // every global input of this wave's rows is requested before the barrier: the latency overlaps the other
         // waves' staging stores and the barrier wait
-        float mk[RPW]; float4 xin[RPW]; int fr[RPW];
+        float mk[RPW]; float4 xin[RPW]; int fr[RPW], tt[RPW]; bool ok[RPW];
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int f = LN ? (wave + u * NW) : ((wave + u * NW) * 2 + hi);
             const int t = tbase + f;
-            fr[u] = f;
-            const bool ok = (t < T) && (p * PASSF + f < fvalid);
-            mk[u] = (ok && mrow) ? mrow[t] : (ok ? 1.0f : 0.0f);
+            fr[u] = f; tt[u] = t;
+            ok[u] = (t < T) && (p * PASSF + f < fvalid);
+            const int tl = t < T ? t : T - 1;            // loads of an invalid row are clamped, its stores dropped
+            mk[u] = mrow ? mrow[tl] : 1.0f;
             xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)(g.out32 + ((size_t)n * T + t) * g.cout + cbase + chl);
-                if constexpr (EPI == EPI_F32) { if (g.add32) xin[u] = *(const float4*)(g.add32 + ((size_t)an * T + t) * g.cout + cbase + chl); }
-            }
+            if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)(g.out32 + ((size_t)n * T + tl) * g.cout + cbase + chl);
+            if constexpr (EPI == EPI_F32) { if (g.add32) xin[u] = *(const float4*)(g.add32 + ((size_t)an * T + tl) * g.cout + cbase + chl); }
         }
         __syncthreads();
-        // ... then each row is finished from LDS
+        // ... then the rows are finished from LDS, all RPW of them phase by phase
+        // (sub-batches of RB rows: 8 rows of the fp32 epilogues in flight on top of the live accumulators spill)
+        constexpr int RB = (EPI != EPI_ACT16 && RPW > 4) ? 4 : RPW;
 #pragma unroll
-        for (int u = 0; u < RPW; ++u) {
-            const int t = tbase + fr[u];
-            const float4 v = *(const float4*)(stage + fr[u] * PITCH + chl);
-            const bool ok = (t < T) && (p * PASSF + fr[u] < fvalid);
-            if (LN) { if (ok) g2_apply<P, EPI, true>(g, kc, n, t, cbase + chl, v, mk[u], xin[u]); }   // wave-uniform branch
-            else    { if (ok) g2_apply<P, EPI, false>(g, kc, n, t, cbase + chl, v, mk[u], xin[u]); }
+        for (int b0 = 0; b0 < RPW; b0 += RB) {
+            float mk2[RB]; float4 xin2[RB], v[RB]; int tt2[RB]; bool ok2[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                v[u] = *(const float4*)(stage + fr[b0 + u] * PITCH + chl);
+                mk2[u] = mk[b0 + u]; xin2[u] = xin[b0 + u]; tt2[u] = tt[b0 + u]; ok2[u] = ok[b0 + u];
+            }
+            g2_rows<P, EPI, LN, RB>(g, kc, n, tt2, ok2, cbase + chl, v, mk2, xin2);
         }
         if (p + 1 < NPASS) __syncthreads();
     }
