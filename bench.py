@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md chip-level table
 B_PER_GPU, T_FRAMES, N_STEPS, CFG = 32, 1000, 10, 3.0
+PROFILE_STRIDE = 4             # timed region: HIP events around every 4th launch of the dominant kernel class
 
 
 def algorithmic_flops_per_frame(T, n_evals, B):
@@ -178,7 +179,17 @@ def main():
     for _ in range(args.warmup):
         step()
     heavy = ["ffn_conv1", "ffn_conv2", "attention", "qkv_rope", "lsc_conv", "out_proj"]
+    # Survey pass (untimed): every heavy class timed with HIP events around every launch -> class breakdown and
+    # the dominant class.  An event pair costs ~10 us of idle stream time (rocprofv3 kernel trace: 3.5 ms per
+    # solve with all six classes instrumented), so the TIMED region below instruments the dominant class only
+    # and samples every 4th launch of it: the roofline's launch duration is still measured live inside the
+    # timed steps, on the launch stream, at <0.2 ms of overhead per solve.
     eng.profile_enable(True, heavy)
+    step()
+    torch.cuda.synchronize(dev)
+    survey = eng.profile_read()
+    dom = max(heavy, key=lambda k: survey[k]["total_ms"])
+    eng.profile_enable(True, [dom], stride=PROFILE_STRIDE)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -203,7 +214,6 @@ def main():
     frames_total = world * B_PER_GPU * T_FRAMES * args.steps
     value = frames_total / elapsed
     if rank == 0:
-        dom = max(heavy, key=lambda k: prof[k]["total_ms"])
         p = prof[dom]
         avg_s = p["total_ms"] / max(p["launches"], 1) * 1e-3
         achieved = p["flops_per_launch"] / avg_s / 1e12
@@ -222,10 +232,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"conv_gemm_kernel [{dom}]", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic(dom, args.dtype), "traffic_unit": "HBM bytes per launch (PMC)",
-                         "launches": p["launches"], "avg_launch_us": avg_s * 1e6,
+                         "launches_sampled": p["launches"], "sample_stride": PROFILE_STRIDE, "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": p["flops_per_launch"]},
             "whole_solve_tflops": falg * B_PER_GPU * T_FRAMES / (elapsed / args.steps) / 1e12 * world,
-            "kernel_classes_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]},
+            "kernel_classes_ms_per_step": {k: v["total_ms"] for k, v in survey.items() if v["launches"]},
+            "kernel_classes_note": "untimed survey solve with every launch of these classes bracketed by events",
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, (fs, fc))

@@ -121,6 +121,10 @@ int64_t st_debug_fetch(st_engine* e, const char* name, float* host_out, int64_t 
 int st_profile_enable(st_engine* e, int enable);
 /* Restrict event recording to the classes whose bit is set in class_mask (default: all). */
 int st_profile_select(st_engine* e, uint64_t class_mask);
+/* Record events around every stride-th launch of a selected class only (default 1 = every launch).  An event
+ * pair costs ~10 us of idle stream time on MI355X, so a timed run samples: st_profile_read then reports the
+ * SAMPLED launches and their total, i.e. total_ms / launches is still the mean launch duration. */
+int st_profile_stride(st_engine* e, int stride);
 int st_profile_num_classes(void);
 const char* st_profile_class_name(int cls);
 int st_profile_read(st_engine* e, int cls, int64_t* launches, double* total_ms, double* flops_per_launch);

@@ -22,7 +22,7 @@ SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_S
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
     "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
-    "st_profile_enable", "st_profile_select", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
+    "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes",
 ]
 
@@ -90,6 +90,8 @@ def load():
     lib.st_profile_enable.restype = c_int
     lib.st_profile_select.argtypes = [c_void_p, ctypes.c_uint64]
     lib.st_profile_select.restype = c_int
+    lib.st_profile_stride.argtypes = [c_void_p, c_int]
+    lib.st_profile_stride.restype = c_int
     lib.st_profile_num_classes.restype = c_int
     lib.st_profile_class_name.argtypes = [c_int]
     lib.st_profile_class_name.restype = ctypes.c_char_p
@@ -182,8 +184,9 @@ class Engine:
             raise NativeError(int(r), self.lib.st_last_error(self.handle).decode())
         return buf
 
-    def profile_enable(self, on, classes=None):
-        """classes: optional iterable of class names to restrict event recording to."""
+    def profile_enable(self, on, classes=None, stride=1):
+        """classes: optional iterable of class names to restrict event recording to; stride: record every
+        stride-th launch of a class only (event pairs cost ~10 us of stream time each)."""
         mask = (1 << 64) - 1
         if classes is not None:
             names = [self.lib.st_profile_class_name(i).decode() for i in range(self.lib.st_profile_num_classes())]
@@ -191,6 +194,7 @@ class Engine:
             for c in classes:
                 mask |= 1 << names.index(c)
         self._check(self.lib.st_profile_select(self.handle, mask))
+        self._check(self.lib.st_profile_stride(self.handle, int(stride)))
         self._check(self.lib.st_profile_enable(self.handle, int(on)))
 
     def profile_read(self):

@@ -77,6 +77,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return xor32_sum(__uint_as_float(a[0]) + __uint_as_float(a[1]));
 }
 
+// Write-through (agent-scope, sc1) global stores for the coalesced epilogues.  MI355X has one L2 per XCD and the
+// consumer of an activation tensor is always the NEXT kernel, running on all XCDs: with ordinary stores up to
+// 8 x 4 MB of dirty lines sit in the L2s until the end-of-kernel release writes them back -- measured as a
+// ~10 us idle gap after every large kernel (rocprofv3 kernel trace) -- whereas written through they reach HBM
+// while the kernel is still computing.  Only for full-line coalesced rows (partial-line scatter stores, e.g.
+// the attention output, keep the write-back path so the L2 can merge them).
+// The trailing s_nop covers the store-data hazard that hipcc cannot see behind inline asm (guide 5.7).
+#ifndef ST_STORE_WT
+#define ST_STORE_WT 1
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_row16(void* p, uint4 v) {
+#if ST_STORE_WT
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
+#else
+    *(uint4*)p = v;
+#endif
+}
+__device__ __forceinline__ void store_row16(void* p, float4 v) { store_row16(p, __builtin_bit_cast(uint4, v)); }
+__device__ __forceinline__ void store_row8(void* p, uint2 v) {
+#if ST_STORE_WT
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x2_t, v)) : "memory");
+#else
+    *(uint2*)p = v;
+#endif
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 

@@ -43,8 +43,10 @@ struct G2Cfg {
     static constexpr int A_BYTES = AROWS * 128, W_BYTES = BC * 128;
     static constexpr int PITCH = BC + 4;                       // fp32 words per staged frame row
     static constexpr int STAGE_BYTES = (NW == 8 ? TF : BF) * PITCH * 4;
+    static constexpr int STAGE16_BYTES = BF * (BC * 2 + 16);  // 16-bit [frame][channel] image of the whole tile (EPI_ACT16)
     static constexpr int LOOP_BYTES = 2 * A_BYTES + 2 * W_BYTES;
-    static constexpr int LDS_BYTES = LOOP_BYTES > STAGE_BYTES ? LOOP_BYTES : STAGE_BYTES;
+    static constexpr int LDS_MAX2 = LOOP_BYTES > STAGE_BYTES ? LOOP_BYTES : STAGE_BYTES;
+    static constexpr int LDS_BYTES = LDS_MAX2 > STAGE16_BYTES ? LDS_MAX2 : STAGE16_BYTES;
     static_assert((BC / 8) % NW == 0 && (BF / 8) % NW == 0, "DMA pieces must split evenly over the waves");
 };
 
@@ -87,22 +89,8 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
     size_t grow[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) grow[u] = (size_t)n * g.T + t[u];
-    if constexpr (EPI == EPI_ACT16) {
-#pragma unroll
-        for (int u = 0; u < R; ++u) { v[u].x += k.bias.x; v[u].y += k.bias.y; v[u].z += k.bias.z; v[u].w += k.bias.w; }
-        if (g.flags & GF_SILU) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) { v[u].x = silu_fast(v[u].x); v[u].y = silu_fast(v[u].y); v[u].z = silu_fast(v[u].z); v[u].w = silu_fast(v[u].w); }
-        }
-        if (g.flags & GF_MASK) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) { v[u].x *= m[u]; v[u].y *= m[u]; v[u].z *= m[u]; v[u].w *= m[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < R; ++u)
-            if (ok[u]) *(uint2*)((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2) = pack4<P>(v[u].x, v[u].y, v[u].z, v[u].w);
-        return;
-    } else {
+    static_assert(EPI != EPI_ACT16, "EPI_ACT16 has its own epilogue (g2_epilogue_act16)");
+    {
         if constexpr (EPI == EPI_F32) {
             const bool msk = g.flags & GF_MASK;
 #pragma unroll
@@ -121,7 +109,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
         if (g.out16) {
 #pragma unroll
             for (int u = 0; u < R; ++u)
-                if (ok[u]) *(uint2*)((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2) = pack4<P>(v[u].x, v[u].y, v[u].z, v[u].w);
+                if (ok[u]) store_row8((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2, pack4<P>(v[u].x, v[u].y, v[u].z, v[u].w));
         }
         if constexpr (LN) {
             if (g.ln_h16) {
@@ -136,7 +124,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
                 if (g.out32) {
 #pragma unroll
                     for (int u = 0; u < R; ++u)
-                        if (ok[u]) *(float4*)(g.out32 + grow[u] * g.cout + ch) = v[u];
+                        if (ok[u]) store_row16(g.out32 + grow[u] * g.cout + ch, v[u]);
                 }
                 float mean[R], rstd[R];
 #pragma unroll
@@ -153,7 +141,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
                     const float mm = mout ? m[u] : 1.0f;
                     const float h0 = (v[u].x * rs * (1.0f + k.sc.x) + k.sh.x) * mm, h1 = (v[u].y * rs * (1.0f + k.sc.y) + k.sh.y) * mm;
                     const float h2 = (v[u].z * rs * (1.0f + k.sc.z) + k.sh.z) * mm, h3 = (v[u].w * rs * (1.0f + k.sc.w) + k.sh.w) * mm;
-                    if (ok[u]) *(uint2*)((unsigned char*)g.ln_h16 + (grow[u] * 256 + ch) * 2) = pack4<P>(h0, h1, h2, h3);
+                    if (ok[u]) store_row8((unsigned char*)g.ln_h16 + (grow[u] * 256 + ch) * 2, pack4<P>(h0, h1, h2, h3));
                 }
                 return;
             }
@@ -161,7 +149,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
         if (g.out32) {
 #pragma unroll
             for (int u = 0; u < R; ++u)
-                if (ok[u]) *(float4*)(g.out32 + grow[u] * g.cout + ch) = v[u];
+                if (ok[u]) store_row16(g.out32 + grow[u] * g.cout + ch, v[u]);
         }
     }
 }
@@ -175,7 +163,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
     const int T = g.T;
-    static_assert(EPI != EPI_QKV, "the QKV epilogue lives in conv_gemm_impl.h");
+    static_assert(EPI != EPI_QKV && EPI != EPI_ACT16, "QKV: conv_gemm_impl.h; ACT16: g2_epilogue_act16");
     static_assert(BC == 128 || BC == 256, "row walker handles 128 or 256 channels");
     constexpr bool LN = (BC == 256);
     // frames staged per pass: the 4-wave 128x128 tile goes in ONE pass (fewer barriers, one exposed global-load
@@ -235,6 +223,70 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
             g2_rows<P, EPI, LN, RB>(g, kc, n, tt2, ok2, cbase + chl, v, mk2, xin2);
         }
         if (p + 1 < NPASS) __syncthreads();
+    }
+}
+
+// Accumulator start value: EPI_ACT16 kernels start from the bias (one add per output saved in the epilogue).
+template <int EPI, int FC, int FF>
+__device__ __forceinline__ void g2_init_acc(f32x16_t (&acc)[FC][FF], const ConvGemmArgs& g, int chw, int hi) {
+#pragma unroll
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == EPI_ACT16) { if (g.bias) bv = *(const float4*)(g.bias + chw + a * 32 + 8 * q4 + 4 * hi); }
+#pragma unroll
+            for (int b = 0; b < FF; ++b) {
+                acc[a][b][4 * q4 + 0] = bv.x; acc[a][b][4 * q4 + 1] = bv.y;
+                acc[a][b][4 * q4 + 2] = bv.z; acc[a][b][4 * q4 + 3] = bv.w;
+            }
+        }
+}
+
+// EPI_ACT16 epilogue (activation tensors that only feed the next GEMM: FFN conv_1, prenet convs).  SiLU and
+// the frame mask are applied IN the accumulator registers (lane = frame, so the mask is one value per fragment
+// column; every wave works at once, no barrier, no per-row control flow), the results are packed to 16 bit and
+// parked in LDS as [frame][channel] (row pitch BC*2+16 B), and after ONE barrier the block writes the tile as
+// whole rows: 16 B per lane, 64 lanes = 1 KiB of consecutive HBM bytes per store instruction.
+template <class P, int BC, int BF, int WC, int WF>
+__device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], unsigned char* stage,
+                                                  const ConvGemmArgs& g, int n, int t0, int fvalid, int cbase, int wave, int lane) {
+    constexpr int NW = WC * WF, TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32, PB = BC * 2 + 16;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int T = g.T;
+    const bool do_silu = g.flags & GF_SILU;
+    const float* mrow = ((g.flags & GF_MASK) && g.mask) ? g.mask + (size_t)(n % g.mask_mod) * T : nullptr;
+#pragma unroll
+    for (int b = 0; b < FF; ++b) {
+        const int fl = wf * TF + b * 32 + l31;
+        const int t = t0 + fl;
+        const float m = mrow ? mrow[t < T ? t : T - 1] : 1.0f;
+#pragma unroll
+        for (int a = 0; a < FC; ++a) {          // one 32x32 fragment at a time: its registers die at the ds_write
+            f32x16_t v = acc[a][b];
+            if (do_silu) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = silu_fast(v[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= m;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
+                *(uint2*)(stage + fl * PB + ch * 2) = pack4<P>(v[4 * q4 + 0], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int LPR = BC / 8, RPI = 64 / LPR;        // lanes per row, rows per wave instruction
+    const int rsub = lane / LPR, cl = lane % LPR;
+    unsigned char* obase = (unsigned char*)g.out16 + (((size_t)n * T + t0) * g.cout + cbase) * 2 + cl * 16;
+#pragma unroll
+    for (int i = 0; i < BF / (NW * RPI); ++i) {
+        const int f = (i * NW + wave) * RPI + rsub;
+        const uint4 v = *(const uint4*)(stage + f * PB + cl * 16);
+        if (t0 + f < T && f < fvalid) store_row16(obase + (size_t)f * g.cout * 2, v);
     }
 }
 
@@ -393,12 +445,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     };
 
     f32x16_t acc[FC][FF];
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-        for (int b = 0; b < FF; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    g2_init_acc<EPI, FC, FF>(acc, g, cbase + wc * TC, hi);
 
     int wrow_off[FC], wswz[FC];
 #pragma unroll
@@ -512,7 +559,8 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #if ST_STAGE_TIMING
     const unsigned long long tLoop = __builtin_amdgcn_s_memtime();
 #endif
-    g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BF, cbase, wave, lane);
+    if constexpr (EPI == EPI_ACT16) g2_epilogue_act16<P, BC, BF, WC, WF>(acc, smem, g, n, t0, BF, cbase, wave, lane);
+    else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BF, cbase, wave, lane);
 #if ST_STAGE_TIMING
     if (g.dbg && lane == 0 && (wave == 0 || wave == NW - 1) && lin < 64) {
         unsigned long long* d = g.dbg + (size_t)(lin * 2 + (wave ? 1 : 0)) * 8;
@@ -592,12 +640,7 @@ __global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvG
     };
 
     f32x16_t acc[FC][FF];
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-        for (int b = 0; b < FF; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    g2_init_acc<EPI, FC, FF>(acc, g, cbase + wc * TC, hi);
 
     int wrow_off[FC], wswz[FC];
 #pragma unroll
@@ -682,13 +725,15 @@ __global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvG
             __builtin_amdgcn_s_barrier();
         }
     }
-    g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
+    if constexpr (EPI == EPI_ACT16) g2_epilogue_act16<P, BC, BF, WC, WF>(acc, smem, g, n, t0, BFV, cbase, wave, lane);
+    else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
 }
 
 template <class P, int EPI, int BC = 128, int BF = 128, int WC = 2, int WF = 2>
 static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int lds_loop = 2 * BF * 128 + 3 * BC * 128, lds_stage = (WC * WF == 8 ? BF / WF : BF) * (BC + 4) * 4;
-    constexpr int lds = lds_loop > lds_stage ? lds_loop : lds_stage;
+    constexpr int lds2 = lds_loop > lds_stage ? lds_loop : lds_stage, lds16 = BF * (BC * 2 + 16);
+    constexpr int lds = lds2 > lds16 ? lds2 : lds16;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_gemm3_kernel<P, EPI, BC, BF, WC, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -210,6 +210,37 @@ hipError_t launch_fill_rows16(int dtype, const float* vec, int C, int Cp, int T,
 }
 
 // ------------------------------------------------------------------------------------------
+// Small per-solve setup helpers (no D2D memcpy calls, no host synchronisation on the solve path)
+struct SetValuesArgs { float v[64]; };
+__global__ void set_values_kernel(float* dst, int n, SetValuesArgs a) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = a.v[i];
+}
+// host values -> device array through kernel arguments (64 per launch): the evaluation times of a solve
+hipError_t launch_set_values(float* dst, const float* host_vals, int n, hipStream_t s) {
+    for (int o = 0; o < n; o += 64) {
+        SetValuesArgs a;
+        const int m = n - o < 64 ? n - o : 64;
+        for (int i = 0; i < 64; ++i) a.v[i] = i < m ? host_vals[o + i] : 0.f;
+        hipLaunchKernelGGL(set_values_kernel, dim3(1), dim3(64), 0, s, dst + o, m, a);
+    }
+    return hipGetLastError();
+}
+
+// speaker rows of a solve: rows [0, B) = c, rows [B, 2B) = the CFG null speaker repeated (flow_matching.py:60)
+__global__ void cvec_prep_kernel(const float* c, const float* fake, int B, int G, float* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = B * G;
+    if (i < n) dst[i] = c[i];
+    else if (fake && i < 2 * n) dst[i] = fake[(i - n) % G];
+}
+hipError_t launch_cvec_prep(const float* c, const float* fake_or_null, int B, int G, float* dst, hipStream_t s) {
+    const int total = (fake_or_null ? 2 : 1) * B * G;
+    hipLaunchKernelGGL(cvec_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, s, c, fake_or_null, B, G, dst);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // CFG combine (flow_matching.py:66) + optional fused Euler update (torchdiffeq euler step)
 template <class P>
 __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* v, int64_t half, int use_cfg, float s,

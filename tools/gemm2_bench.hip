@@ -4,6 +4,7 @@
 #include "../stabletts_amd/csrc/conv_gemm2_impl.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,7 +39,7 @@ static void run_shape(const char* name, int items, int T, int c0, int c1, int co
     a.cout = cout; a.T = T; a.n_items = items;
     a.tiles_f = (T + kBF - 1) / kBF; a.tiles_c = cout / kBC;
     a.mask = dev_f32(rows, 0.f, 1.0f); a.mask_mod = items;
-    a.flags = GF_SILU | GF_MASK;
+    a.flags = getenv("GB_FLAGS") ? atoi(getenv("GB_FLAGS")) : (GF_SILU | GF_MASK);
     const int Tp = (T + 63) / 64 * 64;
     const size_t out16_bytes = rows * cout * 2, out32_bytes = rows * cout * 4;
     CK(hipMalloc(&a.out16, out16_bytes)); CK(hipMalloc((void**)&a.out32, out32_bytes));
@@ -162,6 +163,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 3 ? atoi(argv[3]) : 10;
     printf("items %d, T %d\n", items, T);
     run_shape<3, EPI_ACT16>("ffn1", items, T, 256, 0, 1024, reps);
+    if (getenv("GB_ONLY_FFN1")) return 0;
     run_shape<3, EPI_RESGATE>("ffn2", items, T, 1024, 0, 256, reps);
     run_shape<3, EPI_F32>("lsc", items, T, 256, 256, 256, reps);
     run_shape<1, EPI_RESGATE>("oproj", items, T, 256, 0, 256, reps);
