@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstabletts_hip.so")
+LIB_PATH = os.environ.get("STABLETTS_HIP_LIB") or os.path.join(HERE, "libstabletts_hip.so")   # env: developer A/B builds
 
 ST_OK = 0
 ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_STATE, ST_ERR_UNSUPPORTED = -1, -2, -3, -4

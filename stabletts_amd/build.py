@@ -1,6 +1,9 @@
 """Builds libstabletts_hip.so (gfx950) in-tree with hipcc.  No GPU needed (cross-compile).
 
     python -m stabletts_amd.build [--force]
+
+Developer A/B builds: ST_BUILD_DEFS="-DST_STORE_WT=0" ST_BUILD_OUT=/path/variant.so python -m stabletts_amd.build
+writes a second library (own object directory) that STABLETTS_HIP_LIB=/path/variant.so makes _lib.py load.
 """
 import concurrent.futures as cf
 import hashlib
@@ -11,12 +14,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "build")
-LIB = os.path.join(HERE, "libstabletts_hip.so")
+LIB = os.environ.get("ST_BUILD_OUT") or os.path.join(HERE, "libstabletts_hip.so")
+OBJ = os.path.join(HERE, "csrc", "build") if not os.environ.get("ST_BUILD_OUT") else LIB + ".obj"
 SOURCES = ["engine.cpp", "conv_gemm_bf16.hip", "conv_gemm_f16.hip", "conv_gemm2_bf16.hip", "conv_gemm2_f16.hip",
            "attention.hip", "misc_kernels.hip", "adaptive_ode.hip"]
 HEADERS = ["common.h", "launch.h", "conv_gemm_impl.h", "conv_gemm2_impl.h", "conv_gemm2_inst.h", os.path.join("..", "..", "include", "stabletts_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS += os.environ.get("ST_BUILD_DEFS", "").split()
 
 
 def _hipcc():

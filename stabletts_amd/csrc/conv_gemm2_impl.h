@@ -226,7 +226,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
     }
 }
 
-// Accumulator start value: EPI_ACT16 kernels start from the bias (one add per output saved in the epilogue).
+// Accumulator start value: EPI_ACT16 / EPI_QKV kernels start from the bias (one add per output saved in the epilogue).
 template <int EPI, int FC, int FF>
 __device__ __forceinline__ void g2_init_acc(f32x16_t (&acc)[FC][FF], const ConvGemmArgs& g, int chw, int hi) {
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void g2_init_acc(f32x16_t (&acc)[FC][FF], const ConvG
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_ACT16) { if (g.bias) bv = *(const float4*)(g.bias + chw + a * 32 + 8 * q4 + 4 * hi); }
+            if constexpr (EPI == EPI_ACT16 || EPI == EPI_QKV) { if (g.bias) bv = *(const float4*)(g.bias + chw + a * 32 + 8 * q4 + 4 * hi); }
 #pragma unroll
             for (int b = 0; b < FF; ++b) {
                 acc[a][b][4 * q4 + 0] = bv.x; acc[a][b][4 * q4 + 1] = bv.y;
@@ -287,6 +287,99 @@ __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][
         const int f = (i * NW + wave) * RPI + rsub;
         const uint4 v = *(const uint4*)(stage + f * PB + cl * 16);
         if (t0 + f < T && f < fvalid) store_row16(obase + (size_t)f * g.cout * 2, v);
+    }
+}
+
+// EPI_QKV epilogue (fused q/k/v projection of diffusion_transformer.py:60-62, cout = 3 x 256, tile = 256 channels
+// = exactly the q, the k or the v plane of 256 frames).  Like EPI_ACT16 everything elementwise happens in the
+// accumulator registers and the tile goes through ONE 16-bit LDS image so that every global store is a full
+// coalesced row:
+//   q / k : partial RoPE (pairs d, d+16 for d < 16 are register groups q4, q4+2 of the head's first fragment:
+//           lane local; diffusion_transformer.py:180-198), q scaled by log2(e)/sqrt(64); image [head][frame][64]
+//           (pitch 144 B) -> q/k [item][H][T][64]: the 256 frames of a head are one contiguous 32 KB run.
+//   v     : image [channel][frame] with the PV-operand key order (bits 2<->3 of the frame index swapped inside
+//           every 16, attention.hip), frames >= T zeroed -> vT [item][H][64][Tp]: 512 B runs per (head, dim).
+constexpr int kQkvRowPitch = 144;
+template <int BC, int BF> constexpr int g2_qkv_lds_bytes() {
+    return (BC / 64) * BF * kQkvRowPitch > BC * (BF * 2 + 16) ? (BC / 64) * BF * kQkvRowPitch : BC * (BF * 2 + 16);
+}
+template <class P, int BC, int BF, int WC, int WF>
+__device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], unsigned char* stage,
+                                                const ConvGemmArgs& g, int n, int t0, int cbase, int wave, int lane) {
+    static_assert(BC == 256 && (BC / WC) % 64 == 0, "one q/k/v plane per block, whole heads per wave");
+    constexpr int NW = WC * WF, TC = BC / WC, TF = BF / WF, FF = TF / 32, HPW = TC / 64, PQ = kQkvRowPitch, PV = BF * 2 + 16;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int T = g.T, H = g.n_heads;
+    const int which = cbase / BC;                 // 0 q, 1 k, 2 v
+    if (which < 2) {
+        const float sc = which == 0 ? g.qscale : 1.0f;
+#pragma unroll
+        for (int b = 0; b < FF; ++b) {
+            const int fl = wf * TF + b * 32 + l31;
+            const int tl = t0 + fl < T ? t0 + fl : T - 1;
+            float cc[2][4], ss[2][4];
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const float4 cs = *(const float4*)(g.rope_cos + (size_t)tl * 16 + 8 * q4 + 4 * hi);
+                const float4 sn = *(const float4*)(g.rope_sin + (size_t)tl * 16 + 8 * q4 + 4 * hi);
+                cc[q4][0] = cs.x; cc[q4][1] = cs.y; cc[q4][2] = cs.z; cc[q4][3] = cs.w;
+                ss[q4][0] = sn.x; ss[q4][1] = sn.y; ss[q4][2] = sn.z; ss[q4][3] = sn.w;
+            }
+#pragma unroll
+            for (int hh = 0; hh < HPW; ++hh) {
+                f32x16_t r = acc[2 * hh][b];
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x1 = r[4 * q4 + e], x2 = r[4 * (q4 + 2) + e];
+                        r[4 * q4 + e] = x1 * cc[q4][e] - x2 * ss[q4][e];
+                        r[4 * (q4 + 2) + e] = x2 * cc[q4][e] + x1 * ss[q4][e];
+                    }
+                unsigned char* row = stage + ((wc * HPW + hh) * BF + fl) * PQ + 4 * hi * 2;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    *(uint2*)(row + 16 * q4) = pack4<P>(r[4 * q4 + 0] * sc, r[4 * q4 + 1] * sc, r[4 * q4 + 2] * sc, r[4 * q4 + 3] * sc);
+                    *(uint2*)(row + 64 + 16 * q4) = pack4<P>(acc[2 * hh + 1][b][4 * q4 + 0] * sc, acc[2 * hh + 1][b][4 * q4 + 1] * sc,
+                                                             acc[2 * hh + 1][b][4 * q4 + 2] * sc, acc[2 * hh + 1][b][4 * q4 + 3] * sc);
+                }
+            }
+        }
+        __syncthreads();
+        unsigned char* dst = (unsigned char*)(which == 0 ? g.q : g.k);
+        const int rsub = lane >> 3, seg = lane & 7;
+#pragma unroll
+        for (int i = 0; i < (BC / 64) * BF / (NW * 8); ++i) {
+            const int rowid = (i * NW + wave) * 8 + rsub;
+            const int head = rowid / BF, f = rowid % BF;
+            const uint4 v = *(const uint4*)(stage + rowid * PQ + seg * 16);
+            if (t0 + f < T) store_row16(dst + (((size_t)n * H + head) * T + t0 + f) * 128 + seg * 16, v);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < FF; ++b) {
+            const int fl = wf * TF + b * 32 + l31;
+            const bool tv = t0 + fl < T;
+            const int pos = (fl & ~12) | ((fl & 4) << 1) | ((fl & 8) >> 1);
+#pragma unroll
+            for (int a = 0; a < TC / 32; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = wc * TC + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    *(typename P::elem*)(stage + ch * PV + pos * 2) = to16<P>(tv ? acc[a][b][r] : 0.0f);
+                }
+        }
+        __syncthreads();
+        const int rsub = lane >> 5, seg = lane & 31;
+#pragma unroll
+        for (int i = 0; i < BC / (NW * 2); ++i) {
+            const int ch = (i * NW + wave) * 2 + rsub;
+            const uint4 v = *(const uint4*)(stage + ch * PV + seg * 16);
+            const int tcol = t0 + seg * 8;
+            if (tcol < g.Tp)
+                store_row16((unsigned char*)g.vt + ((((size_t)n * H + (ch >> 6)) * 64 + (ch & 63)) * g.Tp + tcol) * 2, v);
+        }
     }
 }
 
@@ -560,6 +653,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const unsigned long long tLoop = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (EPI == EPI_ACT16) g2_epilogue_act16<P, BC, BF, WC, WF>(acc, smem, g, n, t0, BF, cbase, wave, lane);
+    else if constexpr (EPI == EPI_QKV) g2_epilogue_qkv<P, BC, BF, WC, WF>(acc, smem, g, n, t0, cbase, wave, lane);
     else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BF, cbase, wave, lane);
 #if ST_STAGE_TIMING
     if (g.dbg && lane == 0 && (wave == 0 || wave == NW - 1) && lin < 64) {
@@ -753,10 +847,12 @@ static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
 template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF>
 static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
     using K = G2Cfg<BC, BF, WC, WF, TAPS>;
+    constexpr int qkv_lds = (EPI == EPI_QKV) ? g2_qkv_lds_bytes<BC, BF>() : 0;
+    constexpr int LDS = K::LDS_BYTES > qkv_lds ? K::LDS_BYTES : qkv_lds;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -766,7 +862,8 @@ static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
     b.tiles_c = a.cout / BC;
     const int total = b.n_items * b.tiles_f * b.tiles_c;
     const int grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL((conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>), dim3(grid), dim3(K::NT), K::LDS_BYTES, s, b);
+    if (EPI == EPI_QKV && (a.cout != 3 * BC || a.n_heads * 64 != BC || !a.q || !a.k || !a.vt)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>), dim3(grid), dim3(K::NT), LDS, s, b);
     return hipGetLastError();
 }
 

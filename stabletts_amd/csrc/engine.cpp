@@ -152,6 +152,12 @@ bool use_gen2() {
 
 hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
     const bool bf = e->dt == DT_BF16;
+    // fused QKV projection: 256x256 tiles with the LDS-transposed coalesced epilogue when the three planes are
+    // 256 channels each and T fills 256-frame tiles; otherwise the first-generation register epilogue
+    static const bool qkv_gen1 = [] { const char* v = getenv("ST_QKV_GEN"); return v && atoi(v) == 1; }();
+    if (use_gen2() && epi == EPI_QKV && !qkv_gen1 && a.cout == 768 && a.n_heads == 4 &&
+        ((a.T + 255) / 256) * 256 * 10 <= ((a.T + 127) / 128) * 128 * 11)
+        return bf ? launch_conv_gemm2_bf16(G2_BIG, taps, epi, a, s) : launch_conv_gemm2_f16(G2_BIG, taps, epi, a, s);
     if (use_gen2() && epi != EPI_QKV) {
         // 256x256 tiles (half the LDS traffic per MFMA of the 128x128 ones: the K loop is LDS-bound) whenever the
         // output is a multiple of 256 channels and T fills 256-frame tiles about as well as 128-frame ones; otherwise
