@@ -91,7 +91,7 @@ CLASS_KERNEL = {
     "ffn_conv2": "conv_gemm2_kernel<st::Op{DT}, 3, 2, 256, 256, 2, 4>",
     "lsc_conv": "conv_gemm2_kernel<st::Op{DT}, 3, 1, 256, 256, 2, 4>",
     "attention": "attention_kernel<st::Op{DT}>",
-    "qkv_rope": "conv_gemm_glds_kernel<st::Op{DT}, 1, 3, 0>",
+    "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 256, 2, 4>",
     "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4>",
 }
 

@@ -27,6 +27,10 @@
 #include "common.h"
 #include "launch.h"
 
+#ifndef ST_ATTN_NEGM
+#define ST_ATTN_NEGM 0
+#endif
+
 namespace st {
 
 template <class P>
@@ -100,7 +104,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#if ST_ATTN_NEGM
+    // The running maximum enters the score MFMA as its C operand (a 16-register vector holding -m for this
+    // lane's query), so S^T comes out already shifted and the per-score subtraction disappears from the
+    // softmax; the vector is rewritten only when some lane's maximum moves.
+    float m_run = 0.f, l_run = 0.f;
+    f32x16_t negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+#else
     float m_run = -1e30f, l_run = 0.f;
+#endif
 
     if (ntiles > 0) issueKV(0, 0);
     ST_DMA_WAIT(0);
@@ -114,8 +128,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
         f32x16_t s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+#if ST_ATTN_NEGM
+            s[kb] = negm;
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#endif
             const unsigned char* kp = Ks + buf * TILE_BYTES + row_off[kb];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -139,6 +157,27 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = xor32_max(mx);
+#if ST_ATTN_NEGM
+        // s holds score - m_run.  The first tile always contains a valid key (key 0), so its maximum is finite
+        // and becomes m_run whatever its sign; later tiles move m_run only upwards.
+        const bool mv = (kt == 0) || (mx > 0.f);
+        if (__any(mv)) {
+            const float delta = mv ? mx : 0.f;
+            const float alpha = (kt == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+        }
+#else
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -149,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
             m_run = m_new;
         }
+#endif
 
         vec8 pf[4];
         float psum = 0.f;
@@ -156,7 +196,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if ST_ATTN_NEGM
+                const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+#else
                 const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+#endif
                 psum += p;
                 pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p);
             }

@@ -308,3 +308,35 @@ def test_error_behaviour(decoders):
     from stabletts_amd._lib import NativeError
     with pytest.raises(NativeError):
         d(inp["mu"].cuda(), inp["mask"].cuda(), 0, 1.0, inp["c"].cuda(), "euler")
+
+
+def test_non_native_solver_runs_torchdiffeq_controller_over_native_estimator(decoders, cfg_params, monkeypatch):
+    """solver names without a native controller (webui.py:110: bosh3, fehlberg2, ...) hand the time stepping to
+    torchdiffeq while every vector-field evaluation stays native.  torchdiffeq is not installed here, so a
+    stand-in module whose ``odeint`` is the fixed-grid Euler rule checks the plumbing (call signature of
+    flow_matching.py:54, CFG wrapper, trajectory[-1]): the result must equal the fused native euler solve."""
+    import sys
+    import types
+    calls = {}
+
+    def odeint(fn, y0, t, method=None, rtol=None, atol=None):
+        calls.update(method=method, rtol=rtol, atol=atol, nfe=0)
+        ys, y = [y0], y0
+        for i in range(len(t) - 1):
+            y = y + (t[i + 1] - t[i]) * fn(t[i], y)
+            calls["nfe"] += 1
+            ys.append(y)
+        return torch.stack(ys)
+
+    fake = types.ModuleType("torchdiffeq")
+    fake.odeint = odeint
+    monkeypatch.setitem(sys.modules, "torchdiffeq", fake)
+    d = decoders["f16"]
+    fs, fc = cfg_params
+    kw = dict(fake_speaker=fs.cuda(), fake_content=fc.cuda(), cfg_strength=2.0)
+    inp = {k: v.cuda() for k, v in make_inputs(2, 60, seed=41, lengths=[60, 37]).items() if k != "lengths"}
+    for cfg in (None, kw):
+        ref = d(inp["mu"], inp["mask"], 4, 0.8, inp["c"], "euler", cfg, z=inp["z"])
+        out = d(inp["mu"], inp["mask"], 4, 0.8, inp["c"], "bosh3", cfg, z=inp["z"])
+        assert calls == dict(method="bosh3", rtol=1e-5, atol=1e-5, nfe=4)
+        assert _rel(out.cpu(), ref.cpu()) <= 2e-4
