@@ -10,10 +10,13 @@ CMD="python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o s -- $CMD > $OUT/sq.log 2>&1
 cd $ROOT
 KS=$(find $OUT/kt -name '*kernel_stats.csv' | head -1)
 FC=$(find $OUT/fetch -name '*counter_collection.csv' | head -1)
 WC=$(find $OUT/write -name '*counter_collection.csv' | head -1)
 python tools/rocprof_summary.py stats $KS > $OUT/kernel_stats.txt
 python tools/rocprof_summary.py pmc $FC $WC $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
-ls $OUT; head -12 $OUT/kernel_stats.txt; head -12 $OUT/pmc_traffic.txt
+SC=$(find $OUT/sq -name '*counter_collection.csv' | head -1)
+python tools/rocprof_summary.py mfma $SC $KS > $OUT/mfma_util.txt
+ls $OUT; head -14 $OUT/mfma_util.txt; head -12 $OUT/kernel_stats.txt; head -12 $OUT/pmc_traffic.txt

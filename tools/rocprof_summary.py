@@ -1,6 +1,7 @@
 """Summarise rocprofv3 outputs (ROCm 7.2) as text for profiles/:
    python tools/rocprof_summary.py stats  <kernel_stats.csv | results.db>
    python tools/rocprof_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv>
+   python tools/rocprof_summary.py mfma   <sq_counter_collection.csv> <kernel_stats.csv>
 PMC: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
 coalesced streams (MI355X_MICROARCH.md, HBM section) -> doubled below.  One counter per pass (TCC slot limits)."""
 import collections
@@ -44,9 +45,42 @@ def pmc(fetch_csv, write_csv):
     return out
 
 
+def mfma(pmc_csv, stats_csv):
+    """Matrix-pipe occupancy per kernel: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs of the chip;
+    32 per v_mfma_f32_32x32x16) / (GRBM_GUI_ACTIVE x 1024 SIMDs).  GRBM_GUI_ACTIVE is reported per XCD and summed by
+    rocprofv3 over the 8 XCDs on this stack (detected from the implied clock: active / duration must be < 3 GHz)."""
+    dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(stats_csv))}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    for r in csv.DictReader(open(pmc_csv)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[r["Kernel_Name"]][r["Counter_Name"]] += 1
+    print("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (per launch, means)")
+    print(f"{'launches':>8} {'mfma_busy_Mcyc':>15} {'gui_active_kcyc':>16} {'clock_GHz':>10} {'mfma_util':>10} {'vs_2.4GHz_peak':>15}  kernel")
+    rows = []
+    for k, a in agg.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in a or "GRBM_GUI_ACTIVE" not in a or k not in dur:
+            continue
+        n = cnt[k]["GRBM_GUI_ACTIVE"]
+        busy = a["SQ_VALU_MFMA_BUSY_CYCLES"] / cnt[k]["SQ_VALU_MFMA_BUSY_CYCLES"]
+        act = a["GRBM_GUI_ACTIVE"] / n
+        clock = act / dur[k]                      # cycles per ns = GHz
+        if clock > 3.0:                           # summed over the 8 XCDs
+            act /= 8.0; clock /= 8.0
+        if busy <= 0:
+            continue
+        util = busy / (act * 1024.0)
+        peak = busy / (dur[k] * 2.4 * 1024.0)     # against the 2.4 GHz nominal clock the 2.5 PFLOP/s peak assumes
+        rows.append((busy, n, act, clock, util, peak, k))
+    for busy, n, act, clock, util, peak, k in sorted(rows, reverse=True):
+        print(f"{n:8d} {busy / 1e6:15.2f} {act / 1e3:16.1f} {clock:10.2f} {util:10.3f} {peak:15.3f}  {k[:110]}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3])
     else:
         res = pmc(sys.argv[2], sys.argv[3])
         if len(sys.argv) > 4:
