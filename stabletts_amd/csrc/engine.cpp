@@ -155,7 +155,11 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
     // fused QKV projection: 256x256 tiles with the LDS-transposed coalesced epilogue when the three planes are
     // 256 channels each and T fills 256-frame tiles; otherwise the first-generation register epilogue
     static const bool qkv_gen1 = [] { const char* v = getenv("ST_QKV_GEN"); return v && atoi(v) == 1; }();
-    if (use_gen2() && epi == EPI_QKV && !qkv_gen1 && a.cout == 768 && a.n_heads == 4 &&
+    // small grids (few utterances): 256x256 tiles would leave most CUs idle behind a few long-running blocks, so
+    // they are used only when they give at least ~3/4 of a block per CU; below that the 128-wide tiles run 2-4x
+    // as many, shorter blocks
+    const bool big_fills_chip = (int64_t)a.n_items * ((a.T + 255) / 256) * (a.cout / 256) >= 192;
+    if (use_gen2() && epi == EPI_QKV && !qkv_gen1 && a.cout == 768 && a.n_heads == 4 && big_fills_chip &&
         ((a.T + 255) / 256) * 256 * 10 <= ((a.T + 127) / 128) * 128 * 11)
         return bf ? launch_conv_gemm2_bf16(G2_BIG, taps, epi, a, s) : launch_conv_gemm2_f16(G2_BIG, taps, epi, a, s);
     if (use_gen2() && epi != EPI_QKV) {
@@ -167,7 +171,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         const int T = a.T;
         const bool fills = ((T + 255) / 256) * 256 * 10 <= ((T + 127) / 128) * 128 * 11;
         int cfg;
-        if (a.cout % 256 == 0 && fills) cfg = G2_BIG;
+        if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = G2_BIG;
         else if (a.ln_h16) cfg = G2_RC;
         else if (taps == 3 && a.c0 + a.c1 >= 512) cfg = G2_K3PIPE;
         else cfg = G2_T128;

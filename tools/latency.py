@@ -1,0 +1,31 @@
+"""Solve latency for small batches (developer tool): median wall time of CFMDecoder.forward per configuration."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle                                  # noqa: E402  (seeded weights / inputs only)
+from oracle.inputs import make_inputs          # noqa: E402
+from stabletts_amd.flow_matching import CFMDecoder   # noqa: E402
+
+dev = torch.device("cuda", 0)
+dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256)
+dec.estimator.load_state_dict(oracle.make_state_dict(1234))
+dec = dec.to(dev)
+fs, fc = oracle.make_cfg_params(4321)
+kw = dict(fake_speaker=fs.to(dev), fake_content=fc.to(dev), cfg_strength=3.0)
+for B, T, cfg in [(1, 500, None), (1, 500, kw), (4, 500, kw), (8, 1000, kw), (32, 1000, kw)]:
+    g = {k: v.to(dev) for k, v in make_inputs(B, T, seed=0).items() if k != "lengths"}
+    ts = []
+    for i in range(8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec(g["mu"], g["mask"], 10, 1.0, g["c"], "euler", cfg, z=g["z"])
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    print(f"B={B:3d} T={T:5d} cfg={'on ' if cfg else 'off'}: median {ts[len(ts) // 2] * 1e3:8.3f} ms  "
+          f"({B * T / ts[len(ts) // 2]:10.0f} frames/s)", flush=True)
