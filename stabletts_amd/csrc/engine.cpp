@@ -158,7 +158,9 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
     // small grids (few utterances): 256x256 tiles would leave most CUs idle behind a few long-running blocks, so
     // they are used only when they give at least ~3/4 of a block per CU; below that the 128-wide tiles run 2-4x
     // as many, shorter blocks
-    const bool big_fills_chip = (int64_t)a.n_items * ((a.T + 255) / 256) * (a.cout / 256) >= 192;
+    // (ST_BIG_MIN_BLOCKS overrides the threshold; read per call so that tests can force either tile family)
+    const char* mb = getenv("ST_BIG_MIN_BLOCKS");
+    const bool big_fills_chip = (int64_t)a.n_items * ((a.T + 255) / 256) * (a.cout / 256) >= (mb ? atoi(mb) : 192);
     if (use_gen2() && epi == EPI_QKV && !qkv_gen1 && a.cout == 768 && a.n_heads == 4 && big_fills_chip &&
         ((a.T + 255) / 256) * 256 * 10 <= ((a.T + 127) / 128) * 128 * 11)
         return bf ? launch_conv_gemm2_bf16(G2_BIG, taps, epi, a, s) : launch_conv_gemm2_f16(G2_BIG, taps, epi, a, s);

@@ -156,6 +156,20 @@ def test_c2_deterministic_and_batch_permutation_equivariant(decoders, cfg_params
     assert torch.equal(pout, out[perm])                               # utterances are independent units
 
 
+def test_c2_batch_rows_match_oracle(sd, cfg_params, c2):
+    """The production configuration itself (B=32 x T=1000, 256x256 tiles, 10 Euler steps, CFG 3.0): utterances are
+    independent units, so rows of the batched native solve are checked against the oracle run on those utterances
+    alone (the longest one and a ragged one)."""
+    inp, out = c2
+    lens = inp["mask"][:, 0].sum(-1)
+    rows = [int(lens.argmax()), int(lens.argmin())]
+    sub = {k: v[rows] for k, v in inp.items() if k != "lengths"}
+    ref = oracle.cfm_forward(sd, sub["mu"], sub["mask"], 10, sub["z"], sub["c"], "euler", _cfg(cfg_params, 3.0, False))
+    got = out[rows]
+    assert _rel(got, ref) <= MEL_TOL
+    assert float((got - ref).abs().max() / (ref - sub["z"]).abs().max()) <= DISP_TOL["bf16"]
+
+
 def test_c2_items_match_oracle_at_full_length(decoders, sd, cfg_params):
     """Two utterances at T=1000 (ragged) with CFG, 2 Euler steps, against the oracle."""
     inp = make_inputs(2, 1000, seed=7, lengths=[1000, 731])
