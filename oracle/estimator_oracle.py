@@ -140,6 +140,50 @@ def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None):
     return x
 
 
+def dit_conv_block(sd, p, x, c, mask, n_heads=4, k=3, taps=None):
+    """DiTConVBlock.forward (models/diffusion_transformer.py:98-117) with parameters under prefix ``p``
+    (the text encoder's blocks, models/text_encoder.py:25,40-41: no FiLM wrapper)."""
+    x = x * mask
+    hc = c
+    if (p + "adaLN_modulation.0.weight") in sd:
+        hc = F.linear(hc, sd[p + "adaLN_modulation.0.weight"], sd[p + "adaLN_modulation.0.bias"])
+    ada = F.linear(F.silu(hc), sd[p + "adaLN_modulation.2.weight"], sd[p + "adaLN_modulation.2.bias"])
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = ada.unsqueeze(2).chunk(6, dim=1)
+    if taps is not None:
+        taps["x1"] = x
+    h = layer_norm_c(x) * (1 + sc_a) + sh_a
+    if taps is not None:
+        taps["h1"] = h
+    x = x + g_a * mha(sd, p + "attn.", h, mask, n_heads, taps) * mask
+    if taps is not None:
+        taps["x2"] = x
+    h = layer_norm_c(x) * (1 + sc_m) + sh_m
+    x = x + g_m * ffn(sd, p + "mlp.", h, mask, k, taps)
+    if taps is not None:
+        taps["x3"] = x
+    return x
+
+
+def text_encoder_forward(sd, tokens, c, lengths, n_heads=4, k=3, taps=None):
+    """models/text_encoder.py:34-44 (TextEncoder.forward): tokens (B,T) long, c (B,gin), lengths (B,) ->
+    x (B,C,T), mu_x (B,out,T), x_mask (B,1,T).  sequence_mask = utils/mask.py (arange < length)."""
+    C = sd["emb.weight"].shape[1]
+    x = F.embedding(tokens, sd["emb.weight"]) * (C ** 0.5)
+    x = x.transpose(1, -1)
+    T = x.size(2)
+    mask = (torch.arange(T)[None, :] < lengths[:, None]).unsqueeze(1).to(x.dtype)
+    i = 0
+    while f"encoder.{i}.attn.conv_q.weight" in sd:
+        bt = {} if taps is not None else None
+        x = dit_conv_block(sd, f"encoder.{i}.", x, c, mask, n_heads, k, bt)
+        if taps is not None:
+            for kk, vv in bt.items():
+                taps[f"b{i}.{kk}"] = vv
+        i += 1
+    mu_x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"]) * mask
+    return x, mu_x, mask
+
+
 # ----------------------------------------------------------------------------- estimator
 def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None):
     """models/estimator.py:103-138 (Decoder.forward): one vector-field evaluation.

@@ -93,3 +93,41 @@ def make_cfg_params(seed: int = 4321, cfg: DecoderConfig = DecoderConfig(), std:
     fs = torch.from_numpy((rng.standard_normal((1, cfg.gin_channels)) * std).astype(np.float32))
     fc = torch.from_numpy((rng.standard_normal((1, cfg.cond_channels, 1)) * std).astype(np.float32))
     return fs, fc
+
+
+@dataclass(frozen=True)
+class TextEncoderConfig:
+    """Constructor arguments of reference TextEncoder (models/text_encoder.py:9) as StableTTS builds it
+    (models/model.py:36; config.py ModelConfig; text/symbols.py: 401 symbols)."""
+    n_vocab: int = 401
+    out_channels: int = 128
+    hidden_channels: int = 256
+    filter_channels: int = 1024
+    n_heads: int = 4
+    n_layers: int = 3
+    kernel_size: int = 3
+    p_dropout: float = 0.1
+    gin_channels: int = 256
+
+
+def make_text_encoder_state_dict(seed: int = 2468, cfg: TextEncoderConfig = TextEncoderConfig(), ada_std: float = 0.02):
+    """state_dict of reference ``TextEncoder`` (models/text_encoder.py:8-32) with seeded values: embedding
+    N(0, hidden^-0.5) (:23), block convs / linears as in make_state_dict, adaLN-Zero output layers re-randomised
+    N(0, ada_std) for the same reason (zero init, :30-32, would make every block the identity)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    C, F, G, K = cfg.hidden_channels, cfg.filter_channels, cfg.gin_channels, cfg.kernel_size
+    sd = {}
+    sd["emb.weight"] = torch.from_numpy((rng.standard_normal((cfg.n_vocab, C)) * C ** -0.5).astype(np.float32))
+    for i in range(cfg.n_layers):
+        p = f"encoder.{i}."
+        for nm in ("q", "k", "v"):
+            _conv(rng, sd, p + f"attn.conv_{nm}", C, C, 1, xavier=True)
+        _conv(rng, sd, p + "attn.conv_o", C, C, 1)
+        _conv(rng, sd, p + "mlp.conv_1", F, C, K)
+        _conv(rng, sd, p + "mlp.conv_2", C, F, K)
+        if G != C:
+            _linear(rng, sd, p + "adaLN_modulation.0", C, G)
+        sd[p + "adaLN_modulation.2.weight"] = torch.from_numpy((rng.standard_normal((6 * C, C)) * ada_std).astype(np.float32))
+        sd[p + "adaLN_modulation.2.bias"] = torch.from_numpy((rng.standard_normal((6 * C,)) * ada_std).astype(np.float32))
+    _conv(rng, sd, "proj", cfg.out_channels, C, 1)
+    return sd

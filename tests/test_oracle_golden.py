@@ -108,3 +108,23 @@ def test_fused_cfg_batch_equivalence(sd, cfg_params):
     o = oracle.decoder_forward(sd, t, x2, m2, mu2, c2)
     fused = o[2:] + 3.0 * (o[:2] - o[2:])
     assert float((fused - ref).abs().max()) <= 1e-6
+
+
+def test_text_encoder_oracle_matches_reference_fixture():
+    """oracle.text_encoder_forward vs the outputs of the real reference TextEncoder
+    (tests/golden/text_encoder_outputs.npz, written by oracle/make_golden_text_encoder.py)."""
+    import os
+    import numpy as np
+    import torch
+    import oracle
+    from oracle.make_golden_text_encoder import CASES, text_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "text_encoder_outputs.npz"))
+    sd = oracle.make_text_encoder_state_dict(2468)
+    for name, (B, T, lengths, seed) in CASES.items():
+        tok, c, lens = text_inputs(B, T, lengths, seed)
+        with torch.inference_mode():
+            x, mu_x, mask = oracle.text_encoder_forward(sd, tok, c, lens)
+        for got, key in ((x, "_x"), (mu_x, "_mu_x"), (mask, "_mask")):
+            want = g[name + key]
+            assert got.shape == want.shape
+            assert np.abs(got.numpy() - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0)
