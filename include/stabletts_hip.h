@@ -102,6 +102,23 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                  const float* fake_speaker, const float* fake_content,
                  float* out, int B, int T, void* stream);
 
+/* ---- TextEncoder: the caller side of the path, on the same DiT block kernels ---------------- */
+
+/* Replaces TextEncoder.__init__ (models/text_encoder.py:9-28).  cfg fields are read as: noise_channels =
+ * out_channels (n_mels), hidden / filter / n_heads / kernel_size / gin_channels / operand_dtype as for the
+ * decoder, n_layers = n_enc_layers (any 1..16).  Parameters are loaded with st_load_param under the reference
+ * names ("emb.weight", "encoder.<i>.attn.conv_q.weight", ..., "proj.bias") and packed by st_finalize; the handle
+ * is destroyed with st_destroy.  The decoder entry points reject such a handle and vice versa. */
+int st_create_text_encoder(const st_config* cfg, int n_vocab, int device, st_engine** out);
+
+/* Replaces TextEncoder.forward(x, c, x_lengths) (models/text_encoder.py:34-44).
+ *   tokens  : (B, T) int64 phoneme ids (ids outside [0, n_vocab) are clamped; nn.Embedding would raise)
+ *   lengths : (B,) int64 valid lengths;  c: (B, gin) fp32 speaker vectors          -- all device pointers
+ *   x_out   : (B, hidden, T) fp32 encoder states;  mu_out: (B, n_mels, T) fp32 = proj(x) * mask;
+ *   mask_out: (B, 1, T) fp32 sequence mask (utils/mask.py). */
+int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* lengths, const float* c,
+                            float* x_out, float* mu_out, float* mask_out, int B, int T, void* stream);
+
 /* Function evaluations, attempted steps and rejected steps of the last st_cfm_solve (adaptive solvers vary). */
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects);
 

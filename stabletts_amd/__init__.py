@@ -5,17 +5,23 @@ Public surface mirrors the reference's ``models/flow_matching.py``:
     from stabletts_amd.flow_matching import CFMDecoder
 
 ``install()`` registers that module as ``models.flow_matching`` so the reference's
-``models/model.py:7`` (``from models.flow_matching import CFMDecoder``) picks it up unmodified.
+``models/model.py:7`` (``from models.flow_matching import CFMDecoder``) picks it up unmodified;
+``install(text_encoder=True)`` also registers ``stabletts_amd.text_encoder`` as ``models.text_encoder``
+(``models/model.py:6``), the caller side of the path on the same block kernels.
 """
 import sys
 
-__all__ = ["install", "CFMDecoder"]
+__all__ = ["install", "CFMDecoder", "TextEncoder"]
 
 
-def install():
-    """Make ``models.flow_matching`` resolve to the native drop-in (call before importing models.model)."""
+def install(text_encoder=False):
+    """Make ``models.flow_matching`` (and optionally ``models.text_encoder``) resolve to the native drop-ins
+    (call before importing models.model)."""
     from . import flow_matching
     sys.modules["models.flow_matching"] = flow_matching
+    if text_encoder:
+        from . import text_encoder as te
+        sys.modules["models.text_encoder"] = te
     return flow_matching
 
 
@@ -23,4 +29,7 @@ def __getattr__(name):
     if name == "CFMDecoder":
         from .flow_matching import CFMDecoder
         return CFMDecoder
+    if name == "TextEncoder":
+        from .text_encoder import TextEncoder
+        return TextEncoder
     raise AttributeError(name)

@@ -22,6 +22,7 @@ SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_S
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
     "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
+    "st_create_text_encoder", "st_text_encoder_forward",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes",
 ]
@@ -90,6 +91,10 @@ def load():
     lib.st_profile_enable.restype = c_int
     lib.st_profile_select.argtypes = [c_void_p, ctypes.c_uint64]
     lib.st_profile_select.restype = c_int
+    lib.st_create_text_encoder.argtypes = [ctypes.POINTER(StConfig), c_int, c_int, ctypes.POINTER(c_void_p)]
+    lib.st_create_text_encoder.restype = c_int
+    lib.st_text_encoder_forward.argtypes = [c_void_p] + [c_void_p] * 6 + [c_int, c_int, c_void_p]
+    lib.st_text_encoder_forward.restype = c_int
     lib.st_profile_stride.argtypes = [c_void_p, c_int]
     lib.st_profile_stride.restype = c_int
     lib.st_profile_num_classes.restype = c_int
@@ -110,7 +115,9 @@ class Engine:
     """Thin owner of one ``st_engine`` handle."""
 
     def __init__(self, noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
-                 gin_channels, operand_dtype="bf16", device=0):
+                 gin_channels, operand_dtype="bf16", device=0, text_encoder_vocab=None):
+        """text_encoder_vocab: None -> CFM decoder estimator (st_create); n_vocab -> TextEncoder handle
+        (st_create_text_encoder; noise_channels is then the encoder's out_channels)."""
         self.lib = load()
         if operand_dtype not in OPERAND_DTYPES:
             raise ValueError(f"operand_dtype must be one of {sorted(OPERAND_DTYPES)}")
@@ -118,7 +125,10 @@ class Engine:
         cfg = StConfig(noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
                        gin_channels, OPERAND_DTYPES[operand_dtype])
         h = ctypes.c_void_p()
-        rc = self.lib.st_create(ctypes.byref(cfg), int(device), ctypes.byref(h))
+        if text_encoder_vocab is None:
+            rc = self.lib.st_create(ctypes.byref(cfg), int(device), ctypes.byref(h))
+        else:
+            rc = self.lib.st_create_text_encoder(ctypes.byref(cfg), int(text_encoder_vocab), int(device), ctypes.byref(h))
         if rc != ST_OK:
             raise NativeError(rc, self.lib.st_last_error(None).decode())
         self.handle = h
@@ -163,6 +173,12 @@ class Engine:
                                           fake_speaker.data_ptr() if fake_speaker is not None else None,
                                           fake_content.data_ptr() if fake_content is not None else None,
                                           out.data_ptr(), B, T, ctypes.c_void_p(stream)))
+
+    def text_encoder_forward(self, tokens, lengths, c, x_out, mu_out, mask_out, stream):
+        B, T = tokens.shape
+        self._check(self.lib.st_text_encoder_forward(self.handle, tokens.data_ptr(), lengths.data_ptr(), c.data_ptr(),
+                                                     x_out.data_ptr(), mu_out.data_ptr(), mask_out.data_ptr(), B, T,
+                                                     ctypes.c_void_p(stream)))
 
     def last_solve_stats(self):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()

@@ -53,6 +53,12 @@ struct st_engine {
     int device = 0;
     int dt = DT_BF16;
     int M = 0, Mp = 0, C = 0, F = 0, H = 0, L = 0, K = 0, G = 0;
+    int kind = 0;                       // 0: CFM decoder estimator, 1: TextEncoder (same DiT block kernels)
+    int n_vocab = 0;
+    // parameter-name prefix of DiT block i: estimator.py:13,79 "blocks.i.block." / text_encoder.py:25 "encoder.i."
+    std::string blk(int i) const {
+        return kind == 0 ? "blocks." + std::to_string(i) + ".block." : "encoder." + std::to_string(i) + ".";
+    }
     std::map<std::string, Param> params;
     bool finalized = false;
     std::string err;
@@ -112,6 +118,22 @@ void expect(st_engine* e, const std::string& name, std::vector<int64_t> shape) {
 
 void build_param_table(st_engine* e) {
     const int C = e->C, F = e->F, M = e->M, K = e->K, G = e->G;
+    if (e->kind == 1) {     // TextEncoder state_dict (models/text_encoder.py:22-26)
+        expect(e, "emb.weight", {e->n_vocab, C});
+        for (int i = 0; i < e->L; ++i) {
+            const std::string p = e->blk(i);
+            for (const char* nm : {"q", "k", "v", "o"}) {
+                expect(e, p + "attn.conv_" + nm + ".weight", {C, C, 1});
+                expect(e, p + "attn.conv_" + nm + ".bias", {C});
+            }
+            expect(e, p + "mlp.conv_1.weight", {F, C, K}); expect(e, p + "mlp.conv_1.bias", {F});
+            expect(e, p + "mlp.conv_2.weight", {C, F, K}); expect(e, p + "mlp.conv_2.bias", {C});
+            if (G != C) { expect(e, p + "adaLN_modulation.0.weight", {C, G}); expect(e, p + "adaLN_modulation.0.bias", {C}); }
+            expect(e, p + "adaLN_modulation.2.weight", {6 * C, C}); expect(e, p + "adaLN_modulation.2.bias", {6 * C});
+        }
+        expect(e, "proj.weight", {M, C, 1}); expect(e, "proj.bias", {M});
+        return;
+    }
     expect(e, "time_mlp.layer.0.weight", {F, C}); expect(e, "time_mlp.layer.0.bias", {F});
     expect(e, "time_mlp.layer.2.weight", {C, F}); expect(e, "time_mlp.layer.2.bias", {C});
     expect(e, "in_proj.weight", {C, C + M, 1}); expect(e, "in_proj.bias", {C});
@@ -369,7 +391,7 @@ int run_adaln(st_engine* e, const Plan& p, hipStream_t s) {
     const int C = e->C;
     ProfScope ps(e, s, PC_PREP, 0);
     for (int i = 0; i < e->L; ++i) {
-        const std::string pre = "blocks." + std::to_string(i) + ".block.adaLN_modulation.";
+        const std::string pre = e->blk(i) + "adaLN_modulation.";
         const float* in = p.cvec; int k = e->G;
         if (e->G != C) {
             HIPCHK(e, launch_linear(p.cvec, p.N, e->G, P(e, pre + "0.weight"), P(e, pre + "0.bias"), C, p.ada_tmp, 0, 0, s));
@@ -535,6 +557,88 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
 }
 
 // ---------------------------------------------------------------------------------------------
+// TextEncoder body (models/text_encoder.py:40-42): L DiTConVBlocks WITHOUT the FiLM wrapper on the residual
+// stream p.X (already masked by the embedding kernel), then proj.  Same kernels and the same fused-LayerNorm
+// epilogues as run_estimator: out-proj carries LN2, FFN conv_2 carries the next block's LN1.
+int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t s) {
+    const int C = e->C, F = e->F, L = e->L, N = p.N, T = p.T;
+    const int64_t rowsC = (int64_t)N * T * C;
+    const bool cap = e->capture;
+    const bool fuse = use_gen2();
+    auto ada_of = [&](int i) { return p.ada + (size_t)i * N * 6 * C; };
+    auto ln_launch = [&](int i, int shift_off, int scale_off, int mask_out, int cls) -> int {
+        FilmLnArgs a; memset(&a, 0, sizeof(a));
+        a.X = p.X; a.h16 = p.h16; a.film = nullptr; a.film_mod = 1;
+        a.ada = ada_of(i); a.ada_stride = 6 * C; a.shift_off = shift_off; a.scale_off = scale_off;
+        a.mask = mask; a.mask_mod = p.B; a.mask_out = mask_out; a.T = T; a.rows = N * T;
+        ProfScope ps(e, s, cls, 0);
+        HIPCHK(e, launch_film_ln(e->dt, a, s));
+        return ST_OK;
+    };
+    int rc;
+    for (int i = 0; i < L; ++i) {
+        const std::string bn = "b" + std::to_string(i) + ".";
+        const float* ada_i = ada_of(i);
+        if ((i == 0 || !fuse) && (rc = ln_launch(i, 0, C, 0, PC_FILM_LN1))) return rc;     // LN1 + modulate
+        if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
+        {
+            ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
+            a.a0 = p.h16; a.c0 = C;
+            a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+            a.Tp = p.Tp; a.n_heads = e->H;
+            a.qscale = 1.4426950408889634f / sqrtf((float)(C / e->H));
+            ProfScope ps(e, s, PC_QKV, conv_flops(p, e->qkv[i], N));
+            HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
+        }
+        {
+            AttnArgs a; memset(&a, 0, sizeof(a));
+            a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.kbias = p.kbias; a.mask_mod = p.B; a.zeros = e->zeros;
+            a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
+            ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
+            HIPCHK(e, launch_attention(e->dt, a, s));
+        }
+        if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
+        {
+            ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
+            a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
+            if (fuse) {
+                a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
+                a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
+            }
+            ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
+            HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
+        }
+        if (cap) capture(e, bn + "x2", p.X, rowsC, false, s);
+        if (!fuse && (rc = ln_launch(i, 3 * C, 4 * C, 1, PC_LN2))) return rc;              // LN2 + modulate, masked
+        {
+            ConvGemmArgs a = base_args(e, p, e->ffn1[i], N);
+            a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
+            ProfScope ps(e, s, PC_FFN1, conv_flops(p, e->ffn1[i], N));
+            HIPCHK(e, gemm(e, 3, EPI_ACT16, a, s));
+        }
+        {
+            ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
+            a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
+            a.out16 = p.cur16;
+            if (fuse && i + 1 < L) {      // LN1 + modulate of block i+1 (no FiLM, not masked)
+                a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
+                a.ln_ada = ada_of(i + 1); a.ln_ada_stride = 6 * C; a.ln_shift_off = 0; a.ln_scale_off = C; a.ln_mask_out = 0;
+            }
+            ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
+            HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
+        }
+        if (cap) capture(e, bn + "x3", p.X, rowsC, false, s);
+    }
+    {   // mu_x = proj(x) * x_mask (text_encoder.py:42)
+        ConvGemmArgs a = base_args(e, p, e->fin, N);
+        a.a0 = p.cur16; a.c0 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
+        ProfScope ps(e, s, PC_FINAL, conv_flops(p, e->fin, N));
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    return ST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adaptive Dormand-Prince 5(4): torchdiffeq's `dopri5`, the reference's default solver
 // (models/flow_matching.py:54 with solver=None; rtol = atol = 1e-5 hard-coded there).  Restated from the
 // published algorithm (rk_common.py / dopri5.py / misc.py of torchdiffeq 0.2.x): RMS error norm over the
@@ -675,12 +779,14 @@ extern "C" {
 
 int st_abi_version(void) { return ST_ABI_VERSION; }
 
-int st_create(const st_config* cfg, int device, st_engine** out) {
+static int create_engine(const st_config* cfg, int kind, int n_vocab, int device, st_engine** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return ST_ERR_INVALID; }
     auto bad = [&](const char* m) { g_create_error = m; return ST_ERR_INVALID; };
     // the reference's own assertions
-    if (cfg->n_layers % 2 != 0 || cfg->n_layers < 2 || cfg->n_layers > 16)
+    if (kind == 0 && (cfg->n_layers % 2 != 0 || cfg->n_layers < 2 || cfg->n_layers > 16))
         return bad("n_layers must be even (estimator.py:92) and in [2, 16]");
+    if (kind == 1 && (cfg->n_layers < 1 || cfg->n_layers > 16)) return bad("n_layers must be in [1, 16]");
+    if (kind == 1 && n_vocab < 1) return bad("n_vocab must be >= 1");
     if (cfg->hidden_channels % 2 != 0) return bad("SinusoidalPosEmb requires dim to be even (estimator.py:39)");
     if (cfg->n_heads < 1 || cfg->hidden_channels % cfg->n_heads != 0)
         return bad("channels % n_heads != 0 (diffusion_transformer.py:35)");
@@ -704,6 +810,7 @@ int st_create(const st_config* cfg, int device, st_engine** out) {
     e->M = cfg->noise_channels; e->Mp = (e->M + 127) / 128 * 128;
     e->C = cfg->hidden_channels; e->F = cfg->filter_channels; e->H = cfg->n_heads; e->L = cfg->n_layers;
     e->K = cfg->kernel_size; e->G = cfg->gin_channels;
+    e->kind = kind; e->n_vocab = n_vocab;
     build_param_table(e);
     if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
         g_create_error = "hipMalloc failed";
@@ -712,6 +819,12 @@ int st_create(const st_config* cfg, int device, st_engine** out) {
     }
     *out = e;
     return ST_OK;
+}
+
+int st_create(const st_config* cfg, int device, st_engine** out) { return create_engine(cfg, 0, 0, device, out); }
+
+int st_create_text_encoder(const st_config* cfg, int n_vocab, int device, st_engine** out) {
+    return create_engine(cfg, 1, n_vocab, device, out);
 }
 
 void st_destroy(st_engine* e) {
@@ -775,6 +888,9 @@ int st_finalize(st_engine* e) {
         return ST_OK;
     };
     int rc;
+    if (e->kind == 1) {
+        if ((rc = pack(e->fin, "proj.weight", P(e, "proj.bias"), M, Mp, C, 1, 0, C, C))) return rc;
+    } else {
     e->pre.assign(3, Conv());
     if ((rc = pack(e->pre[0], "cond_proj.0.weight", P(e, "cond_proj.0.bias"), F, F, M, K, 0, M, Mp))) return rc;
     if ((rc = pack(e->pre[1], "cond_proj.2.weight", P(e, "cond_proj.2.bias"), F, F, F, K, 0, F, F))) return rc;
@@ -788,9 +904,10 @@ int st_finalize(st_engine* e) {
         const std::string n = "lsc_layers." + std::to_string(i);
         if ((rc = pack(e->lsc[i], n + ".weight", P(e, n + ".bias"), C, C, 2 * C, K, 0, 2 * C, 2 * C))) return rc;
     }
+    }
     e->qkv.assign(L, Conv()); e->oproj.assign(L, Conv()); e->ffn1.assign(L, Conv()); e->ffn2.assign(L, Conv());
     for (int i = 0; i < L; ++i) {
-        const std::string b = "blocks." + std::to_string(i) + ".block.";
+        const std::string b = e->blk(i);
         Conv& q = e->qkv[i];
         q.cout = 3 * C; q.cin = C; q.taps = 1;
         if ((rc = dev_alloc(e, &q.w, (size_t)3 * C * C * 2))) return rc;
@@ -814,6 +931,7 @@ int st_finalize(st_engine* e) {
 int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x, const float* mu,
                          const float* mask, const float* c, float* out, int B, int T, void* stream) {
     int rc = check_ready(e, B, T); if (rc) return rc;
+    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
     if (!t || !x || !mu || !mask || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (t_len != 1 && t_len != B) return e->fail(ST_ERR_INVALID, "t must have 1 or B elements");
     HIPCHK(e, hipSetDevice(e->device));
@@ -845,6 +963,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                  const float* fake_speaker, const float* fake_content,
                  float* out, int B, int T, void* stream) {
     int rc = check_ready(e, B, T); if (rc) return rc;
+    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
     if (!mu || !mask || !z || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (n_steps < 1 || n_steps > 4096) return e->fail(ST_ERR_INVALID, "n_steps out of range");
     if (solver != ST_SOLVER_EULER && solver != ST_SOLVER_MIDPOINT && solver != ST_SOLVER_RK4 && solver != ST_SOLVER_DOPRI5)
@@ -934,6 +1053,34 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     {
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, launch_from_time_major(adaptive ? p.ynew : p.xstate, B, e->M, T, e->Mp, out, s));
+    }
+    return ST_OK;
+}
+
+int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* lengths, const float* c,
+                            float* x_out, float* mu_out, float* mask_out, int B, int T, void* stream) {
+    int rc = check_ready(e, B, T); if (rc) return rc;
+    if (e->kind != 1) return e->fail(ST_ERR_STATE, "this handle is not a text encoder (st_create_text_encoder)");
+    if (!tokens || !lengths || !c || !x_out || !mu_out || !mask_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    Plan p;
+    if ((rc = make_plan(e, B, T, false, 1, &p))) return rc;
+    if ((rc = ensure_rope(e, T, s))) return rc;
+    {
+        ProfScope ps(e, s, PC_PREP, 0);
+        // embedding * sqrt(C) * mask -> residual stream; the (B,1,T) mask is written straight into the caller's tensor
+        HIPCHK(e, launch_embed_tokens((const long long*)tokens, (const long long*)lengths, P(e, "emb.weight"), e->n_vocab,
+                                      e->C, sqrtf((float)e->C), B, T, p.X, mask_out, s));
+        HIPCHK(e, launch_mask_prep(mask_out, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
+        HIPCHK(e, launch_cvec_prep(c, nullptr, B, e->G, p.cvec, s));
+    }
+    if ((rc = run_adaln(e, p, s))) return rc;
+    if ((rc = run_text_blocks(e, p, mask_out, s))) return rc;
+    {
+        ProfScope ps(e, s, PC_PREP, 0);
+        HIPCHK(e, launch_from_time_major(p.X, B, e->C, T, e->C, x_out, s));
+        HIPCHK(e, launch_from_time_major(p.v32, B, e->M, T, e->Mp, mu_out, s));
     }
     return ST_OK;
 }

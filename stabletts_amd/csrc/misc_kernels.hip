@@ -241,6 +241,36 @@ hipError_t launch_cvec_prep(const float* c, const float* fake_or_null, int B, in
 }
 
 // ------------------------------------------------------------------------------------------
+// TextEncoder front end (models/text_encoder.py:35-37): x = emb[token] * sqrt(C), time-major fp32, and the
+// sequence mask (utils/mask.py: t < length) in both the (B,1,T) boundary layout and as the engine's mask row.
+// The block's first statement x = x * x_mask (diffusion_transformer.py:106) is applied here.
+// One wave per (item, position) row; out-of-range token ids are clamped to [0, n_vocab).
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* tokens, const long long* lengths,
+                                                           const float* emb, int n_vocab, int C, float scale, int B,
+                                                           int T, float* X, float* mask_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * T) return;
+    const int b = row / T, t = row % T;
+    const float m = (long long)t < lengths[b] ? 1.0f : 0.0f;
+    long long tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= n_vocab ? n_vocab - 1 : tok);
+    const float s = scale * m;
+    for (int ch = lane * 4; ch < C; ch += 256) {
+        const float4 v = *(const float4*)(emb + (size_t)tok * C + ch);
+        *(float4*)(X + (size_t)row * C + ch) = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+    }
+    if (lane == 0) mask_out[row] = m;
+}
+hipError_t launch_embed_tokens(const long long* tokens, const long long* lengths, const float* emb, int n_vocab,
+                               int C, float scale, int B, int T, float* X, float* mask_out, hipStream_t s) {
+    const int rows = B * T;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, tokens, lengths, emb, n_vocab, C,
+                       scale, B, T, X, mask_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // CFG combine (flow_matching.py:66) + optional fused Euler update (torchdiffeq euler step)
 template <class P>
 __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* v, int64_t half, int use_cfg, float s,
