@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md chip-level table
+HBM_PEAK_GBPS = 8000.0         # HBM3E, same table
 B_PER_GPU, T_FRAMES, N_STEPS, CFG = 32, 1000, 10, 3.0
 PROFILE_STRIDE = 4             # timed region: HIP events around every 4th launch of the dominant kernel class
 
@@ -96,6 +97,14 @@ CLASS_KERNEL = {
 }
 
 
+def pmc_solve_bytes():
+    """HBM bytes per solve over ALL kernels (same PMC passes; profiles/r01_pmc_traffic.json "_summary")."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["_summary"]["hbm_bytes_per_solve"]
+    except Exception:
+        return None
+
+
 def pmc_traffic(cls, dtype):
     """HBM bytes per launch of the class's kernel, from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command,
@@ -107,7 +116,7 @@ def pmc_traffic(cls, dtype):
         return None
     want = CLASS_KERNEL.get(cls, "").replace("{DT}", "BF16" if dtype == "bf16" else "F16")
     for name, v in table.items():
-        if want and want in name:
+        if want and want in name and "fetch_bytes_per_launch" in v:
             return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
     return None
 
@@ -235,6 +244,9 @@ def main():
                          "launches_sampled": p["launches"], "sample_stride": PROFILE_STRIDE, "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": p["flops_per_launch"]},
             "whole_solve_tflops": falg * B_PER_GPU * T_FRAMES / (elapsed / args.steps) / 1e12 * world,
+            "whole_solve_hbm": (lambda b: None if b is None else {
+                "bytes_per_solve_pmc": b, "achieved": b / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS})(pmc_solve_bytes()),
             "kernel_classes_ms_per_step": {k: v["total_ms"] for k, v in survey.items() if v["launches"]},
             "kernel_classes_note": "untimed survey solve with every launch of these classes bracketed by events",
         }

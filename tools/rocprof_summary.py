@@ -42,6 +42,11 @@ def pmc(fetch_csv, write_csv):
         w = a["write_kib"] / a["wl"] * 1024 / 1e6
         out[k] = {"fetch_bytes_per_launch": f * 1e6, "write_bytes_per_launch": w * 1e6, "launches": a["launches"]}
         print(f"{a['launches']:8d} {f:24.1f} {w:10.1f} {f + w:10.1f}  {k[:120]}")
+    # whole-solve HBM traffic: every kernel of the run, divided by the number of solves (one from_time_major per solve)
+    solves = max([v["launches"] for k, v in out.items() if "from_time_major" in k] or [1])
+    total = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in out.values())
+    out["_summary"] = {"solves": solves, "hbm_bytes_per_solve": total / solves}
+    print(f"# {solves} solves in the run, {total / solves / 1e9:.2f} GB of HBM traffic per solve (all kernels)")
     return out
 
 
