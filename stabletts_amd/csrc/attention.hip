@@ -8,7 +8,7 @@
 //   kbias: [mask row][Tp]     fp32 additive key bias in log2 units: 0 for valid keys, -1e30 for masked
 //                             or out-of-range keys (built once per solve from the (B,1,T) mask)
 //
-// One block = 4 waves = 128 queries of one (item, head); each wave owns 32 queries.  K / V^T tiles of
+// One block = ST_ATTN_WAVES (8) waves = 256 queries of one (item, head); each wave owns 32 queries.  K / V^T tiles of
 // 64 keys go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per tile;
 // the LDS image is dense 128-byte rows with the source-side XOR swizzle of conv_gemm_impl.h, so every
 // ds_read_b128 fragment read is bank-conflict free.
@@ -30,6 +30,9 @@
 #ifndef ST_ATTN_NEGM
 #define ST_ATTN_NEGM 0
 #endif
+#ifndef ST_ATTN_WAVES
+#define ST_ATTN_WAVES 8      // waves (x 32 queries) per block sharing one K/V tile stream: 4, 8 or 16
+#endif
 #ifndef ST_ATTN_EPI_LDS
 #define ST_ATTN_EPI_LDS 1
 #endif
@@ -49,15 +52,17 @@
 namespace st {
 
 template <class P>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) void attention_kernel(const AttnArgs a) {
+    constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW;      // waves and queries per block
     using vec8 = typename P::vec8;
     constexpr int TILE_BYTES = 64 * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+    constexpr int SMEM = 4 * TILE_BYTES > NW * 32 * 144 ? 4 * TILE_BYTES : NW * 32 * 144;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     unsigned char* Ks = smem;                    // 2 buffers
     unsigned char* Vs = smem + 2 * TILE_BYTES;   // 2 buffers
 
     const int T = a.T, Tp = a.Tp, H = a.H;
-    const int qtiles = (T + 127) >> 7;
+    const int qtiles = (T + QB - 1) / QB;
     const int total = a.n_items * H * qtiles;
     const int per_xcd = gridDim.x >> 3;
     const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int query = qt * 128 + wave * 32 + l31;
+    const int query = qt * QB + wave * 32 + l31;
 
     const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
     const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
@@ -90,19 +95,27 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     }
 
     const int ntiles = (kvend + 63) >> 6;
-    // LDS-DMA: wave w moves pieces 2w, 2w+1 (8 rows x 128 B each) of the K tile and of the V^T tile
+    // LDS-DMA: the 8 + 8 pieces (8 rows x 128 B each) of the K tile and of the V^T tile are split over the waves
     auto issueKV = [&](int kt, int buf) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int piece = wave * 2 + k;
+        auto k_piece = [&](int piece) {
             const int row = piece * 8 + (lane >> 3);
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const int key = kt * 64 + row;
             const unsigned char* ksrc = key < T ? kbase + (size_t)key * 128 + seg * 16 : zeros;
             glds16b(ksrc, Ks + buf * TILE_BYTES + piece * 1024);
+        };
+        auto v_piece = [&](int piece) {
             // V^T row = head dim `row`; 8 consecutive (permuted) keys kt*64 + seg*8 .. +8, always inside Tp
+            const int row = piece * 8 + (lane >> 3);
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
             const unsigned char* vsrc = vbase + ((size_t)row * Tp + kt * 64 + seg * 8) * 2;
             glds16b(vsrc, Vs + buf * TILE_BYTES + piece * 1024);
+        };
+        if constexpr (NW <= 8) {
+#pragma unroll
+            for (int k = 0; k < 8 / NW; ++k) { k_piece(wave * (8 / NW) + k); v_piece(wave * (8 / NW) + k); }
+        } else {        // 16 waves: waves 0..7 move the K pieces, waves 8..15 the V^T pieces
+            if (wave < 8) k_piece(wave); else v_piece(wave - 8);
         }
     };
 
@@ -306,12 +319,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
             *(uint2*)(mine + l31 * 144 + (d * 32 + 8 * q4 + 4 * hi) * 2) =
                 pack4<P>(o[d][4 * q4 + 0] * inv, o[d][4 * q4 + 1] * inv, o[d][4 * q4 + 2] * inv, o[d][4 * q4 + 3] * inv);
     const int rsub = lane >> 3, seg = lane & 7;
-    unsigned char* obase = (unsigned char*)a.out + (((size_t)n * T + qt * 128 + wave * 32) * (H * 64) + h * 64) * 2 + seg * 16;
+    unsigned char* obase = (unsigned char*)a.out + (((size_t)n * T + qt * QB + wave * 32) * (H * 64) + h * 64) * 2 + seg * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + rsub;
         const uint4 v = *(const uint4*)(mine + row * 144 + seg * 16);
-        if (qt * 128 + wave * 32 + row < T) *(uint4*)(obase + (size_t)row * (H * 64) * 2) = v;
+        if (qt * QB + wave * 32 + row < T) *(uint4*)(obase + (size_t)row * (H * 64) * 2) = v;
     }
 #else
     if (query < T) {
@@ -330,11 +343,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
 
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (!a.zeros || !a.kbias) return hipErrorInvalidValue;
-    const int qtiles = (a.T + 127) / 128;
+    const int qtiles = (a.T + 32 * ST_ATTN_WAVES - 1) / (32 * ST_ATTN_WAVES);
     const int total = a.n_items * a.H * qtiles;
     const int grid = ((total + 7) / 8) * 8;
-    if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, a);
-    else                  hipLaunchKernelGGL((attention_kernel<OpF16>), dim3(grid), dim3(256), 0, s, a);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+    else                  hipLaunchKernelGGL((attention_kernel<OpF16>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
     return hipGetLastError();
 }
 
