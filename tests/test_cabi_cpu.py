@@ -94,3 +94,30 @@ def test_install_registers_dropin_module():
         sys.modules.pop("models.flow_matching", None)
         if saved is not None:
             sys.modules["models.flow_matching"] = saved
+
+
+def test_text_encoder_shim_mirrors_reference_interface():
+    """models/text_encoder.py:9,34: constructor, forward(x, c, x_lengths), checkpoint key layout, adaLN-Zero init,
+    and no CPU fallback."""
+    import inspect
+    import sys
+    import oracle
+    import stabletts_amd
+    from stabletts_amd.text_encoder import TextEncoder
+    enc = TextEncoder(401, 128, 256, 1024, 4, 3, 3, 0.1, 256)
+    sd = enc.state_dict()
+    ref = oracle.make_text_encoder_state_dict(2468)
+    assert set(sd) == set(ref) and all(sd[k].shape == ref[k].shape for k in ref)
+    assert list(inspect.signature(enc.forward).parameters) == ["x", "c", "x_lengths"]
+    assert float(sd["encoder.0.adaLN_modulation.2.weight"].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc(torch.zeros(1, 5, dtype=torch.long), torch.zeros(1, 256), torch.tensor([5]))
+    saved = {k: sys.modules.pop(k, None) for k in ("models.flow_matching", "models.text_encoder")}
+    try:
+        stabletts_amd.install(text_encoder=True)
+        assert sys.modules["models.text_encoder"].TextEncoder is TextEncoder
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
