@@ -122,13 +122,18 @@ def pmc_traffic(cls, dtype):
 
 
 def main():
+    global N_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-timesteps", type=int, default=N_STEPS,
+                    help="Euler steps per solve: 10 = BASELINE config 2 (default, the headline metric); 50 = config 3, "
+                         "the long-ODE stress case")
     args = ap.parse_args()
+    N_STEPS = args.n_timesteps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,12 +234,12 @@ def main():
         n_evals = 2 * N_STEPS
         falg = algorithmic_flops_per_frame(T_FRAMES, n_evals, B_PER_GPU)
         line = {
-            "metric": "mel-frames/sec (whole node), 31M DiT, n_timesteps=10+CFG",
+            "metric": f"mel-frames/sec (whole node), 31M DiT, n_timesteps={N_STEPS}+CFG",
             "value": value, "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 31M CFM decoder (hidden 256, filter 1024, 4 heads, 6 DiT blocks, "
-                                   "n_mels 128), batch 32 x T=1000 synthetic mu/mask per GPU, n_timesteps=10 euler, "
+            "config": {"workload": f"BASELINE config {2 if N_STEPS == 10 else 3}: 31M CFM decoder (hidden 256, filter 1024, 4 heads, 6 DiT blocks, "
+                                   f"n_mels 128), batch 32 x T=1000 synthetic mu/mask per GPU, n_timesteps={N_STEPS} euler, "
                                    "cfg=3.0, seeded random weights (adaLN re-randomised)",
                        "global_batch": world * B_PER_GPU, "seq_len": T_FRAMES,
                        "parallelism": f"utterance-sharded x{world}, no data-path collective"},
