@@ -1,17 +1,23 @@
 // Implicit-GEMM Conv1d (k = 1 or 3) for gfx950, second generation: LDS-DMA staged K loop (as
-// conv_gemm_impl.h) + an LDS-staged, fully coalesced epilogue that can carry the NEXT LayerNorm.
+// conv_gemm_impl.h) + LDS-staged, fully coalesced epilogues that can carry the NEXT LayerNorm.
 //
 // Tile shapes (template): BC output channels x BF frames, WC x WF waves, wave tile (BC/WC) x (BF/WF)
 // built from 32x32x16 MFMA fragments.  Shipping configurations:
-//     T128 : 128 ch x 128 fr, 4 waves (2x2) of 64x64      -- 2 blocks/CU
-//     RC   : 256 ch x 128 fr, 8 waves (4x2) of 64x64      -- "row complete": a block owns all 256
-//            hidden channels of its frames, so the epilogue can apply FiLM + LayerNorm + adaLN modulate
-//            (the prologue of the next op in the reference: estimator.py:16, diffusion_transformer.py:111-112)
-//            and write the 16-bit MFMA operand of the next GEMM directly.
-// Epilogue: each wave parks its accumulator tile in LDS as [frame][channel] fp32 (conflict-free 16-B
-// stores, row pitch BC+4), then the block walks the tile one FRAME PER WAVE with lane = 4 channels: bias /
-// SiLU / mask / gate / residual / RoPE / FiLM / LayerNorm all run on contiguous 1 KB rows, and every
-// global access is a full-row coalesced 16-B (fp32) or 8-B (16-bit) per-lane transfer.
+//     BIG  : 256 ch x 256 fr, 8 waves (2x4) of 128x64     -- 1 block/CU, least LDS / DMA bytes per MFMA; used
+//            whenever Cout % 256 == 0 and the launch has >= ~3/4 block per CU
+//     T128 : 128 ch x 128 fr, 4 waves (2x2) of 64x64      -- 2 blocks/CU (small grids, Cout = 128)
+//     RC   : 256 ch x 128 fr, 8 waves (4x2) of 64x64      -- "row complete" for LayerNorm-carrying epilogues
+//            on small grids
+//     (+ conv_gemm3_kernel: 128 x 126, three weight buffers, counted vmcnt, deep k=3 convs on small grids)
+// A block that owns all 256 hidden channels of its frames can apply FiLM + LayerNorm + adaLN modulate -- the
+// prologue of the next op in the reference (estimator.py:16, diffusion_transformer.py:111-112) -- in its
+// epilogue and write the 16-bit MFMA operand of the next GEMM directly.
+// Epilogues (one per EPI, all ending in full-row coalesced stores):
+//     EPI_F32 / EPI_RESGATE : accumulators parked in LDS as [frame][channel] fp32 (conflict-free 16-B stores, row
+//            pitch BC+4), rows finished one frame per wave with lane = 4 channels, in batches of 4 rows, phase by
+//            phase (g2_rows): bias / mask / gate / residual / FiLM / LayerNorm on contiguous 1 KB rows
+//     EPI_ACT16 : SiLU + mask in the accumulator registers, one 16-bit LDS image, 1-KiB row stores (g2_epilogue_act16)
+//     EPI_QKV   : RoPE + q scaling in registers, one 16-bit LDS image per q / k / v plane (g2_epilogue_qkv)
 #pragma once
 #include "common.h"
 #include "launch.h"

@@ -426,11 +426,9 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
     const int C = e->C, F = e->F, L = e->L, N = p.N, T = p.T;
     const int64_t rowsC = (int64_t)N * T * C;
     const bool cap = e->capture;
-    // measured on MI355X (profiles/): fused FiLM+LN epilogues on row-complete tiles are a wash against the faster
-    // 128x128 tiles + separate LayerNorm launches (38.2 vs 38.0 ms/solve), so fusion is opt-in: ST_FUSE_LN=1
-    // ST_FUSE_LN (default 2; with the 256x256 row-complete tiles: 34.9 / 34.3 / 34.0 ms per solve for 0 / 1 / 2):
-    // 0 = every FiLM/LayerNorm is its own launch, 1 = fused into the long-skip convs and
-    // FFN conv_2 -> next block's LN1), 2 = fused everywhere (also in_proj and out_proj)
+    // ST_FUSE_LN (default 2; measured with the 256x256 row-complete tiles: 34.9 / 34.3 / 34.0 ms per solve for
+    // 0 / 1 / 2): 0 = every FiLM/LayerNorm is its own launch, 1 = fused into the long-skip convs and FFN conv_2
+    // (-> next block's LN1), 2 = fused everywhere (also in_proj and out_proj)
     static const int fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v ? atoi(v) : 2; }();
     const bool fuse = use_gen2() && fuse_env >= 1;        // lsc + ffn2
     const bool fuse_all = use_gen2() && fuse_env >= 2;    // + in_proj, out_proj
