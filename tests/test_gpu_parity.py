@@ -322,6 +322,13 @@ def test_error_behaviour(decoders):
     from stabletts_amd._lib import NativeError
     with pytest.raises(NativeError):
         d(inp["mu"].cuda(), inp["mask"].cuda(), 0, 1.0, inp["c"].cuda(), "euler")
+    # maximum size: 2*B*T*filter must stay below 2^31 (32-bit row indexing); rejected before anything is allocated
+    eng = d.estimator.engine()
+    fake = torch.zeros(1, device="cuda")
+    with pytest.raises(NativeError, match="too large"):
+        eng.lib.st_cfm_solve.restype  # noqa: B018  (binding exists)
+        eng._check(eng.lib.st_cfm_solve(eng.handle, fake.data_ptr(), fake.data_ptr(), fake.data_ptr(), fake.data_ptr(),
+                                        2, 0, 0, 0.0, None, None, fake.data_ptr(), 1024, 2048, None))
 
 
 def test_non_native_solver_runs_torchdiffeq_controller_over_native_estimator(decoders, cfg_params, monkeypatch):

@@ -117,3 +117,33 @@ def test_every_stage_of_one_evaluation(sd, monkeypatch, dt, case):
         assert pad.numel() == 0 or float(pad.abs().max()) == 0.0       # estimator.py:138: output * mask
     finally:
         eng.debug_capture(False)
+
+
+# ---------------------------------------------------------------- shape sweep: tile / halo / tail boundaries
+SWEEP_T = [1, 2, 31, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 383, 511, 512, 513, 767]
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_one_evaluation_across_tile_boundaries(sd, monkeypatch, big):
+    """One estimator evaluation (f16 operands, tight gate) for every T around the 64-key attention tiles, the
+    128/256-frame GEMM tiles and the k=3 halo, ragged lengths [T, T//2 or 1], against the oracle.  big=True forces
+    the 256x256-tile kernels wherever they are legal (ST_BIG_MIN_BLOCKS=0), big=False the 128-wide family
+    (ST_BIG_MIN_BLOCKS huge)."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    monkeypatch.setenv("ST_BIG_MIN_BLOCKS", "0" if big else "1000000000")
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+    dec.estimator.load_state_dict(sd)
+    dec = dec.cuda()
+    t = torch.tensor(0.61)
+    worst = 0.0
+    for T in SWEEP_T:
+        inp = make_inputs(2, T, seed=100 + T, lengths=[T, max(1, T // 2)])
+        with torch.inference_mode():
+            ref = oracle.decoder_forward(sd, t, inp["z"], inp["mask"], inp["mu"], inp["c"])
+        out = dec.estimator(t, inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+        assert torch.isfinite(out).all(), f"T={T}"
+        r = _rel(out.numpy(), ref.numpy())
+        worst = max(worst, r)
+        assert r <= 2e-3, f"T={T}: rel {r:.3e}"
+        pad = out[~inp["mask"].bool().expand_as(out)]
+        assert pad.numel() == 0 or float(pad.abs().max()) == 0.0, f"T={T}: padded frames must be exactly zero"
