@@ -40,7 +40,9 @@ enum { ST_OPERAND_BF16 = 0, ST_OPERAND_F16 = 1 };
 
 /* Fixed-grid solvers of torchdiffeq.odeint as used at models/flow_matching.py:54. */
 enum { ST_SOLVER_EULER = 0, ST_SOLVER_MIDPOINT = 1, ST_SOLVER_RK4 = 2,
-       ST_SOLVER_DOPRI5 = 3   /* adaptive Dormand-Prince 5(4), rtol = atol = 1e-5: the reference default (solver=None) */ };
+       ST_SOLVER_DOPRI5 = 3,  /* adaptive Dormand-Prince 5(4), rtol = atol = 1e-5: the reference default (solver=None) */
+       /* the other explicit adaptive pairs of torchdiffeq offered by webui.py:110, same controller and tolerances */
+       ST_SOLVER_BOSH3 = 4, ST_SOLVER_FEHLBERG2 = 5, ST_SOLVER_ADAPTIVE_HEUN = 6 };
 
 /* Constructor arguments of reference CFMDecoder.__init__ (models/flow_matching.py:12). */
 typedef struct st_config {
@@ -91,7 +93,7 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
  * torchdiffeq.odeint fixed-grid stepping (:54): the whole ODE solve.
  *   z            : initial noise (B, n_feats, T), ALREADY multiplied by the temperature (:45).
  *   n_steps      : n_timesteps; the grid is linspace(0, 1, n_steps + 1) (:46).
- *   solver       : ST_SOLVER_*.  For ST_SOLVER_DOPRI5 n_steps only names the output grid of the reference
+ *   solver       : ST_SOLVER_*.  For the adaptive solvers (>= ST_SOLVER_DOPRI5) n_steps only names the output grid of the reference
  *                  call (flow_matching.py:46,54) and does not influence the steps taken.
  *   use_cfg != 0 : classifier-free guidance with fake_speaker (gin,), fake_content (n_feats,)
  *                  and cfg_strength (models/model.py:43-44,102); cond and uncond branches run as

@@ -286,51 +286,74 @@ def _rms(x):
     return float(x.abs().pow(2).mean().sqrt())
 
 
-def odeint_dopri5(f, y0, t_end=1.0, rtol=1e-5, atol=1e-5, stats=None):
-    """torchdiffeq's adaptive dopri5 as called at models/flow_matching.py:54 (method=None or 'dopri5',
-    rtol=atol=1e-5), integrating from 0 to t_end and returning the state at t_end.  Intermediate output times
-    only add interpolation, never change the steps, so they are not modelled.  Steps are NOT clipped to t_end:
-    the last step may overshoot and the result is the 4th-order dense-output interpolant at t_end.
-    Time is carried in float64 on the host; f receives it as an fp32 0-dim tensor."""
+# torchdiffeq's explicit adaptive Runge-Kutta solvers (rk_common.py + dopri5.py / bosh3.py / fehlberg2.py /
+# adaptive_heun.py of torchdiffeq 0.2.x), restated from the published tableaus: (alpha, beta, c_sol, c_error,
+# c_mid, order).  PARITY UNPINNED against torchdiffeq itself (absent offline).
+ADAPTIVE_TABLEAUS = {
+    "dopri5": (_DP_ALPHA, _DP_BETA, _DP_C_SOL, _DP_C_ERR, _DP_C_MID, 5),
+    "bosh3": ([1 / 2, 3 / 4, 1.0],
+              [[1 / 2], [0.0, 3 / 4], [2 / 9, 1 / 3, 4 / 9]],
+              [2 / 9, 1 / 3, 4 / 9, 0.0],
+              [2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8],
+              [0.0, 0.5, 0.0, 0.0], 3),
+    "fehlberg2": ([1 / 2, 1.0],
+                  [[1 / 2], [1 / 256, 255 / 256]],
+                  [1 / 512, 255 / 256, 1 / 512],
+                  [-1 / 512, 0.0, 1 / 512],
+                  [0.0, 0.5, 0.0], 2),
+    "adaptive_heun": ([1.0], [[1.0]], [0.5, 0.5], [0.5, -0.5], [0.5, 0.0], 2),
+}
+
+
+def odeint_adaptive(f, y0, method="dopri5", t_end=1.0, rtol=1e-5, atol=1e-5, stats=None):
+    """torchdiffeq's RKAdaptiveStepsizeODESolver as called at models/flow_matching.py:54 (rtol=atol=1e-5),
+    integrating from 0 to t_end and returning the state at t_end.  Intermediate output times only add
+    interpolation, never change the steps, so they are not modelled.  Steps are NOT clipped to t_end: the last
+    step may overshoot and the result is the 4th-order dense-output interpolant at t_end (_interp_fit with
+    f0 = k[0], f1 = k[-1]).  As in torchdiffeq, the derivative carried into the next step is k[-1] whether or not
+    the tableau is FSAL.  Time is carried in float64 on the host; f receives it as an fp32 0-dim tensor."""
+    alphas, betas, c_sol, c_err, c_mid, order = ADAPTIVE_TABLEAUS[method]
+    fsal = c_sol[-1] == 0.0 and list(c_sol[:-1]) == list(betas[-1])
     tt = lambda t: torch.tensor(t, dtype=torch.float32)
     t0 = 0.0
     f0 = f(tt(t0), y0)
     nfe = 1
-    # _select_initial_step (order 4)
+    # _select_initial_step(order - 1)
     scale = atol + y0.abs() * rtol
     d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
     h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
     f1 = f(tt(t0 + h0), y0 + h0 * f0)
     nfe += 1
     d2 = _rms((f1 - f0) / scale) / h0
-    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / order)
     dt = min(100 * h0, h1)
     y, fcur, t = y0, f0, t0
     steps = rejects = 0
     while True:
         t1 = t + dt
         k = [fcur]
-        for alpha, beta in zip(_DP_ALPHA, _DP_BETA):
+        for alpha, beta in zip(alphas, betas):
             ti = t1 if alpha == 1.0 else t + alpha * dt
             yi = y + sum((b * dt) * kj for b, kj in zip(beta, k) if b != 0.0)
             k.append(f(tt(ti), yi))
             nfe += 1
-        y1 = yi                                      # c_sol[:-1] == beta[-1] (FSAL): the last stage IS y1
-        err = sum((c * dt) * kj for c, kj in zip(_DP_C_ERR, k) if c != 0.0)
+        # c_sol[:-1] == beta[-1] and c_sol[-1] == 0 (FSAL, e.g. Dormand-Prince): the last stage input IS y1
+        y1 = yi if fsal else y + sum((c * dt) * kj for c, kj in zip(c_sol, k) if c != 0.0)
+        err = sum((c * dt) * kj for c, kj in zip(c_err, k) if c != 0.0)
         tol = atol + rtol * torch.max(y.abs(), y1.abs())
         ratio = _rms(err / tol)
         accept = ratio <= 1.0
-        # _optimal_step_size(safety 0.9, ifactor 10, dfactor 0.2, order 5)
+        # _optimal_step_size(safety 0.9, ifactor 10, dfactor 0.2, order)
         if ratio == 0.0:
             dt_next = dt * 10.0
         else:
             dfactor = 1.0 if ratio < 1.0 else 0.2
-            dt_next = dt * min(10.0, max(0.9 / ratio ** 0.2, dfactor))
+            dt_next = dt * min(10.0, max(0.9 / ratio ** (1.0 / order), dfactor))
         steps += 1
         if accept:
             if t1 >= t_end:
                 # dense output (_interp_fit / _interp_evaluate) at t_end inside [t, t1]
-                y_mid = y + sum((c * dt) * kj for c, kj in zip(_DP_C_MID, k) if c != 0.0)
+                y_mid = y + sum((c * dt) * kj for c, kj in zip(c_mid, k) if c != 0.0)
                 fa, fb = k[0], k[-1]
                 a = 2 * dt * (fb - fa) - 8 * (y1 + y) + 16 * y_mid
                 b = dt * (5 * fa - 3 * fb) + 18 * y + 14 * y1 - 32 * y_mid
@@ -345,6 +368,13 @@ def odeint_dopri5(f, y0, t_end=1.0, rtol=1e-5, atol=1e-5, stats=None):
         else:
             rejects += 1
         dt = dt_next
+        if not dt > 0.0 or dt < 1e-12:
+            raise RuntimeError(f"{method}: step size underflow")
+
+
+def odeint_dopri5(f, y0, t_end=1.0, rtol=1e-5, atol=1e-5, stats=None):
+    """torchdiffeq's dopri5 (the reference default, models/flow_matching.py:54 with solver=None)."""
+    return odeint_adaptive(f, y0, "dopri5", t_end, rtol, atol, stats)
 
 
 @torch.inference_mode()
@@ -359,6 +389,8 @@ def cfm_forward(sd, mu, mask, n_timesteps, z, c, solver="euler", cfg_kwargs=None
                                      cfg_kwargs["fake_content"], cfg_kwargs["cfg_strength"], **kw)
     if solver in (None, "dopri5"):
         return odeint_dopri5(f, z, float(t_span[-1]))
+    if solver in ADAPTIVE_TABLEAUS:
+        return odeint_adaptive(f, z, solver, float(t_span[-1]))
     return odeint_fixed(f, z, t_span, solver)
 
 

@@ -637,27 +637,57 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Adaptive Dormand-Prince 5(4): torchdiffeq's `dopri5`, the reference's default solver
-// (models/flow_matching.py:54 with solver=None; rtol = atol = 1e-5 hard-coded there).  Restated from the
-// published algorithm (rk_common.py / dopri5.py / misc.py of torchdiffeq 0.2.x): RMS error norm over the
-// whole state tensor, FSAL, controller safety 0.9 / ifactor 10 / dfactor 0.2, initial step from
-// _select_initial_step, steps NOT clipped to t = 1 and the result taken from the 4th-order dense output.
+// torchdiffeq's explicit ADAPTIVE Runge-Kutta solvers: `dopri5` -- the reference's default
+// (models/flow_matching.py:54 with solver=None; rtol = atol = 1e-5 hard-coded there) -- and the other embedded
+// pairs the reference's web UI offers (webui.py:110: bosh3, fehlberg2, adaptive_heun).  Restated from the
+// published algorithm (rk_common.py / dopri5.py / bosh3.py / fehlberg2.py / adaptive_heun.py / misc.py of
+// torchdiffeq 0.2.x): RMS error norm over the whole state tensor, controller safety 0.9 / ifactor 10 / dfactor
+// 0.2 with exponent 1/order, initial step from _select_initial_step(order - 1), steps NOT clipped to t = 1 and the
+// result taken from the 4th-order dense output (_interp_fit with f0 = k[0], f1 = k[-1]); like torchdiffeq the
+// derivative carried into the next step is k[-1] whether or not the tableau is FSAL.
 // The state, stage derivatives and norms live on the device; time and the controller run on the host
 // (float64), with one 8-byte read-back per step (torchdiffeq synchronises the same way).
-int solve_dopri5(st_engine* e, const Plan& p, const float* mask, int use_cfg, float cfg_strength, hipStream_t s) {
-    static const double ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
-    static const double BETA[6][6] = {
-        {1.0 / 5},
-        {3.0 / 40, 9.0 / 40},
-        {44.0 / 45, -56.0 / 15, 32.0 / 9},
-        {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
-        {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
-        {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
-    static const double CERR[7] = {35.0 / 384 - 1951.0 / 21600, 0.0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
-                                   -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
-    static const double CMID[7] = {6025192743.0 / 30085553152.0 / 2, 0.0, 51252292925.0 / 65400821598.0 / 2,
-                                   -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
-                                   -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+struct RkTableau {
+    const char* name; int n; int order;       // n stages after k0 (k has n + 1 entries)
+    double alpha[6]; double beta[6][6]; double csol[7]; double cerr[7]; double cmid[7];
+};
+static const RkTableau kDopri5 = {
+    "dopri5", 6, 5,
+    {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0},
+    {{1.0 / 5},
+     {3.0 / 40, 9.0 / 40},
+     {44.0 / 45, -56.0 / 15, 32.0 / 9},
+     {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+     {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
+     {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}},
+    {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0.0},
+    {35.0 / 384 - 1951.0 / 21600, 0.0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+     -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60},
+    {6025192743.0 / 30085553152.0 / 2, 0.0, 51252292925.0 / 65400821598.0 / 2, -2691868925.0 / 45128329728.0 / 2,
+     187940372067.0 / 1594534317056.0 / 2, -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2}};
+static const RkTableau kBosh3 = {
+    "bosh3", 3, 3,
+    {1.0 / 2, 3.0 / 4, 1.0},
+    {{1.0 / 2}, {0.0, 3.0 / 4}, {2.0 / 9, 1.0 / 3, 4.0 / 9}},
+    {2.0 / 9, 1.0 / 3, 4.0 / 9, 0.0},
+    {2.0 / 9 - 7.0 / 24, 1.0 / 3 - 1.0 / 4, 4.0 / 9 - 1.0 / 3, -1.0 / 8},
+    {0.0, 0.5, 0.0, 0.0}};
+static const RkTableau kFehlberg2 = {
+    "fehlberg2", 2, 2,
+    {1.0 / 2, 1.0},
+    {{1.0 / 2}, {1.0 / 256, 255.0 / 256}},
+    {1.0 / 512, 255.0 / 256, 1.0 / 512},
+    {-1.0 / 512, 0.0, 1.0 / 512},
+    {0.0, 0.5, 0.0}};
+static const RkTableau kAdaptiveHeun = {
+    "adaptive_heun", 1, 2,
+    {1.0}, {{1.0}}, {0.5, 0.5}, {0.5, -0.5}, {0.5, 0.0}};
+
+int solve_adaptive(st_engine* e, const Plan& p, const float* mask, int use_cfg, float cfg_strength,
+                   const RkTableau& tb, hipStream_t s) {
+    const int S = tb.n;
+    bool fsal = tb.csol[S] == 0.0;
+    for (int j = 0; j < S; ++j) fsal = fsal && tb.csol[j] == tb.beta[S - 1][j];
     const double rtol = 1e-5, atol = 1e-5, t_end = 1.0;
     const int B = p.B;
     const int64_t per_item = (int64_t)p.T * e->Mp;
@@ -687,7 +717,7 @@ int solve_dopri5(st_engine* e, const Plan& p, const float* mask, int use_cfg, fl
     for (int j = 0; j < 7; ++j) k[j] = p.kbuf[j];
     // f0 = f(0, y0)   (x16 already holds y0)
     if ((rc = eval(0.0, k[0]))) return rc;
-    // _select_initial_step, order 4
+    // _select_initial_step(order - 1)
     OdeNormArgs na; memset(&na, 0, sizeof(na));
     na.mode = 0; na.y = y; na.b = k[0];
     if ((rc = norms(na))) return rc;
@@ -702,54 +732,64 @@ int solve_dopri5(st_engine* e, const Plan& p, const float* mask, int use_cfg, fl
     na.mode = 1; na.y = y; na.a = k[0]; na.b = k[1];
     if ((rc = norms(na))) return rc;
     const double d2 = sqrt(host2[0] / count) / h0;
-    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : pow(0.01 / std::max(d1, d2), 1.0 / 5.0);
+    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3)
+                                                   : pow(0.01 / std::max(d1, d2), 1.0 / (double)tb.order);
     double dt = std::min(100.0 * h0, h1), t = 0.0;
-    for (int64_t step = 0; step < 100000; ++step) {
+    for (int64_t step = 0; step < 1000000; ++step) {
         const double t1 = t + dt;
-        for (int i = 0; i < 6; ++i) {       // stage i+1: y_i = y + dt * sum_j beta[i][j] k_j ; k_{i+1} = f(t_i, y_i)
+        for (int i = 0; i < S; ++i) {       // stage i+1: y_i = y + dt * sum_j beta[i][j] k_j ; k_{i+1} = f(t_i, y_i)
             const float* ks[7]; float cf[7]; int nk = 0;
-            for (int j = 0; j <= i; ++j) if (BETA[i][j] != 0.0) { ks[nk] = k[j]; cf[nk] = (float)(BETA[i][j] * dt); ++nk; }
+            for (int j = 0; j <= i; ++j) if (tb.beta[i][j] != 0.0) { ks[nk] = k[j]; cf[nk] = (float)(tb.beta[i][j] * dt); ++nk; }
             {
                 ProfScope ps(e, s, PC_ODE, 0);
-                HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, i == 5 ? y1 : nullptr, p.x16, s));
+                // with an FSAL tableau (c_sol[:-1] == beta[-1], c_sol[-1] == 0) the last stage input IS y1
+                HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, (fsal && i == S - 1) ? y1 : nullptr, p.x16, s));
             }
-            const double ti = (ALPHA[i] == 1.0) ? t1 : t + ALPHA[i] * dt;
+            const double ti = (tb.alpha[i] == 1.0) ? t1 : t + tb.alpha[i] * dt;
             if ((rc = eval(ti, k[i + 1]))) return rc;
         }
-        // the 6th stage IS y1 (c_sol[:-1] == beta[-1], FSAL); error estimate from the seven derivatives
+        if (!fsal) {                        // y1 = y + dt * sum_j c_sol[j] k_j
+            const float* ks[7]; float cf[7]; int nk = 0;
+            for (int j = 0; j <= S; ++j) if (tb.csol[j] != 0.0) { ks[nk] = k[j]; cf[nk] = (float)(tb.csol[j] * dt); ++nk; }
+            ProfScope ps(e, s, PC_ODE, 0);
+            HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, y1, p.x16, s));
+        }
+        // error estimate from the stage derivatives
         memset(&na, 0, sizeof(na));
         na.mode = 2; na.y = y; na.a = y1; na.nk = 0;
-        for (int j = 0; j < 7; ++j) if (CERR[j] != 0.0) { na.k[na.nk] = k[j]; na.coef[na.nk] = (float)(CERR[j] * dt); ++na.nk; }
+        for (int j = 0; j <= S; ++j) if (tb.cerr[j] != 0.0) { na.k[na.nk] = k[j]; na.coef[na.nk] = (float)(tb.cerr[j] * dt); ++na.nk; }
         if ((rc = norms(na))) return rc;
         const double ratio = sqrt(host2[0] / count);
-        if (!(ratio == ratio)) return e->fail(ST_ERR_INVALID, "dopri5: non-finite error estimate");
+        if (!(ratio == ratio)) return e->fail(ST_ERR_INVALID, std::string(tb.name) + ": non-finite error estimate");
         const bool accept = ratio <= 1.0;
         double dt_next;
         if (ratio == 0.0) dt_next = dt * 10.0;
         else {
             const double dfactor = ratio < 1.0 ? 1.0 : 0.2;
-            dt_next = dt * std::min(10.0, std::max(0.9 / pow(ratio, 0.2), dfactor));
+            dt_next = dt * std::min(10.0, std::max(0.9 / pow(ratio, 1.0 / (double)tb.order), dfactor));
         }
         e->last_steps += 1;
         if (accept) {
-            if (t1 >= t_end) {      // dense output at t_end inside [t, t1] -> p.ynew
+            if (t1 >= t_end) {      // dense output at t_end inside [t, t1] -> p.ynew; slot 6 of the kernel is f1 = k[S]
                 const float* ks[7]; float cm[7];
-                for (int j = 0; j < 7; ++j) { ks[j] = k[j]; cm[j] = (float)(CMID[j] * dt); }
+                for (int j = 0; j < 7; ++j) { ks[j] = k[0]; cm[j] = 0.f; }
+                for (int j = 0; j < S; ++j) { ks[j] = k[j]; cm[j] = (float)(tb.cmid[j] * dt); }
+                ks[6] = k[S]; cm[6] = (float)(tb.cmid[S] * dt);
                 ProfScope ps(e, s, PC_ODE, 0);
                 // elementwise, so writing p.ynew in place is safe whichever of y / y1 it currently aliases
                 HIPCHK(e, launch_dopri5_interp(y, y1, ks, cm, (float)dt, (float)((t_end - t) / (t1 - t)), nstate, p.ynew, s));
                 return ST_OK;
             }
             std::swap(y, y1);                        // y <- y1
-            std::swap(k[0], k[6]);                   // f0 <- k7 (FSAL)
+            std::swap(k[0], k[S]);                   // f0 <- k[-1]
             t = t1;
         } else {
             e->last_rejects += 1;
         }
         dt = dt_next;
-        if (!(dt > 0.0) || dt < 1e-12) return e->fail(ST_ERR_INVALID, "dopri5: step size underflow");
+        if (!(dt > 0.0) || dt < 1e-12) return e->fail(ST_ERR_INVALID, std::string(tb.name) + ": step size underflow");
     }
-    return e->fail(ST_ERR_INVALID, "dopri5: too many steps");
+    return e->fail(ST_ERR_INVALID, std::string(tb.name) + ": too many steps");
 }
 
 int check_ready(st_engine* e, int B, int T) {
@@ -964,12 +1004,15 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
     if (!mu || !mask || !z || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (n_steps < 1 || n_steps > 4096) return e->fail(ST_ERR_INVALID, "n_steps out of range");
-    if (solver != ST_SOLVER_EULER && solver != ST_SOLVER_MIDPOINT && solver != ST_SOLVER_RK4 && solver != ST_SOLVER_DOPRI5)
-        return e->fail(ST_ERR_UNSUPPORTED, "solver not implemented natively (euler, midpoint, rk4, dopri5 are)");
+    if (solver < ST_SOLVER_EULER || solver > ST_SOLVER_ADAPTIVE_HEUN)
+        return e->fail(ST_ERR_UNSUPPORTED, "solver not implemented natively (euler, midpoint, rk4, dopri5, bosh3, "
+                                           "fehlberg2, adaptive_heun are)");
     if (use_cfg && (!fake_speaker || !fake_content)) return e->fail(ST_ERR_INVALID, "CFG needs fake_speaker and fake_content");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    const bool adaptive = solver == ST_SOLVER_DOPRI5;
+    const bool adaptive = solver >= ST_SOLVER_DOPRI5;
+    const RkTableau& tableau = solver == ST_SOLVER_BOSH3 ? kBosh3 : solver == ST_SOLVER_FEHLBERG2 ? kFehlberg2
+                             : solver == ST_SOLVER_ADAPTIVE_HEUN ? kAdaptiveHeun : kDopri5;
     const int stages = solver == ST_SOLVER_EULER ? 1 : (solver == ST_SOLVER_MIDPOINT ? 2 : 4);
     const int n_t = adaptive ? 1 : n_steps * stages;
     Plan p;
@@ -1007,7 +1050,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive ? 0 : n_steps; e->last_rejects = 0;
 
     if (adaptive) {
-        if ((rc = solve_dopri5(e, p, mask, use_cfg, cfg_strength, s))) return rc;
+        if ((rc = solve_adaptive(e, p, mask, use_cfg, cfg_strength, tableau, s))) return rc;
     } else
     for (int i = 0; i < n_steps; ++i) {
         const float dt = dts[i];

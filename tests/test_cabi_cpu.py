@@ -76,7 +76,7 @@ def test_shim_mirrors_reference_interface():
     # adaLN-Zero init like the reference (estimator.py:98-101)
     assert float(sd["blocks.0.block.adaLN_modulation.2.weight"].abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
-        dec(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), "bosh3")
+        dec(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), "implicit_adams")
     with pytest.raises(AssertionError):
         CFMDecoder(128, 128, 256, 128, 1024, 4, 5, 3, 0.1, 256)       # n_layers % 2 (estimator.py:92)
     with pytest.raises(NotImplementedError, match="backward"):        # training path: not native yet, fails loudly
