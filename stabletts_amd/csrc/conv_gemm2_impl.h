@@ -834,7 +834,11 @@ static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int lds_loop = 2 * BF * 128 + 3 * BC * 128, lds_stage = (WC * WF == 8 ? BF / WF : BF) * (BC + 4) * 4;
     constexpr int lds2 = lds_loop > lds_stage ? lds_loop : lds_stage, lds16 = BF * (BC * 2 + 16);
     constexpr int lds = lds2 > lds16 ? lds2 : lds16;
-    static bool attr_done = false;
+    // the >64 KB dynamic-LDS opt-in is per device: remember it per device id (engines may live on several GPUs)
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    bool& attr_done = attr_done_dev[dev_];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_gemm3_kernel<P, EPI, BC, BF, WC, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -855,7 +859,11 @@ static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
     using K = G2Cfg<BC, BF, WC, WF, TAPS>;
     constexpr int qkv_lds = (EPI == EPI_QKV) ? g2_qkv_lds_bytes<BC, BF>() : 0;
     constexpr int LDS = K::LDS_BYTES > qkv_lds ? K::LDS_BYTES : qkv_lds;
-    static bool attr_done = false;
+    // the >64 KB dynamic-LDS opt-in is per device: remember it per device id (engines may live on several GPUs)
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    bool& attr_done = attr_done_dev[dev_];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

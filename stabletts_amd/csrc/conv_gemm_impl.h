@@ -545,7 +545,11 @@ template <class P, int TAPS, int EPI, int OPT = 0>
 static hipError_t launch_glds(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int AROWS = kBF + TAPS - 1;
     constexpr int lds = ((OPT & 8) ? 1 : 2) * AROWS * 128 + 2 * kBC * 128;
-    static bool attr_done = false;
+    // the >64 KB dynamic-LDS opt-in is per device: remember it per device id (engines may live on several GPUs)
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    bool& attr_done = attr_done_dev[dev_];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<P, TAPS, EPI, OPT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -563,7 +567,11 @@ template <class P, int TAPS, int EPI, int VAR>
 static hipError_t launch_var(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int AROWS = kBF + TAPS - 1;
     constexpr int lds = 2 * AROWS * kLdsRowBytes + 2 * kBC * kLdsRowBytes;
-    static bool attr_done = false;
+    // the >64 KB dynamic-LDS opt-in is per device: remember it per device id (engines may live on several GPUs)
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    bool& attr_done = attr_done_dev[dev_];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<P, TAPS, EPI, VAR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
