@@ -98,7 +98,9 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
  *   use_cfg != 0 : classifier-free guidance with fake_speaker (gin,), fake_content (n_feats,)
  *                  and cfg_strength (models/model.py:43-44,102); cond and uncond branches run as
  *                  one 2B batch.
- *   out          : trajectory[-1], (B, n_feats, T). */
+ *   out          : trajectory[-1], (B, n_feats, T).
+ * Environment: ST_HIP_GRAPH=1 replays the fixed-grid solve body (everything between the boundary layout
+ * conversions) from a HIP graph captured at the second call with the same (B, T, n_steps, solver, CFG) signature. */
 int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* z, const float* c,
                  int n_steps, int solver, int use_cfg, float cfg_strength,
                  const float* fake_speaker, const float* fake_content,

@@ -91,6 +91,17 @@ struct st_engine {
 
     int64_t last_nfe = 0, last_steps = 0, last_rejects = 0;   // statistics of the last solve
 
+    // HIP-graph replay of the fixed-grid solve body (ST_HIP_GRAPH=1): one instantiated graph per solve signature
+    struct SolveGraph {
+        int B, T, n_steps, solver, use_cfg; float cfg_strength; const char* ws; int seen; hipGraphExec_t exec;
+    };
+    std::vector<SolveGraph> graphs;
+    hipStream_t gstream = nullptr;      // capture stream
+    void drop_graphs() {
+        for (auto& g : graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
+
     int fail(int code, const std::string& msg) { err = msg; return code; }
 };
 
@@ -262,6 +273,7 @@ struct Plan {
     float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
     int *n_full, *kv_end;
     float* kbias;
+    float* maskbuf;     // engine-owned copy of the caller's (B,1,T) mask: the solve body touches arena memory only
 };
 
 int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
@@ -308,7 +320,9 @@ int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
     want((void**)&p->n_full, (size_t)B * 4);
     want((void**)&p->kv_end, (size_t)B * 4);
     want((void**)&p->kbias, (size_t)B * p->Tp * 4);
+    want((void**)&p->maskbuf, (size_t)B * TT * 4);
     if (off > e->ws_cap) {
+        e->drop_graphs();      // instantiated graphs hold arena pointers
         if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
         HIPCHK(e, hipMalloc((void**)&e->ws, off));
         e->ws_cap = off;
@@ -869,6 +883,8 @@ void st_destroy(st_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     hipDeviceSynchronize();
+    e->drop_graphs();
+    if (e->gstream) hipStreamDestroy(e->gstream);
     for (auto& kv : e->params) if (kv.second.dev) hipFree(kv.second.dev);
     for (void* p : e->owned) hipFree(p);
     for (auto& kv : e->caps) if (kv.second.dev) hipFree(kv.second.dev);
@@ -908,6 +924,7 @@ int st_finalize(st_engine* e) {
     for (auto& kv : e->params)
         if (!kv.second.loaded) return e->fail(ST_ERR_STATE, "parameter not loaded: " + kv.first);
     HIPCHK(e, hipDeviceSynchronize());
+    e->drop_graphs();          // instantiated graphs hold the old packed-weight pointers
     for (void* p : e->owned) hipFree(p);
     e->owned.clear(); e->weight_bytes = 0;
     const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
@@ -1035,6 +1052,8 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, launch_set_values(p.tvals, tv.data(), (int)tv.size(), s));   // by kernel argument: no copy, no sync
         HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
+        HIPCHK(e, launch_cvec_prep(mask, nullptr, B, T, p.maskbuf, s));      // plain copy of the (B,1,T) mask
+        mask = p.maskbuf;
         HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
         HIPCHK(e, launch_to_time_major(e->dt, z, B, e->M, T, e->Mp, p.xstate, p.x16, s));
         HIPCHK(e, launch_cvec_prep(c, use_cfg ? fake_speaker : nullptr, B, e->G, p.cvec, s));
@@ -1044,11 +1063,15 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                                          (char*)p.mu16 + (size_t)B * per_item * 2, s));
         }
     }
+    e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive ? 0 : n_steps; e->last_rejects = 0;
+
+    // Everything between the boundary conversions above and below touches engine memory only, so for the fixed-grid
+    // solvers it is a static launch sequence: `body` enqueues it, either directly or once into a HIP graph.
+    auto body = [&](hipStream_t s) -> int {      // (the parameter shadows the caller's stream on purpose)
+    int rc;
     if ((rc = run_prenet(e, p, s))) return rc;
     if ((rc = run_adaln(e, p, s))) return rc;
     if (!adaptive && (rc = run_time_tables(e, p, s))) return rc;
-    e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive ? 0 : n_steps; e->last_rejects = 0;
-
     if (adaptive) {
         if ((rc = solve_adaptive(e, p, mask, use_cfg, cfg_strength, tableau, s))) return rc;
     } else
@@ -1091,6 +1114,44 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
             }
         }
     }
+    return ST_OK;
+    };   // body
+
+    // ST_HIP_GRAPH=1 (read per call): the fixed-grid solve body (~45 launches per evaluation) is captured into a HIP
+    // graph the second time a solve signature is seen (the first run is eager: it also performs the one-time
+    // per-kernel attribute set-up, which must not happen inside a capture) and replayed afterwards.  Adaptive
+    // solvers have a host-side controller and always run eagerly; so do profiled / debug-captured solves.
+    const char* genv = getenv("ST_HIP_GRAPH");
+    const bool want_graph = genv && atoi(genv) == 1 && !adaptive && !e->prof && !e->capture;
+    bool done = false;
+    if (want_graph) {
+        st_engine::SolveGraph* g = nullptr;
+        for (auto& q : e->graphs)
+            if (q.B == B && q.T == T && q.n_steps == n_steps && q.solver == solver && q.use_cfg == (use_cfg != 0) &&
+                q.cfg_strength == cfg_strength && q.ws == e->ws) g = &q;
+        if (!g) {
+            if (e->graphs.size() >= 16) e->drop_graphs();
+            e->graphs.push_back({B, T, n_steps, solver, use_cfg != 0, cfg_strength, e->ws, 0, nullptr});
+            g = &e->graphs.back();
+        }
+        if (g->seen >= 1 && !g->exec) {
+            // captured on an engine-owned stream (the caller's may be the legacy default stream, which cannot
+            // capture); nothing executes during capture, the instantiated graph is launched on the caller's stream
+            if (!e->gstream) HIPCHK(e, hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            HIPCHK(e, hipStreamBeginCapture(e->gstream, hipStreamCaptureModeRelaxed));
+            const int brc = body(e->gstream);
+            const hipError_t ec = hipStreamEndCapture(e->gstream, &graph);
+            if (brc) { if (graph) hipGraphDestroy(graph); return brc; }
+            if (ec != hipSuccess || !graph) return e->fail(ST_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+            const hipError_t ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (ei != hipSuccess) { g->exec = nullptr; return e->fail(ST_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+        }
+        g->seen += 1;
+        if (g->exec) { HIPCHK(e, hipGraphLaunch(g->exec, s)); done = true; }
+    }
+    if (!done && (rc = body(s))) return rc;
     {
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, launch_from_time_major(adaptive ? p.ynew : p.xstate, B, e->M, T, e->Mp, out, s));

@@ -378,3 +378,20 @@ def test_non_native_solver_runs_torchdiffeq_controller_over_native_estimator(dec
         out = d(inp["mu"], inp["mask"], 4, 0.8, inp["c"], "implicit_adams", cfg, z=inp["z"])
         assert calls == dict(method="implicit_adams", rtol=1e-5, atol=1e-5, nfe=4)
         assert _rel(out.cpu(), ref.cpu()) <= 2e-4
+
+
+@pytest.mark.parametrize("solver,n", [("euler", 6), ("rk4", 2)])
+def test_hip_graph_replay_is_bitwise_identical(decoders, cfg_params, monkeypatch, solver, n):
+    """ST_HIP_GRAPH=1: the fixed-grid solve body is captured into a HIP graph the second time a solve signature is
+    seen and replayed afterwards.  Replays must equal the eager launches bit for bit, also when the caller's input
+    tensors (content and addresses) change between calls."""
+    d = decoders["bf16"]
+    kw = _cfg(cfg_params, 2.5, True)
+    cases = [make_inputs(3, 90, seed=50 + i, lengths=[90, 64, 33]) for i in range(4)]
+    monkeypatch.delenv("ST_HIP_GRAPH", raising=False)
+    eager = [_solve(d, c, n, solver, kw, c["z"]) for c in cases]
+    monkeypatch.setenv("ST_HIP_GRAPH", "1")
+    for rep in range(2):
+        for c, ref in zip(cases, eager):          # call 1 eager (warm), call 2 captures, later calls replay
+            out = _solve(d, c, n, solver, kw, c["z"])
+            assert torch.equal(out, ref)

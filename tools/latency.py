@@ -17,6 +17,7 @@ dec.estimator.load_state_dict(oracle.make_state_dict(1234))
 dec = dec.to(dev)
 fs, fc = oracle.make_cfg_params(4321)
 kw = dict(fake_speaker=fs.to(dev), fake_content=fc.to(dev), cfg_strength=3.0)
+print("ST_HIP_GRAPH =", os.environ.get("ST_HIP_GRAPH", "0"))
 for B, T, cfg in [(1, 500, None), (1, 500, kw), (4, 500, kw), (8, 1000, kw), (32, 1000, kw)]:
     g = {k: v.to(dev) for k, v in make_inputs(B, T, seed=0).items() if k != "lengths"}
     ts = []
