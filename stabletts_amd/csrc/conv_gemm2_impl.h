@@ -268,6 +268,7 @@ __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][
         const int fl = wf * TF + b * 32 + l31;
         const int t = t0 + fl;
         const float m = mrow ? mrow[t < T ? t : T - 1] : 1.0f;
+        const bool allone = __all(m == 1.0f);
 #pragma unroll
         for (int a = 0; a < FC; ++a) {          // one 32x32 fragment at a time: its registers die at the ds_write
             f32x16_t v = acc[a][b];
@@ -275,8 +276,10 @@ __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = silu_fast(v[r]);
             }
+            if (!allone) {                      // wave-uniform: tiles inside the valid prefix skip the multiply
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] *= m;
+                for (int r = 0; r < 16; ++r) v[r] *= m;
+            }
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
