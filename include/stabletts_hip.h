@@ -79,6 +79,11 @@ int st_load_param(st_engine* e, const char* name, const float* data, const int64
 /* Number of state_dict tensors the configured architecture expects (116 for the 31M model). */
 int st_num_params(const st_engine* e);
 
+/* Enumerates the expected tensors (index in [0, st_num_params), name order): reference state_dict name and
+ * shape, so that a host without the Python module tree can discover what to load.  Returns the number of
+ * dimensions (<= 4) and writes them to shape[0..ndim) if shape != NULL; *name points into the engine. */
+int st_param_info(const st_engine* e, int index, const char** name, int64_t* shape);
+
 /* Packs the uploaded fp32 parameters into the engine's 16-bit MFMA operand layouts.  Must be
  * called after loading (and again after any parameter update). */
 int st_finalize(st_engine* e);

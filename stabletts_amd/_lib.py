@@ -24,7 +24,7 @@ SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_S
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
     "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
-    "st_create_text_encoder", "st_text_encoder_forward",
+    "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes",
 ]
@@ -93,6 +93,8 @@ def load():
     lib.st_profile_enable.restype = c_int
     lib.st_profile_select.argtypes = [c_void_p, ctypes.c_uint64]
     lib.st_profile_select.restype = c_int
+    lib.st_param_info.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64)]
+    lib.st_param_info.restype = c_int
     lib.st_create_text_encoder.argtypes = [ctypes.POINTER(StConfig), c_int, c_int, ctypes.POINTER(c_void_p)]
     lib.st_create_text_encoder.restype = c_int
     lib.st_text_encoder_forward.argtypes = [c_void_p] + [c_void_p] * 6 + [c_int, c_int, c_void_p]
@@ -153,6 +155,18 @@ class Engine:
 
     def num_params(self):
         return self.lib.st_num_params(self.handle)
+
+    def param_info(self):
+        """[(reference state_dict name, shape)] the handle expects, in the engine's (name) order."""
+        out = []
+        for i in range(self.num_params()):
+            name = ctypes.c_char_p()
+            shape = (ctypes.c_int64 * 4)()
+            nd = self.lib.st_param_info(self.handle, i, ctypes.byref(name), shape)
+            if nd < 0:
+                raise NativeError(nd, "st_param_info")
+            out.append((name.value.decode(), tuple(shape[:nd])))
+        return out
 
     def load_state_dict(self, sd):
         """sd: name -> torch.Tensor (fp32, any device), reference ``decoder.estimator.*`` names."""

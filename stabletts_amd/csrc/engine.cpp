@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <string>
 #include <vector>
@@ -900,6 +901,15 @@ void st_destroy(st_engine* e) {
 const char* st_last_error(const st_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
 int st_num_params(const st_engine* e) { return e ? (int)e->params.size() : ST_ERR_INVALID; }
+
+int st_param_info(const st_engine* e, int index, const char** name, int64_t* shape) {
+    if (!e || index < 0 || index >= (int)e->params.size()) return ST_ERR_INVALID;
+    auto it = e->params.begin();
+    std::advance(it, index);
+    if (name) *name = it->first.c_str();
+    if (shape) for (size_t i = 0; i < it->second.shape.size(); ++i) shape[i] = it->second.shape[i];
+    return (int)it->second.shape.size();
+}
 
 int st_load_param(st_engine* e, const char* name, const float* data, const int64_t* shape, int ndim) {
     if (!e) return ST_ERR_INVALID;
