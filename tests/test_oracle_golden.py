@@ -128,3 +128,37 @@ def test_text_encoder_oracle_matches_reference_fixture():
             want = g[name + key]
             assert got.shape == want.shape
             assert np.abs(got.numpy() - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0)
+
+
+def test_oracle_gradients_match_reference_fixture(sd, golden):
+    """Backward arithmetic of the oracle (autograd through oracle.compute_loss) vs gradients of the REAL reference
+    modules (tests/golden/loss_grads.npz, oracle/make_golden_grads.py; dropout off): every parameter's gradient
+    norm, seven tensors in full, d loss / d mu and d loss / d c.  Pins the checker for the native backward pass
+     before that pass exists."""
+    import os
+    import numpy as np
+    import torch
+    import oracle
+    from oracle.inputs import make_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_grads.npz"))
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    inp = make_inputs(2, 44, seed=31, lengths=[44, 29])
+    x1 = make_inputs(2, 44, seed=32)["z"]
+    mu = inp["mu"].clone().requires_grad_(True)
+    c = inp["c"].clone().requires_grad_(True)
+    loss, _ = oracle.compute_loss(p, x1, inp["mask"], mu, c, torch.from_numpy(golden["loss_t_rand"]),
+                                  torch.from_numpy(golden["loss_z"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss_value"][0])) <= 1e-5 * float(g["loss_value"][0])
+    names = [str(n) for n in g["names"]]
+    assert names == list(sd.keys()) or set(names) == set(sd.keys())
+    scale = float(g["grad_norms"].max())
+    for name, want in zip(names, g["grad_norms"]):
+        got = float(p[name].grad.double().norm())
+        assert abs(got - want) <= 2e-4 * want + 1e-7 * scale, name
+    for key in g.files:
+        if key.startswith("grad."):
+            got, want = p[key[5:]].grad.numpy(), g[key]
+            assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 1e-9, key
+    for got, want in ((mu.grad.numpy(), g["grad_mu"]), (c.grad.numpy(), g["grad_c"])):
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
