@@ -16,9 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("ST_BUILD_OUT") or os.path.join(HERE, "libstabletts_hip.so")
 OBJ = os.path.join(HERE, "csrc", "build") if not os.environ.get("ST_BUILD_OUT") else LIB + ".obj"
-SOURCES = ["engine.cpp", "conv_gemm_bf16.hip", "conv_gemm_f16.hip", "conv_gemm2_bf16.hip", "conv_gemm2_f16.hip",
+SOURCES = ["engine.cpp", "conv_gemm2_bf16.hip", "conv_gemm2_f16.hip",
            "attention.hip", "misc_kernels.hip", "adaptive_ode.hip"]
-HEADERS = ["common.h", "launch.h", "conv_gemm_impl.h", "conv_gemm2_impl.h", "conv_gemm2_inst.h", os.path.join("..", "..", "include", "stabletts_hip.h")]
+HEADERS = ["common.h", "launch.h", "conv_gemm2_impl.h", "conv_gemm2_inst.h", os.path.join("..", "..", "include", "stabletts_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 FLAGS += os.environ.get("ST_BUILD_DEFS", "").split()
 

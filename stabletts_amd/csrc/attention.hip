@@ -27,26 +27,8 @@
 #include "common.h"
 #include "launch.h"
 
-#ifndef ST_ATTN_NEGM
-#define ST_ATTN_NEGM 0
-#endif
 #ifndef ST_ATTN_WAVES
 #define ST_ATTN_WAVES 8      // waves (x 32 queries) per block sharing one K/V tile stream: 4, 8 or 16
-#endif
-#ifndef ST_ATTN_EPI_LDS
-#define ST_ATTN_EPI_LDS 1
-#endif
-#ifndef ST_ATTN_ILV
-#define ST_ATTN_ILV 0
-#endif
-#ifndef ST_ATTN_VPRE
-#define ST_ATTN_VPRE 0
-#endif
-#ifndef ST_ATTN_DIAG
-#define ST_ATTN_DIAG 0
-#endif
-#ifndef ST_ATTN_PRIO
-#define ST_ATTN_PRIO 0     // 1: s_setprio 1 around the MFMA clusters, 2: static priority 1 for odd blocks
 #endif
 
 namespace st {
@@ -132,57 +114,24 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-#if ST_ATTN_NEGM
-    // The running maximum enters the score MFMA as its C operand (a 16-register vector holding -m for this
-    // lane's query), so S^T comes out already shifted and the per-score subtraction disappears from the
-    // softmax; the vector is rewritten only when some lane's maximum moves.
-    float m_run = 0.f, l_run = 0.f;
-    f32x16_t negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-#else
     float m_run = -1e30f, l_run = 0.f;
-#endif
 
-#if ST_ATTN_PRIO == 2
-    if (blockIdx.x & 8) __builtin_amdgcn_s_setprio(1);
-#endif
     if (ntiles > 0) issueKV(0, 0);
     ST_DMA_WAIT(0);
     __syncthreads();
 
-#if ST_ATTN_DIAG == 3        // timing diagnostic only (wrong numerics): a quarter of the key tiles
-    const int ntiles_run = (ntiles + 3) / 4;
-#else
     const int ntiles_run = ntiles;
-#endif
     for (int kt = 0; kt < ntiles_run; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ntiles_run) issueKV(kt + 1, buf ^ 1);
 
         // ---- S^T = K . Q^T  (log2 units)
         f32x16_t s[2];
-#if ST_ATTN_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#if ST_ATTN_NEGM
-            s[kb] = negm;
-#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#endif
         }
-#if ST_ATTN_ILV
-        // the two accumulator chains alternate, so no MFMA waits on the result of the one issued just before it
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-                s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(Ks + buf * TILE_BYTES + row_off[kb] + (((ks * 2 + hi) ^ swz[kb]) << 4))),
-                                qf[ks], s[kb]);
-#else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const unsigned char* kp = Ks + buf * TILE_BYTES + row_off[kb];
@@ -190,19 +139,6 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
             for (int ks = 0; ks < 4; ++ks)
                 s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(kp + (((ks * 2 + hi) ^ swz[kb]) << 4))), qf[ks], s[kb]);
         }
-#endif
-#if ST_ATTN_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if ST_ATTN_VPRE
-        // V^T fragments of this tile are requested now, so their LDS latency runs under the softmax below
-        vec8 vf[2][4];
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                vf[d][g] = as_vec8<P>(*(const uint4*)(Vs + buf * TILE_BYTES + row_off[d] + (((g * 2 + hi) ^ swz[d]) << 4)));
-#endif
         // ---- key bias (only tiles that are not entirely inside the valid prefix)
         if ((kt + 1) * 64 > nfull) {
 #pragma unroll
@@ -221,27 +157,6 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = xor32_max(mx);
-#if ST_ATTN_NEGM
-        // s holds score - m_run.  The first tile always contains a valid key (key 0), so its maximum is finite
-        // and becomes m_run whatever its sign; later tiles move m_run only upwards.
-        const bool mv = (kt == 0) || (mx > 0.f);
-        if (__any(mv)) {
-            const float delta = mv ? mx : 0.f;
-            const float alpha = (kt == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-            m_run += delta;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-        }
-#else
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -252,7 +167,6 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
             m_run = m_new;
         }
-#endif
 
         vec8 pf[4];
         float psum = 0.f;
@@ -260,54 +174,26 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#if ST_ATTN_DIAG == 1      // timing diagnostic only (wrong numerics): no transcendental
-                const float p = fabsf(s[kb][r] - m_run) * 1e-3f + 1e-3f;
-#elif ST_ATTN_DIAG == 2    // timing diagnostic only: no subtraction, no transcendental
-                const float p = fabsf(s[kb][r]);
-#elif ST_ATTN_NEGM
-                const float p = __builtin_amdgcn_exp2f(s[kb][r]);
-#else
                 const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
-#endif
                 psum += p;
                 pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p);
             }
         l_run += psum;
 
         // ---- O^T += V^T . P^T
-#if ST_ATTN_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#if ST_ATTN_ILV
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-                o[d] = P::mfma(as_vec8<P>(*(const uint4*)(Vs + buf * TILE_BYTES + row_off[d] + (((g * 2 + hi) ^ swz[d]) << 4))),
-                               pf[g], o[d]);
-#else
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             const unsigned char* vp = Vs + buf * TILE_BYTES + row_off[d];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-#if ST_ATTN_VPRE
-                o[d] = P::mfma(vf[d][g], pf[g], o[d]);
-#else
                 o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
-#endif
         }
-#endif
-#if ST_ATTN_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
         ST_DMA_WAIT(0);       // tile kt+1 (asm-issued LDS-DMA, flying under this tile's MFMAs and exps) has landed
         __syncthreads();      // fence the buffer swap
     }
 
     const float l_tot = xor32_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-#if ST_ATTN_EPI_LDS
     // Output through LDS: each wave parks its 32 x 64 tile as [query][d] (144-B pitch) in its own slice of the K/V
     // buffers (free after the loop's last barrier) and writes it out as 128-B rows, 16 B per lane -- 4 wide stores
     // per lane instead of 16 scattered 8-B ones (the row-per-lane epilogue is store-issue bound, guide T21).
@@ -326,19 +212,6 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
         const uint4 v = *(const uint4*)(mine + row * 144 + seg * 16);
         if (qt * QB + wave * 32 + row < T) *(uint4*)(obase + (size_t)row * (H * 64) * 2) = v;
     }
-#else
-    if (query < T) {
-        unsigned char* dst = (unsigned char*)a.out + (((size_t)n * T + query) * (H * 64) + h * 64) * 2;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int dd = d * 32 + 8 * q4 + 4 * hi;
-                *(uint2*)(dst + dd * 2) = pack4<P>(o[d][4 * q4 + 0] * inv, o[d][4 * q4 + 1] * inv,
-                                                   o[d][4 * q4 + 2] * inv, o[d][4 * q4 + 3] * inv);
-            }
-    }
-#endif
 }
 
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {

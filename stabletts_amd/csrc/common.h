@@ -84,25 +84,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // while the kernel is still computing.  Only for full-line coalesced rows (partial-line scatter stores, e.g.
 // the attention output, keep the write-back path so the L2 can merge them).
 // The trailing s_nop covers the store-data hazard that hipcc cannot see behind inline asm (guide 5.7).
-#ifndef ST_STORE_WT
-#define ST_STORE_WT 1
-#endif
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_row16(void* p, uint4 v) {
-#if ST_STORE_WT
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
-#else
-    *(uint4*)p = v;
-#endif
 }
 __device__ __forceinline__ void store_row16(void* p, float4 v) { store_row16(p, __builtin_bit_cast(uint4, v)); }
 __device__ __forceinline__ void store_row8(void* p, uint2 v) {
-#if ST_STORE_WT
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x2_t, v)) : "memory");
-#else
-    *(uint2*)p = v;
-#endif
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -115,7 +104,6 @@ typedef __attribute__((address_space(1))) const void global_cvoid_t;
 // the ISA; measured: DMA-only 113 us + compute-only 97 us -> 142 us).  An asm statement is invisible to that
 // pass; completion is tracked by hand with counted `s_waitcnt vmcnt(N)` in front of the stage barrier.
 // M0 (LDS destination base of the DMA) is saved/restored inside the statement (guide section 5.7).
-#ifndef ST_GLDS_BUILTIN
 __device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
     const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)lds_wave_base);
     unsigned keep;
@@ -131,13 +119,5 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(off) : "memory");
 }
 #define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#else
-__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((global_cvoid_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
-}
-#define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#endif
-
-constexpr int kLdsRowBytes = 144;  // 64 x 16-bit channels + 16 B pad: conflict-free ds_read_b128 over 16 rows
 
 }  // namespace st

@@ -1,5 +1,5 @@
-// Implicit-GEMM Conv1d (k = 1 or 3) for gfx950, second generation: LDS-DMA staged K loop (as
-// conv_gemm_impl.h) + LDS-staged, fully coalesced epilogues that can carry the NEXT LayerNorm.
+// Implicit-GEMM Conv1d (k = 1 or 3) for gfx950: LDS-DMA staged K loop + LDS-staged, fully coalesced
+// epilogues that can carry the NEXT LayerNorm.
 //
 // Tile shapes (template): BC output channels x BF frames, WC x WF waves, wave tile (BC/WC) x (BF/WF)
 // built from 32x32x16 MFMA fragments.  Shipping configurations:
@@ -23,20 +23,8 @@
 #include "launch.h"
 #include <cstdlib>
 
-#ifndef ST_FRAG_PREFETCH
-#define ST_FRAG_PREFETCH 0
-#endif
-#ifndef ST_DMA_SPREAD
-#define ST_DMA_SPREAD 0
-#endif
 #ifndef ST_STAGE_TIMING
-#define ST_STAGE_TIMING 0
-#endif
-#ifndef ST_DMA_FAST
-#define ST_DMA_FAST 1
-#endif
-#ifndef ST_DMA_SPLIT
-#define ST_DMA_SPLIT 0
+#define ST_STAGE_TIMING 0      // 1: s_memtime anatomy of the K loop into ConvGemmArgs::dbg (tools/gemm2_bench.hip only)
 #endif
 
 namespace st {
@@ -116,6 +104,14 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
 #pragma unroll
             for (int u = 0; u < R; ++u)
                 if (ok[u]) store_row8((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2, pack4<P>(v[u].x, v[u].y, v[u].z, v[u].w));
+            if (g.out16_lo) {      // split-precision copy: lo = x - float(hi), the operand pair of final_proj
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const float4 l = make_float4(v[u].x - (float)to16<P>(v[u].x), v[u].y - (float)to16<P>(v[u].y),
+                                                 v[u].z - (float)to16<P>(v[u].z), v[u].w - (float)to16<P>(v[u].w));
+                    if (ok[u]) store_row8((unsigned char*)g.out16_lo + (grow[u] * g.cout + ch) * 2, pack4<P>(l.x, l.y, l.z, l.w));
+                }
+            }
         }
         if constexpr (LN) {
             if (g.ln_h16) {
@@ -169,7 +165,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
     const int T = g.T;
-    static_assert(EPI != EPI_QKV && EPI != EPI_ACT16, "QKV: conv_gemm_impl.h; ACT16: g2_epilogue_act16");
+    static_assert(EPI != EPI_QKV && EPI != EPI_ACT16, "QKV: g2_epilogue_qkv; ACT16: g2_epilogue_act16");
     static_assert(BC == 128 || BC == 256, "row walker handles 128 or 256 channels");
     constexpr bool LN = (BC == 256);
     // frames staged per pass: the 4-wave 128x128 tile goes in ONE pass (fewer barriers, one exposed global-load
@@ -380,10 +376,11 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
                 }
         }
         __syncthreads();
-        const int rsub = lane >> 5, seg = lane & 31;
+        constexpr int SPR = BF / 8, RPI = 64 / SPR;      // 16-B segments per channel row, channel rows per wave instruction
+        const int rsub = lane / SPR, seg = lane % SPR;
 #pragma unroll
-        for (int i = 0; i < BC / (NW * 2); ++i) {
-            const int ch = (i * NW + wave) * 2 + rsub;
+        for (int i = 0; i < BC / (NW * RPI); ++i) {
+            const int ch = (i * NW + wave) * RPI + rsub;
             const uint4 v = *(const uint4*)(stage + ch * PV + seg * 16);
             const int tcol = t0 + seg * 8;
             if (tcol < g.Tp)
@@ -393,17 +390,16 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
 }
 
 template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF>
-__global__ __launch_bounds__(64 * WC * WF, (64 * WC * WF) == 256 ? 2 : 2)
+__global__ __launch_bounds__(64 * WC * WF, 2)
 void conv_gemm2_kernel(const ConvGemmArgs g) {
     using vec8 = typename P::vec8;
     using K = G2Cfg<BC, BF, WC, WF, TAPS>;
-    constexpr int NW = K::NW, NT = K::NT, FC = K::FC, FF = K::FF, TC = K::TC, TF = K::TF;
-    constexpr int A_BYTES = K::A_BYTES, W_BYTES = K::W_BYTES, PITCH = K::PITCH;
+    constexpr int NW = K::NW, FC = K::FC, FF = K::FF, TC = K::TC, TF = K::TF;
+    constexpr int A_BYTES = K::A_BYTES, W_BYTES = K::W_BYTES;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
     unsigned char* Ws = smem + 2 * A_BYTES;
-    float* stage = (float*)smem;
 
     const int total = g.n_items * g.tiles_f * g.tiles_c;
     const int per_xcd = gridDim.x >> 3;
@@ -419,33 +415,20 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
     const int cbase = tc * BC, t0 = tf * BF;
-    const int cin = g.c0 + g.c1;
+    const int cin = g.c0 + g.c1 + g.c2;
     const int nch = cin >> 6;
     const int T = g.T;
 
     const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
     const unsigned char* a1 = g.c1 ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;
     const unsigned char* wsrc = (const unsigned char*)g.w;
-    const unsigned char* zeros = (const unsigned char*)g.zeros;
 
+    // LDS-DMA addressing.  The loop-invariant per-lane part of every source address is computed once (the
+    // per-stage part is scalar arithmetic on an SGPR base): issuing a 1-KiB piece costs the issuing wave ~100
+    // cycles, address VALU included.  Activation rows outside [0, T) are never transferred; their LDS rows are
+    // zeroed once, here (both buffers).
+    constexpr int WPW = (BC / 8) / NW, APW = (BF / 8) / NW;       // 1-KiB DMA pieces per wave per tile
     const int prow = lane >> 3;
-    // ST_DMA_SPLIT (8-wave tiles): only waves 0..3 -- one per SIMD -- issue LDS-DMA.  Issuing a piece costs the
-    // issuing wave ~100 cycles (measured with s_memtime: 560 of 2700 ticks per stage when all 8 waves issue in
-    // lockstep and the matrix pipe idles meanwhile); with one loader wave per SIMD its partner wave (4..7)
-    // owns the matrix pipe during the issue phase, and the loader's MFMAs follow.
-    constexpr int NL = (ST_DMA_SPLIT && NW == 8) ? NW / 2 : NW;    // number of DMA-issuing waves
-    constexpr int WPW = (BC / 8) / NL, APW = (BF / 8) / NL;       // 1-KiB DMA pieces per loader wave per tile
-    const bool loader = wave < NL;
-    auto issueW1 = [&](int c, int j, int buf, int k) {
-        const int piece = wave * WPW + k;
-        const int row = piece * 8 + prow;
-        const int seg = (lane & 7) ^ ((row >> 1) & 7);
-        const unsigned char* src = wsrc + ((size_t)((cbase + row) * TAPS + j) * cin + (c << 6)) * 2 + seg * 16;
-        glds16b(src, Ws + buf * W_BYTES + piece * 1024);
-    };
-#if ST_DMA_FAST
-    // Loop-invariant per-lane parts of every DMA source address, computed once: the per-stage part is scalar.
-    // Activation rows outside [0, T) are never transferred; their LDS rows are zeroed once, here.
     unsigned voffW[WPW], voffA0[APW + 1], voffA1[APW + 1];
     bool validA[APW + 1];
 #pragma unroll
@@ -455,13 +438,13 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     }
 #pragma unroll
     for (int k = 0; k <= APW; ++k) {
-        const int row = (k < APW) ? (wave * APW + k) * 8 + prow : BF + prow;
+        const int row = (k < APW) ? (wave * APW + k) * 8 + prow : BF + prow;     // k == APW: the two halo rows (k = 3)
         const int t = t0 + row - (TAPS / 2);
         const unsigned segb = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
-        validA[k] = loader && (t >= 0 && t < T) && (k < APW || (TAPS == 3 && wave == 0 && lane < 16));
+        const bool mine = (k < APW) || (TAPS == 3 && wave == 0 && lane < 16);
+        validA[k] = mine && (t >= 0 && t < T);
         voffA0[k] = (unsigned)(t * g.c0 * 2) + segb;
         voffA1[k] = (unsigned)(t * g.c1 * 2) + segb;
-        const bool mine = loader && ((k < APW) || (TAPS == 3 && wave == 0 && lane < 16));
         if (mine && !(t >= 0 && t < T)) {
             const int pc = (k < APW) ? wave * APW + k : BF / 8;
             *(uint4*)(As + pc * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
@@ -473,8 +456,12 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #pragma unroll
         for (int k = 0; k < WPW; ++k) glds16s(sb, voffW[k], Ws + buf * W_BYTES + (wave * WPW + k) * 1024);
     };
+    // K source of channel chunk c: [0, c0) -> a0, [c0, c0 + c1) -> a1 (torch.cat without the copy), and
+    // [c0 + c1, c0 + c1 + c2) -> a0 AGAIN from its channel 0 (split-precision operands: [x_hi | x_lo | x_hi]
+    // against packed weights [W_hi | W_hi | W_lo])
     auto issueA = [&](int c, int buf) {
-        const int ch0 = c << 6;
+        int ch0 = c << 6;
+        if (ch0 >= g.c0 + g.c1) ch0 -= g.c0 + g.c1;
         const bool first = ch0 < g.c0;
         const unsigned char* sb = first ? a0 + (size_t)ch0 * 2 : a1 + (size_t)(ch0 - g.c0) * 2;
 #pragma unroll
@@ -483,67 +470,6 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
             const int pc = (k < APW) ? wave * APW + k : BF / 8;
             if (validA[k]) glds16s(sb, first ? voffA0[k] : voffA1[k], As + buf * A_BYTES + pc * 1024);
         }
-    };
-#else
-    auto issueW = [&](int c, int j, int buf) {
-#pragma unroll
-        for (int k = 0; k < WPW; ++k) issueW1(c, j, buf, k);
-    };
-    auto issueA = [&](int c, int buf) {
-        const int ch0 = c << 6;
-        const unsigned char* srcb; int cs, coff;
-        if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
-        else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
-#pragma unroll
-        for (int k = 0; k < APW; ++k) {
-            const int piece = wave * APW + k;
-            const int row = piece * 8 + prow;
-            const int seg = (lane & 7) ^ ((row >> 1) & 7);
-            const int t = t0 + row - (TAPS / 2);
-            const unsigned char* src = (t >= 0 && t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
-            glds16b(src, As + buf * A_BYTES + piece * 1024);
-        }
-        if constexpr (TAPS == 3) {
-            if (wave == 0 && lane < 16) {          // halo rows BF, BF+1
-                const int row = BF + prow;
-                const int seg = (lane & 7) ^ ((row >> 1) & 7);
-                const int t = t0 + row - 1;
-                const unsigned char* src = (t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
-                glds16b(src, As + buf * A_BYTES + (BF / 8) * 1024);
-            }
-        }
-    };
-#endif
-    // one slice (k-step ks of 4) of the same transfers, for spreading the DMA issue over the MFMA k-steps
-    auto issueA_slice = [&](int c, int buf, int ks) {
-        const int ch0 = c << 6;
-        const unsigned char* srcb; int cs, coff;
-        if (ch0 < g.c0) { srcb = a0; cs = g.c0; coff = ch0; }
-        else            { srcb = a1; cs = g.c1; coff = ch0 - g.c0; }
-#pragma unroll
-        for (int k = 0; k < APW; ++k) {
-            if ((k * 4) / APW != ks) continue;
-            const int piece = wave * APW + k;
-            const int row = piece * 8 + prow;
-            const int seg = (lane & 7) ^ ((row >> 1) & 7);
-            const int t = t0 + row - (TAPS / 2);
-            const unsigned char* src = (t >= 0 && t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
-            glds16b(src, As + buf * A_BYTES + piece * 1024);
-        }
-        if constexpr (TAPS == 3) {
-            if (ks == 3 && wave == 0 && lane < 16) {
-                const int row = BF + prow;
-                const int seg = (lane & 7) ^ ((row >> 1) & 7);
-                const int t = t0 + row - 1;
-                const unsigned char* src = (t < T) ? srcb + ((size_t)t * cs + coff) * 2 + seg * 16 : zeros;
-                glds16b(src, As + buf * A_BYTES + (BF / 8) * 1024);
-            }
-        }
-    };
-    auto issueW_slice = [&](int c, int j, int buf, int ks) {
-#pragma unroll
-        for (int k = 0; k < WPW; ++k)
-            if ((k * 4) / WPW == ks) issueW1(c, j, buf, k);
     };
 
     f32x16_t acc[FC][FF];
@@ -555,7 +481,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
         const int row = wc * TC + a * 32 + l31;
         wrow_off[a] = row * 128; wswz[a] = (row >> 1) & 7;
     }
-    auto compute = [&](int abuf, int wbuf, int j, auto&& pre) {
+    auto compute = [&](int abuf, int wbuf, int j) {
         const unsigned char* Ab = As + abuf * A_BYTES;
         const unsigned char* Wb = Ws + wbuf * W_BYTES;
         int arow_off[FF], aswz[FF];
@@ -564,34 +490,8 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
             const int row = wf * TF + b * 32 + l31 + j;
             arow_off[b] = row * 128; aswz[b] = (row >> 1) & 7;
         }
-#if ST_FRAG_PREFETCH
-        // fragments run two k-steps ahead of the MFMAs (two register sets), so a wave's own MFMAs cover its LDS latency
-        vec8 wfr[2][FC], afr[2][FF];
-        auto ldf = [&](int ks, int slot) {
-            const int seg = ks * 2 + hi;
-#pragma unroll
-            for (int a = 0; a < FC; ++a) wfr[slot][a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
-#pragma unroll
-            for (int b = 0; b < FF; ++b) afr[slot][b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
-        };
-        // sched_barrier pins the order "issue the reads of k-step ks+1, THEN the MFMAs of k-step ks": left alone,
-        // hipcc shrinks the fragment registers to one set and waits on a ds_read in front of every MFMA pair
-        ldf(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            pre(ks);
-            if (ks + 1 < 4) ldf(ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < FC; ++a)
-#pragma unroll
-                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[ks & 1][a], afr[ks & 1][b], acc[a][b]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            pre(ks);
             vec8 wfr[FC], afr[FF];
             const int seg = ks * 2 + hi;
 #pragma unroll
@@ -603,10 +503,9 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #pragma unroll
                 for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
         }
-#endif
     };
 
-    if (loader) { issueA(0, 0); issueW(0, 0, 0); }
+    issueA(0, 0); issueW(0, 0, 0);
     ST_DMA_WAIT(0);
     __syncthreads();
 #if ST_STAGE_TIMING
@@ -619,26 +518,12 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) {
             const bool last = (c == nch - 1) && (j == TAPS - 1);
-#if ST_DMA_SPREAD
-            // the LDS-DMA of the next stage is issued in four slices, one per k-step, between the MFMA groups:
-            // a burst of 8 pieces at the top of the stage keeps an in-order wave out of the matrix pipe for
-            // several hundred cycles (MI355X_MICROARCH.md: 100-185 cycles per piece inside a busy phase)
-            const bool doA = (j == 0) && (c + 1 < nch);
-            const int nc = (j == TAPS - 1) ? c + 1 : c, nj = (j == TAPS - 1) ? 0 : j + 1;
-            compute(c & 1, it & 1, j, [&](int ks) {
-                if (loader && doA) issueA_slice(c + 1, (c + 1) & 1, ks);
-                if (loader && !last) issueW_slice(nc, nj, (it + 1) & 1, ks);
-            });
-#else
-            if (loader) {
-                if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
-                if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
-            }
+            if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
+            if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
 #if ST_STAGE_TIMING
             const unsigned long long tA = __builtin_amdgcn_s_memtime();
 #endif
-            compute(c & 1, it & 1, j, [](int) {});      // the DMA issued above flies underneath these MFMAs
-#endif
+            compute(c & 1, it & 1, j);      // the DMA issued above flies underneath these MFMAs
 #if ST_STAGE_TIMING
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long tB = __builtin_amdgcn_s_memtime();
@@ -760,30 +645,6 @@ __global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvG
             const int row = wf * TF + b * 32 + l31 + j;      // rows 128,129 (last two frame columns) fall into the next buffer
             arow_off[b] = row * 128; aswz[b] = (row >> 1) & 7;
         }
-#if ST_FRAG_PREFETCH
-        // fragments run two k-steps ahead of the MFMAs (two register sets), so a wave's own MFMAs cover its LDS latency
-        vec8 wfr[2][FC], afr[2][FF];
-        auto ldf = [&](int ks, int slot) {
-            const int seg = ks * 2 + hi;
-#pragma unroll
-            for (int a = 0; a < FC; ++a) wfr[slot][a] = as_vec8<P>(*(const uint4*)(Wb + wrow_off[a] + ((seg ^ wswz[a]) << 4)));
-#pragma unroll
-            for (int b = 0; b < FF; ++b) afr[slot][b] = as_vec8<P>(*(const uint4*)(Ab + arow_off[b] + ((seg ^ aswz[b]) << 4)));
-        };
-        // sched_barrier pins the order "issue the reads of k-step ks+1, THEN the MFMAs of k-step ks": left alone,
-        // hipcc shrinks the fragment registers to one set and waits on a ds_read in front of every MFMA pair
-        ldf(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) ldf(ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < FC; ++a)
-#pragma unroll
-                for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[ks & 1][a], afr[ks & 1][b], acc[a][b]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             vec8 wfr[FC], afr[FF];
@@ -797,7 +658,6 @@ __global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvG
 #pragma unroll
                 for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
         }
-#endif
     };
     // counted wait: everything except the youngest `keep` LDS-DMA instructions of this wave has landed
     auto wait_keep = [&](int keep) {
@@ -847,7 +707,7 @@ static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 + a.c1) & 63) != 0) return hipErrorInvalidValue;
+    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 | a.c1) & 63) != 0 || a.c2 != 0) return hipErrorInvalidValue;
     ConvGemmArgs b = a;
     b.tiles_f = (a.T + BF - 3) / (BF - 2);
     b.tiles_c = a.cout / BC;
@@ -873,7 +733,7 @@ static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 + a.c1) & 63) != 0) return hipErrorInvalidValue;
+    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 | a.c1 | a.c2) & 63) != 0 || (a.c2 && a.c2 > a.c0)) return hipErrorInvalidValue;
     ConvGemmArgs b = a;
     b.tiles_f = (a.T + BF - 1) / BF;
     b.tiles_c = a.cout / BC;

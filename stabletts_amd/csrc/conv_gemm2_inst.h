@@ -3,13 +3,9 @@
 #pragma once
 #include "conv_gemm2_impl.h"
 
-#ifndef ST_ACT16_4X2
-#define ST_ACT16_4X2 0
-#endif
-
 namespace st {
 
-// cfg 0: T128 (128 ch x 128 frames, 4 waves)   cfg 1: RC (256 ch x 128 frames, 8 waves, LayerNorm-capable)
+// cfg 0: T128 (128 ch x 128 frames, 4 waves)   cfg 1: RC (256 ch x 128 frames, 8 waves, LayerNorm- and QKV-capable)
 template <class P>
 static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
     if (cfg == 0) {
@@ -23,12 +19,9 @@ static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemm
         if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 256, 128, 4, 2>(a, s);
         if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 256, 128, 4, 2>(a, s);
         if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 256, 128, 4, 2>(a, s);
+        if (taps == 1 && epi == EPI_QKV) return launch_g2<P, 1, EPI_QKV, 256, 128, 4, 2>(a, s);
     } else if (cfg == 3) {   // 256 ch x 256 frames, 8 waves (2x4) of 128x64: least LDS traffic per MFMA, LayerNorm-capable
-#if ST_ACT16_4X2     // wave grid 4 (channels) x 2 (frames), wave tile 64 x 128 (A/B: tools/gemm2_bench 114 vs 116 us on FFN conv_1)
-        if (taps == 3 && epi == EPI_ACT16) return launch_g2<P, 3, EPI_ACT16, 256, 256, 4, 2>(a, s);
-#else
         if (taps == 3 && epi == EPI_ACT16) return launch_g2<P, 3, EPI_ACT16, 256, 256, 2, 4>(a, s);
-#endif
         if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 256, 256, 2, 4>(a, s);
         if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 256, 256, 2, 4>(a, s);
         if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 256, 256, 2, 4>(a, s);

@@ -20,6 +20,9 @@ namespace {
 
 std::string g_create_error;
 
+// Default of the two-part solve (see st_cfm_solve): -1 = automatic (large fixed-grid batches), 1 = never.
+constexpr int kDefaultSplit = 1;
+
 enum ProfClass {
     PC_PREP = 0, PC_PRENET, PC_INPROJ, PC_FILM_LN1, PC_QKV, PC_ATTN, PC_OPROJ, PC_LN2, PC_FFN1, PC_FFN2,
     PC_LSC, PC_FINAL, PC_ODE, PC_COUNT
@@ -39,6 +42,7 @@ struct Conv {            // packed 16-bit weights [cout][taps][cin] + fp32 bias
     void* w = nullptr;
     float* bias = nullptr;
     int cout = 0, cin = 0, taps = 0;
+    bool split = false;  // cin = 3 x the reference's: [W_hi | W_hi | W_lo] for a split-precision operand [x_hi | x_lo | x_hi]
 };
 
 struct Captured { void* dev = nullptr; int64_t n = 0; bool is16 = false; };
@@ -92,9 +96,16 @@ struct st_engine {
 
     int64_t last_nfe = 0, last_steps = 0, last_rejects = 0;   // statistics of the last solve
 
+    // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
+    // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
+    int big_min_blocks = 192;
+    int conc = 1;                       // solve parts in flight on separate streams (their launches share the chip)
+    hipStream_t s2 = nullptr;           // stream of the second solve part
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
     // HIP-graph replay of the fixed-grid solve body (ST_HIP_GRAPH=1): one instantiated graph per solve signature
     struct SolveGraph {
-        int B, T, n_steps, solver, use_cfg; float cfg_strength; const char* ws; int seen; hipGraphExec_t exec;
+        int B, T, n_steps, solver, use_cfg; float cfg_strength; const char* ws; int parts; int seen; hipGraphExec_t exec;
     };
     std::vector<SolveGraph> graphs;
     hipStream_t gstream = nullptr;      // capture stream
@@ -177,48 +188,22 @@ void build_param_table(st_engine* e) {
 
 const float* P(st_engine* e, const std::string& name) { return e->params.at(name).dev; }
 
-// ST_GEMM_GEN=1 selects the first-generation kernels + separate FiLM/LayerNorm launches (A/B, debugging)
-bool use_gen2() {
-    static int v = -1;
-    if (v < 0) { const char* s = getenv("ST_GEMM_GEN"); v = (s && atoi(s) == 1) ? 0 : 1; }
-    return v == 1;
-}
-
+// Tile configuration of one conv launch.  256x256 tiles (half the LDS traffic per MFMA of the 128-wide ones: the K
+// loop is LDS-bound) whenever the output is a multiple of 256 channels, T fills 256-frame tiles about as well as
+// 128-frame ones and the launch has enough of them for the chip (small grids would leave most CUs idle behind a
+// few long-running blocks); otherwise row-complete 256x128 tiles where the epilogue needs whole rows (fused
+// LayerNorm, QKV planes), the 3-buffer pipeline for deep k=3 convs, 128x128 tiles for the rest.
 hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
     const bool bf = e->dt == DT_BF16;
-    // fused QKV projection: 256x256 tiles with the LDS-transposed coalesced epilogue when the three planes are
-    // 256 channels each and T fills 256-frame tiles; otherwise the first-generation register epilogue
-    static const bool qkv_gen1 = [] { const char* v = getenv("ST_QKV_GEN"); return v && atoi(v) == 1; }();
-    // small grids (few utterances): 256x256 tiles would leave most CUs idle behind a few long-running blocks, so
-    // they are used only when they give at least ~3/4 of a block per CU; below that the 128-wide tiles run 2-4x
-    // as many, shorter blocks
-    // (ST_BIG_MIN_BLOCKS overrides the threshold; read per call so that tests can force either tile family)
-    const char* mb = getenv("ST_BIG_MIN_BLOCKS");
-    const bool big_fills_chip = (int64_t)a.n_items * ((a.T + 255) / 256) * (a.cout / 256) >= (mb ? atoi(mb) : 192);
-    if (use_gen2() && epi == EPI_QKV && !qkv_gen1 && a.cout == 768 && a.n_heads == 4 && big_fills_chip &&
-        ((a.T + 255) / 256) * 256 * 10 <= ((a.T + 127) / 128) * 128 * 11)
-        return bf ? launch_conv_gemm2_bf16(G2_BIG, taps, epi, a, s) : launch_conv_gemm2_f16(G2_BIG, taps, epi, a, s);
-    if (use_gen2() && epi != EPI_QKV) {
-        // 256x256 tiles (half the LDS traffic per MFMA of the 128x128 ones: the K loop is LDS-bound) whenever the
-        // output is a multiple of 256 channels and T fills 256-frame tiles about as well as 128-frame ones; otherwise
-        // row-complete 256x128 tiles where the epilogue carries a LayerNorm, the 3-buffer pipeline for deep k=3
-        // convs, 128x128 tiles for the rest.  ST_GEMM_TILE=0|1|2|3 forces a configuration where it is legal.
-        static const int force = [] { const char* v = getenv("ST_GEMM_TILE"); return v ? atoi(v) : -1; }();
-        const int T = a.T;
-        const bool fills = ((T + 255) / 256) * 256 * 10 <= ((T + 127) / 128) * 128 * 11;
-        int cfg;
-        if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = G2_BIG;
-        else if (a.ln_h16) cfg = G2_RC;
-        else if (taps == 3 && a.c0 + a.c1 >= 512) cfg = G2_K3PIPE;
-        else cfg = G2_T128;
-        if (force >= 0 && !a.ln_h16) {
-            if (force == G2_BIG && a.cout % 256 == 0) cfg = G2_BIG;
-            else if (force == G2_K3PIPE && taps == 3) cfg = G2_K3PIPE;
-            else if (force == G2_T128) cfg = G2_T128;
-        }
-        return bf ? launch_conv_gemm2_bf16(cfg, taps, epi, a, s) : launch_conv_gemm2_f16(cfg, taps, epi, a, s);
-    }
-    return bf ? launch_conv_gemm_bf16(taps, epi, a, s) : launch_conv_gemm_f16(taps, epi, a, s);
+    const int T = a.T;
+    const bool fills = ((T + 255) / 256) * 256 * 10 <= ((T + 127) / 128) * 128 * 11;
+    const bool big_fills_chip = (int64_t)e->conc * a.n_items * ((T + 255) / 256) * (a.cout / 256) >= e->big_min_blocks;
+    int cfg;
+    if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = G2_BIG;
+    else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
+    else if (taps == 3 && a.c0 + a.c1 >= 512 && a.c2 == 0) cfg = G2_K3PIPE;
+    else cfg = G2_T128;
+    return bf ? launch_conv_gemm2_bf16(cfg, taps, epi, a, s) : launch_conv_gemm2_f16(cfg, taps, epi, a, s);
 }
 
 // ---- profiling helpers -----------------------------------------------------------------------
@@ -267,34 +252,38 @@ void capture(st_engine* e, const std::string& name, const void* dev, int64_t n, 
 struct Plan {
     int B, T, Tp, N, Pn, n_t;
     bool cfg;
-    // 16-bit
-    void *mu16, *pre1, *pre2, *cond16, *x16, *h16, *q16, *k16, *vt16, *ao16, *u16, *cur16;
+    // 16-bit MFMA operands.  *lo tensors hold x - float(hi): the split-precision operand pairs of the three GEMMs
+    // whose rounding error reaches the output un-gated (in_proj x-part and cond-part, final_proj)
+    void *mu16, *pre1, *pre2, *cond16, *cond16lo, *x16, *x16lo, *h16, *q16, *k16, *vt16, *ao16, *u16, *cur16, *cur16lo;
     void* skip16[8];
     // fp32
     float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
     int *n_full, *kv_end;
     float* kbias;
     float* maskbuf;     // engine-owned copy of the caller's (B,1,T) mask: the solve body touches arena memory only
+    struct Slot { void** dst; size_t off; };
+    std::vector<Slot> slots;
 };
 
-int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
+// Lays the tensors of one solve (or solve part) out in the arena starting at byte `off`; returns the end offset.
+// Pointers become valid after ensure_ws() + bind_plan().
+size_t layout_plan(st_engine* e, int B, int T, bool cfg, int n_t, size_t off, Plan* p) {
     const int C = e->C, F = e->F, Mp = e->Mp, L = e->L;
     p->B = B; p->T = T; p->cfg = cfg; p->n_t = n_t;
     p->Tp = (T + 63) / 64 * 64;
     p->N = cfg ? 2 * B : B;
     p->Pn = cfg ? B + 1 : B;
     const size_t N = p->N, Pn = p->Pn, TT = T;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    struct Slot { void** dst; size_t off; };
-    std::vector<Slot> slots;
-    auto want = [&](void** dst, size_t bytes) { slots.push_back({dst, carve(bytes)}); };
+    p->slots.clear();
+    auto want = [&](void** dst, size_t bytes) { p->slots.push_back({dst, off}); off = align_up(off + bytes, 256); };
     want(&p->mu16, Pn * TT * Mp * 2);
     want(&p->pre1, Pn * TT * F * 2);
     want(&p->pre2, Pn * TT * F * 2);
     want(&p->cond16, Pn * TT * C * 2);
+    want(&p->cond16lo, Pn * TT * C * 2);
     want((void**)&p->cpart, Pn * TT * C * 4);
     want(&p->x16, (size_t)B * TT * Mp * 2);
+    want(&p->x16lo, (size_t)B * TT * Mp * 2);
     want((void**)&p->xstate, (size_t)B * TT * Mp * 4);
     for (int i = 0; i < 7; ++i) want((void**)&p->kbuf[i], (size_t)B * TT * Mp * 4);
     want((void**)&p->ynew, (size_t)B * TT * Mp * 4);
@@ -308,6 +297,7 @@ int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
     want(&p->ao16, N * TT * C * 2);
     want(&p->u16, N * TT * F * 2);
     want(&p->cur16, N * TT * C * 2);
+    want(&p->cur16lo, N * TT * C * 2);
     for (int i = 0; i < L / 2; ++i) want(&p->skip16[i], N * TT * C * 2);
     want((void**)&p->v32, N * TT * Mp * 4);
     want((void**)&p->tvals, (size_t)n_t * 4);
@@ -322,13 +312,26 @@ int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
     want((void**)&p->kv_end, (size_t)B * 4);
     want((void**)&p->kbias, (size_t)B * p->Tp * 4);
     want((void**)&p->maskbuf, (size_t)B * TT * 4);
-    if (off > e->ws_cap) {
-        e->drop_graphs();      // instantiated graphs hold arena pointers
-        if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
-        HIPCHK(e, hipMalloc((void**)&e->ws, off));
-        e->ws_cap = off;
-    }
-    for (auto& s : slots) *s.dst = e->ws + s.off;
+    return off;
+}
+
+int ensure_ws(st_engine* e, size_t bytes) {
+    if (bytes <= e->ws_cap) return ST_OK;
+    e->drop_graphs();      // instantiated graphs hold arena pointers
+    if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
+    HIPCHK(e, hipMalloc((void**)&e->ws, bytes));
+    e->ws_cap = bytes;
+    return ST_OK;
+}
+
+void bind_plan(st_engine* e, Plan* p) {
+    for (auto& sl : p->slots) *sl.dst = e->ws + sl.off;
+}
+
+int make_plan(st_engine* e, int B, int T, bool cfg, int n_t, Plan* p) {
+    const size_t end = layout_plan(e, B, T, cfg, n_t, 0, p);
+    int rc = ensure_ws(e, end); if (rc) return rc;
+    bind_plan(e, p);
     return ST_OK;
 }
 
@@ -346,7 +349,11 @@ int ensure_rope(st_engine* e, int T, hipStream_t s) {
             hs[(size_t)t * 16 + j] = sinf(ang);
         }
     }
-    if (e->rope_cos) { HIPCHK(e, hipDeviceSynchronize()); hipFree(e->rope_cos); hipFree(e->rope_sin); }
+    if (e->rope_cos) {
+        e->drop_graphs();      // instantiated graphs bake the old table pointers into the QKV kernel arguments
+        HIPCHK(e, hipDeviceSynchronize()); hipFree(e->rope_cos); hipFree(e->rope_sin);
+        e->rope_cos = e->rope_sin = nullptr; e->rope_T = 0;
+    }
     HIPCHK(e, hipMalloc((void**)&e->rope_cos, hc.size() * 4));
     HIPCHK(e, hipMalloc((void**)&e->rope_sin, hs.size() * 4));
     HIPCHK(e, hipMemcpy(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
@@ -367,8 +374,10 @@ ConvGemmArgs base_args(const st_engine* e, const Plan& p, const Conv& cv, int n_
     return a;
 }
 
+// FLOPs of the reference's convolution (a split-precision operand triples the MFMA work of its small GEMM, not
+// the algorithmic count)
 inline double conv_flops(const Plan& p, const Conv& cv, int n_items) {
-    return 2.0 * (double)n_items * p.T * cv.cout * cv.cin * cv.taps;
+    return 2.0 * (double)n_items * p.T * cv.cout * (cv.split ? cv.cin / 3 : cv.cin) * cv.taps;
 }
 
 // cond prenet (estimator.py:83-89,118) + the loop-invariant cond half of in_proj (:120-121)
@@ -387,14 +396,14 @@ int run_prenet(st_engine* e, const Plan& p, hipStream_t s) {
     }
     {
         ConvGemmArgs a = base_args(e, p, e->pre[2], p.Pn);
-        a.a0 = p.pre2; a.c0 = e->F; a.out16 = p.cond16;
+        a.a0 = p.pre2; a.c0 = e->F; a.out16 = p.cond16; a.out16_lo = p.cond16lo;
         ProfScope ps(e, s, PC_PRENET, conv_flops(p, e->pre[2], p.Pn));
         HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
     }
     capture(e, "cond", p.cond16, (int64_t)p.Pn * p.T * e->C, true, s);
-    {
+    {   // K = [cond_hi | cond_lo | cond_hi] against [W_hi | W_hi | W_lo]: once per solve, so the extra MFMA work is free
         ConvGemmArgs a = base_args(e, p, e->inc, p.Pn);
-        a.a0 = p.cond16; a.c0 = e->C; a.out32 = p.cpart;
+        a.a0 = p.cond16; a.c0 = e->C; a.a1 = p.cond16lo; a.c1 = e->C; a.c2 = e->C; a.out32 = p.cpart;
         ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inc, p.Pn));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
@@ -433,20 +442,14 @@ int run_time_tables(st_engine* e, const Plan& p, hipStream_t s) {
     return ST_OK;
 }
 
-// One vector-field evaluation over N items given x16 (B items), cpart, ada, film.  Output p.v32.
+// One vector-field evaluation over N items given x16/x16lo (B items), cpart, ada, film.  Output p.v32.
 // ev: index into the time tables (scalar t shared by all items) or -1 for per-item t (n_t == B).
-// With the second-generation GEMMs (default) every FiLM + LayerNorm + modulate runs inside the epilogue of
-// the GEMM that produces its input (row-complete tiles); ST_GEMM_GEN=1 keeps them as separate launches.
+// Every FiLM + LayerNorm + modulate runs inside the epilogue of the GEMM that produces its input (row-complete
+// tiles): in_proj -> LN1 of block 0, FFN conv_2 -> LN1 of the next block, long-skip conv -> LN1, out-proj -> LN2.
 int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStream_t s) {
     const int C = e->C, F = e->F, L = e->L, N = p.N, T = p.T;
     const int64_t rowsC = (int64_t)N * T * C;
     const bool cap = e->capture;
-    // ST_FUSE_LN (default 2; measured with the 256x256 row-complete tiles: 34.9 / 34.3 / 34.0 ms per solve for
-    // 0 / 1 / 2): 0 = every FiLM/LayerNorm is its own launch, 1 = fused into the long-skip convs and FFN conv_2
-    // (-> next block's LN1), 2 = fused everywhere (also in_proj and out_proj)
-    static const int fuse_env = [] { const char* v = getenv("ST_FUSE_LN"); return v ? atoi(v) : 2; }();
-    const bool fuse = use_gen2() && fuse_env >= 1;        // lsc + ffn2
-    const bool fuse_all = use_gen2() && fuse_env >= 2;    // + in_proj, out_proj
     auto ada_of = [&](int i) { return p.ada + (size_t)i * N * 6 * C; };
     // FiLM_i + LN1_i + modulate (start of block i) fused into the producing GEMM
     auto fuse_ln1 = [&](ConvGemmArgs& a, int i) {
@@ -456,32 +459,18 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         a.ln_ada = ada_of(i); a.ln_ada_stride = 6 * C; a.ln_shift_off = 0; a.ln_scale_off = C;
         a.ln_mask_out = 0; a.ln_h16 = p.h16; a.mask = mask;
     };
-    auto film_ln1 = [&](int i) -> int {      // separate launch (first-generation path)
-        FilmLnArgs a; memset(&a, 0, sizeof(a));
-        a.X = p.X; a.h16 = p.h16;
-        const float* fb = p.film + (size_t)i * p.n_t * 2 * C;
-        if (ev >= 0) { a.film = fb + (size_t)ev * 2 * C; a.film_stride = 0; a.film_mod = 1; }
-        else         { a.film = fb; a.film_stride = 2 * C; a.film_mod = p.B; }
-        a.ada = ada_of(i); a.ada_stride = 6 * C; a.shift_off = 0; a.scale_off = C;
-        a.mask = mask; a.mask_mod = p.B; a.mask_out = 0; a.T = T; a.rows = N * T;
-        ProfScope ps(e, s, PC_FILM_LN1, 0);
-        HIPCHK(e, launch_film_ln(e->dt, a, s));
-        return ST_OK;
-    };
-    int rc;
-    {   // in_proj: X = Wx.x + (Wc.cond + b); also the first long-skip (estimator.py:120-121,129)
+    {   // in_proj: X = Wx.x + (Wc.cond + b); also the first long-skip (estimator.py:120-121,129).  The fp32 ODE state
+        // enters as the operand pair (x_hi, x_lo): K = [x_hi | x_lo | x_hi] against [W_hi | W_hi | W_lo]
         ConvGemmArgs a = base_args(e, p, e->inx, N);
-        a.a0 = p.x16; a.c0 = e->Mp; a.a0_mod = p.B; a.bias = nullptr;
+        a.a0 = p.x16; a.c0 = e->Mp; a.a0_mod = p.B; a.a1 = p.x16lo; a.c1 = e->Mp; a.a1_mod = p.B; a.c2 = e->Mp;
+        a.bias = nullptr;
         a.add32 = p.cpart; a.add_clamp = p.B;
         a.out32 = p.X; a.out16 = p.skip16[0];
-        if (fuse_all) fuse_ln1(a, 0);
+        fuse_ln1(a, 0);
         ProfScope ps(e, s, PC_INPROJ, conv_flops(p, e->inx, N));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
-    if (cap) {
-        if (fuse_all) capture(e, "h0", p.skip16[0], rowsC, true, s);
-        else capture(e, "h0", p.X, rowsC, false, s);
-    }
+    if (cap) capture(e, "h0", p.skip16[0], rowsC, true, s);
     for (int i = 0; i < L; ++i) {
         const std::string bn = "b" + std::to_string(i) + ".";
         const float* ada_i = ada_of(i);
@@ -490,12 +479,10 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             ConvGemmArgs a = base_args(e, p, e->lsc[j], N);
             a.a0 = p.cur16; a.c0 = C; a.a1 = p.skip16[L - 1 - i]; a.c1 = C;
             a.out32 = p.X;
-            if (fuse) fuse_ln1(a, i);
+            fuse_ln1(a, i);
             ProfScope ps(e, s, PC_LSC, conv_flops(p, e->lsc[j], N));
             HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
-            if (cap && !fuse) capture(e, "lsc" + std::to_string(j), p.X, rowsC, false, s);
         }
-        if (!((i == 0) ? fuse_all : fuse) && (rc = film_ln1(i))) return rc;      // FiLM, mask, LN1, modulate
         if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
         {   // q, k, v projections + RoPE (diffusion_transformer.py:59-61,74-75)
             ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
@@ -518,26 +505,15 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
         if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
-        {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111) [+ LN2, modulate, mask]
+        {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111) + LN2, modulate, mask (:112,26)
             ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
-            if (fuse_all) {
-                a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
-                a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
-            }
+            a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
+            a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
-        if (cap) capture(e, bn + "x2", p.X, rowsC, false, s);
-        if (!fuse_all) {   // LN2 + modulate, masked (FFN input, diffusion_transformer.py:112,26)
-            FilmLnArgs a; memset(&a, 0, sizeof(a));
-            a.X = p.X; a.h16 = p.h16; a.film = nullptr; a.film_mod = 1;
-            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
-            a.mask = mask; a.mask_mod = p.B; a.mask_out = 1; a.T = T; a.rows = N * T;
-            ProfScope ps(e, s, PC_LN2, 0);
-            HIPCHK(e, launch_film_ln(e->dt, a, s));
-        }
-        if (cap) capture(e, bn + "h2", p.h16, rowsC, true, s);
+        if (cap) { capture(e, bn + "x2", p.X, rowsC, false, s); capture(e, bn + "h2", p.h16, rowsC, true, s); }
         {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
             ConvGemmArgs a = base_args(e, p, e->ffn1[i], N);
             a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
@@ -550,18 +526,19 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
             a.out16 = copy16;
-            if (fuse && i + 1 < L / 2) fuse_ln1(a, i + 1);     // blocks >= L/2 start with the long-skip conv instead
+            if (i + 1 == L) a.out16_lo = p.cur16lo;        // operand pair of final_proj
+            if (i + 1 < L / 2) fuse_ln1(a, i + 1);         // blocks >= L/2 start with the long-skip conv instead
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
             HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }
         if (cap) {
-            if (fuse && i + 1 < L / 2) capture(e, bn + "x3", copy16, rowsC, true, s);   // X already holds the FiLM'd value
+            if (i + 1 < L / 2) capture(e, bn + "x3", copy16, rowsC, true, s);   // X already holds the FiLM'd value
             else capture(e, bn + "x3", p.X, rowsC, false, s);
         }
     }
     {   // final projection (estimator.py:136-138); block output is already zero on padded frames
         ConvGemmArgs a = base_args(e, p, e->fin, N);
-        a.a0 = p.cur16; a.c0 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
+        a.a0 = p.cur16; a.c0 = C; a.a1 = p.cur16lo; a.c1 = C; a.c2 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
         ProfScope ps(e, s, PC_FINAL, conv_flops(p, e->fin, N));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
@@ -577,7 +554,6 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
     const int C = e->C, F = e->F, L = e->L, N = p.N, T = p.T;
     const int64_t rowsC = (int64_t)N * T * C;
     const bool cap = e->capture;
-    const bool fuse = use_gen2();
     auto ada_of = [&](int i) { return p.ada + (size_t)i * N * 6 * C; };
     auto ln_launch = [&](int i, int shift_off, int scale_off, int mask_out, int cls) -> int {
         FilmLnArgs a; memset(&a, 0, sizeof(a));
@@ -592,7 +568,7 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
     for (int i = 0; i < L; ++i) {
         const std::string bn = "b" + std::to_string(i) + ".";
         const float* ada_i = ada_of(i);
-        if ((i == 0 || !fuse) && (rc = ln_launch(i, 0, C, 0, PC_FILM_LN1))) return rc;     // LN1 + modulate
+        if (i == 0 && (rc = ln_launch(i, 0, C, 0, PC_FILM_LN1))) return rc;     // LN1 + modulate (later blocks: fused)
         if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
         {
             ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
@@ -614,15 +590,12 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
         {
             ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
-            if (fuse) {
-                a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
-                a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
-            }
+            a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;       // + LN2, modulate, mask
+            a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
         if (cap) capture(e, bn + "x2", p.X, rowsC, false, s);
-        if (!fuse && (rc = ln_launch(i, 3 * C, 4 * C, 1, PC_LN2))) return rc;              // LN2 + modulate, masked
         {
             ConvGemmArgs a = base_args(e, p, e->ffn1[i], N);
             a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
@@ -633,7 +606,7 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
             ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
             a.out16 = p.cur16;
-            if (fuse && i + 1 < L) {      // LN1 + modulate of block i+1 (no FiLM, not masked)
+            if (i + 1 < L) {      // LN1 + modulate of block i+1 (no FiLM, not masked)
                 a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
                 a.ln_ada = ada_of(i + 1); a.ln_ada_stride = 6 * C; a.ln_shift_off = 0; a.ln_scale_off = C; a.ln_mask_out = 0;
             }
@@ -715,7 +688,7 @@ int solve_adaptive(st_engine* e, const Plan& p, const float* mask, int use_cfg, 
         int r = run_time_tables(e, p, s); if (r) return r;
         r = run_estimator(e, p, mask, 0, s); if (r) return r;
         ProfScope ps(e, s, PC_ODE, 0);
-        HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, kout, nullptr, nullptr, 0.f, s));
+        HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, kout, nullptr, nullptr, nullptr, 0.f, s));
         e->last_nfe += 1;
         return ST_OK;
     };
@@ -740,7 +713,7 @@ int solve_adaptive(st_engine* e, const Plan& p, const float* mask, int use_cfg, 
     const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     {
         const float* ks[1] = {k[0]}; const float cf[1] = {(float)h0};
-        HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, 1, nstate, nullptr, p.x16, s));
+        HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, 1, nstate, nullptr, p.x16, p.x16lo, s));
     }
     if ((rc = eval(0.0 + h0, k[1]))) return rc;
     memset(&na, 0, sizeof(na));
@@ -758,7 +731,7 @@ int solve_adaptive(st_engine* e, const Plan& p, const float* mask, int use_cfg, 
             {
                 ProfScope ps(e, s, PC_ODE, 0);
                 // with an FSAL tableau (c_sol[:-1] == beta[-1], c_sol[-1] == 0) the last stage input IS y1
-                HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, (fsal && i == S - 1) ? y1 : nullptr, p.x16, s));
+                HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, (fsal && i == S - 1) ? y1 : nullptr, p.x16, p.x16lo, s));
             }
             const double ti = (tb.alpha[i] == 1.0) ? t1 : t + tb.alpha[i] * dt;
             if ((rc = eval(ti, k[i + 1]))) return rc;
@@ -767,7 +740,7 @@ int solve_adaptive(st_engine* e, const Plan& p, const float* mask, int use_cfg, 
             const float* ks[7]; float cf[7]; int nk = 0;
             for (int j = 0; j <= S; ++j) if (tb.csol[j] != 0.0) { ks[nk] = k[j]; cf[nk] = (float)(tb.csol[j] * dt); ++nk; }
             ProfScope ps(e, s, PC_ODE, 0);
-            HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, y1, p.x16, s));
+            HIPCHK(e, launch_lincomb(e->dt, y, ks, cf, nk, nstate, y1, p.x16, p.x16lo, s));
         }
         // error estimate from the stage derivatives
         memset(&na, 0, sizeof(na));
@@ -864,6 +837,7 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     e->C = cfg->hidden_channels; e->F = cfg->filter_channels; e->H = cfg->n_heads; e->L = cfg->n_layers;
     e->K = cfg->kernel_size; e->G = cfg->gin_channels;
     e->kind = kind; e->n_vocab = n_vocab;
+    if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
     build_param_table(e);
     if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
         g_create_error = "hipMalloc failed";
@@ -886,6 +860,9 @@ void st_destroy(st_engine* e) {
     hipDeviceSynchronize();
     e->drop_graphs();
     if (e->gstream) hipStreamDestroy(e->gstream);
+    if (e->s2) hipStreamDestroy(e->s2);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
     for (auto& kv : e->params) if (kv.second.dev) hipFree(kv.second.dev);
     for (void* p : e->owned) hipFree(p);
     for (auto& kv : e->caps) if (kv.second.dev) hipFree(kv.second.dev);
@@ -939,14 +916,17 @@ int st_finalize(st_engine* e) {
     e->owned.clear(); e->weight_bytes = 0;
     const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
     hipStream_t s = nullptr;
-    // generic packer: (cout, cin_total, taps) source slice -> Conv with padded dims
+    // generic packer: (cout, cin_total, taps) source slice -> Conv with padded dims.  split: the packed K dimension
+    // is [W_hi | W_hi | W_lo] (W_lo = W - float(W_hi)), the weight side of a split-precision operand
     auto pack = [&](Conv& cv, const std::string& wname, const float* bias_src, int cout, int cout_p, int cin_total,
-                    int taps, int ci_off, int ci_cnt, int cin_p) -> int {
-        cv.cout = cout_p; cv.cin = cin_p; cv.taps = taps;
-        const size_t wbytes = (size_t)cout_p * taps * cin_p * 2;
+                    int taps, int ci_off, int ci_cnt, int cin_p, bool split) -> int {
+        cv.cout = cout_p; cv.cin = split ? 3 * cin_p : cin_p; cv.taps = taps; cv.split = split;
+        const size_t wbytes = (size_t)cout_p * taps * cv.cin * 2;
         int rc = dev_alloc(e, &cv.w, wbytes); if (rc) return rc;
         HIPCHK(e, hipMemsetAsync(cv.w, 0, wbytes, s));
-        HIPCHK(e, launch_pack_weight(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cin_p, s));
+        for (int part = 0; part < (split ? 3 : 1); ++part)
+            HIPCHK(e, launch_pack_weight(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cv.cin,
+                                         part * cin_p, cin_p, part == 2, s));
         rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4); if (rc) return rc;
         HIPCHK(e, hipMemsetAsync(cv.bias, 0, (size_t)cout_p * 4, s));
         if (bias_src) HIPCHK(e, hipMemcpyAsync(cv.bias, bias_src, (size_t)cout * 4, hipMemcpyDeviceToDevice, s));
@@ -954,20 +934,21 @@ int st_finalize(st_engine* e) {
     };
     int rc;
     if (e->kind == 1) {
-        if ((rc = pack(e->fin, "proj.weight", P(e, "proj.bias"), M, Mp, C, 1, 0, C, C))) return rc;
+        if ((rc = pack(e->fin, "proj.weight", P(e, "proj.bias"), M, Mp, C, 1, 0, C, C, false))) return rc;
     } else {
     e->pre.assign(3, Conv());
-    if ((rc = pack(e->pre[0], "cond_proj.0.weight", P(e, "cond_proj.0.bias"), F, F, M, K, 0, M, Mp))) return rc;
-    if ((rc = pack(e->pre[1], "cond_proj.2.weight", P(e, "cond_proj.2.bias"), F, F, F, K, 0, F, F))) return rc;
-    if ((rc = pack(e->pre[2], "cond_proj.4.weight", P(e, "cond_proj.4.bias"), C, C, F, K, 0, F, F))) return rc;
-    // in_proj input channel order [x(M) ; cond(C)] (estimator.py:120)
-    if ((rc = pack(e->inx, "in_proj.weight", nullptr, C, C, C + M, 1, 0, M, Mp))) return rc;
-    if ((rc = pack(e->inc, "in_proj.weight", P(e, "in_proj.bias"), C, C, C + M, 1, M, C, C))) return rc;
-    if ((rc = pack(e->fin, "final_proj.weight", P(e, "final_proj.bias"), M, Mp, C, 1, 0, C, C))) return rc;
+    if ((rc = pack(e->pre[0], "cond_proj.0.weight", P(e, "cond_proj.0.bias"), F, F, M, K, 0, M, Mp, false))) return rc;
+    if ((rc = pack(e->pre[1], "cond_proj.2.weight", P(e, "cond_proj.2.bias"), F, F, F, K, 0, F, F, false))) return rc;
+    if ((rc = pack(e->pre[2], "cond_proj.4.weight", P(e, "cond_proj.4.bias"), C, C, F, K, 0, F, F, false))) return rc;
+    // in_proj input channel order [x(M) ; cond(C)] (estimator.py:120); both halves and final_proj take
+    // split-precision operands: their rounding error reaches the estimator output without a gate in between
+    if ((rc = pack(e->inx, "in_proj.weight", nullptr, C, C, C + M, 1, 0, M, Mp, true))) return rc;
+    if ((rc = pack(e->inc, "in_proj.weight", P(e, "in_proj.bias"), C, C, C + M, 1, M, C, C, true))) return rc;
+    if ((rc = pack(e->fin, "final_proj.weight", P(e, "final_proj.bias"), M, Mp, C, 1, 0, C, C, true))) return rc;
     e->lsc.assign(L / 2, Conv());
     for (int i = 0; i < L / 2; ++i) {
         const std::string n = "lsc_layers." + std::to_string(i);
-        if ((rc = pack(e->lsc[i], n + ".weight", P(e, n + ".bias"), C, C, 2 * C, K, 0, 2 * C, 2 * C))) return rc;
+        if ((rc = pack(e->lsc[i], n + ".weight", P(e, n + ".bias"), C, C, 2 * C, K, 0, 2 * C, 2 * C, false))) return rc;
     }
     }
     e->qkv.assign(L, Conv()); e->oproj.assign(L, Conv()); e->ffn1.assign(L, Conv()); e->ffn2.assign(L, Conv());
@@ -980,13 +961,13 @@ int st_finalize(st_engine* e) {
         int r = 0;
         for (const char* nm : {"q", "k", "v"}) {
             const std::string n = b + "attn.conv_" + nm;
-            HIPCHK(e, launch_pack_weight(e->dt, P(e, n + ".weight"), C, C, 1, 0, C, q.w, r * C, C, s));
+            HIPCHK(e, launch_pack_weight(e->dt, P(e, n + ".weight"), C, C, 1, 0, C, q.w, r * C, C, 0, C, false, s));
             HIPCHK(e, hipMemcpyAsync(q.bias + (size_t)r * C, P(e, n + ".bias"), (size_t)C * 4, hipMemcpyDeviceToDevice, s));
             ++r;
         }
-        if ((rc = pack(e->oproj[i], b + "attn.conv_o.weight", P(e, b + "attn.conv_o.bias"), C, C, C, 1, 0, C, C))) return rc;
-        if ((rc = pack(e->ffn1[i], b + "mlp.conv_1.weight", P(e, b + "mlp.conv_1.bias"), F, F, C, K, 0, C, C))) return rc;
-        if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F))) return rc;
+        if ((rc = pack(e->oproj[i], b + "attn.conv_o.weight", P(e, b + "attn.conv_o.bias"), C, C, C, 1, 0, C, C, false))) return rc;
+        if ((rc = pack(e->ffn1[i], b + "mlp.conv_1.weight", P(e, b + "mlp.conv_1.bias"), F, F, C, K, 0, C, C, false))) return rc;
+        if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F, false))) return rc;
     }
     HIPCHK(e, hipDeviceSynchronize());
     e->finalized = true;
@@ -1007,8 +988,8 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
     {
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
-        HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
-        HIPCHK(e, launch_to_time_major(e->dt, x, B, e->M, T, e->Mp, nullptr, p.x16, s));
+        HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, nullptr, s));
+        HIPCHK(e, launch_to_time_major(e->dt, x, B, e->M, T, e->Mp, nullptr, p.x16, p.x16lo, s));
         HIPCHK(e, hipMemcpyAsync(p.cvec, c, (size_t)B * e->G * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(e, hipMemcpyAsync(p.tvals, t, (size_t)t_len * 4, hipMemcpyDeviceToDevice, s));
     }
@@ -1042,9 +1023,40 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                              : solver == ST_SOLVER_ADAPTIVE_HEUN ? kAdaptiveHeun : kDopri5;
     const int stages = solver == ST_SOLVER_EULER ? 1 : (solver == ST_SOLVER_MIDPOINT ? 2 : 4);
     const int n_t = adaptive ? 1 : n_steps * stages;
-    Plan p;
-    if ((rc = make_plan(e, B, T, use_cfg != 0, n_t, &p))) return rc;
+
+    // Utterances are independent ODE solves.  A large fixed-grid batch is solved as TWO parts (utterances
+    // [0, B/2) and [B/2, B)) on two streams: every kernel of this path alternates an MFMA-bound K loop with an
+    // HBM-bound epilogue, and with one launch at a time all CUs sit in the same phase (1 block per CU, lock step).
+    // Two half-size launch sequences, started one evaluation apart, put different kernels / phases on the chip at
+    // the same time, so the matrix pipes of one part's blocks run under the other part's epilogues.  Results are
+    // bitwise independent of the split (an utterance never shares a tile with another).  Adaptive solvers keep ONE
+    // part: their step controller takes the error norm over the whole batch.  ST_SPLIT=0|1|2 overrides (read per call).
+    int nparts = 1;
+    {
+        const char* sv = getenv("ST_SPLIT");
+        const int want = sv ? atoi(sv) : kDefaultSplit;
+        const int64_t frames = (int64_t)(use_cfg ? 2 : 1) * B * T;
+        if (!adaptive && !e->capture && B >= 2 && (want == 2 || (want != 0 && want != 1 && frames >= 24000 && B >= 8))) nparts = 2;
+        if (want == 1 || want == 0) nparts = 1;
+    }
+    struct Part { Plan p; int b0, nb; hipStream_t s; const float* mask; };
+    std::vector<Part> parts((size_t)nparts);
+    {
+        size_t off = 0;
+        for (int k = 0; k < nparts; ++k) {
+            parts[k].b0 = (int)((int64_t)B * k / nparts);
+            parts[k].nb = (int)((int64_t)B * (k + 1) / nparts) - parts[k].b0;
+            off = layout_plan(e, parts[k].nb, T, use_cfg != 0, n_t, off, &parts[k].p);
+        }
+        if ((rc = ensure_ws(e, off))) return rc;
+        for (auto& pt : parts) bind_plan(e, &pt.p);
+    }
     if ((rc = ensure_rope(e, T, s))) return rc;
+    if (nparts > 1 && !e->s2) {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
 
     // evaluation times, fp32 arithmetic as torchdiffeq does on the fp32 t_span (flow_matching.py:46)
     const std::vector<float> grid = linspace01(n_steps);
@@ -1057,75 +1069,101 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         else { tv[4 * i] = t0; tv[4 * i + 1] = t0 + dt / 3.0f; tv[4 * i + 2] = t0 + dt * 2.0f / 3.0f; tv[4 * i + 3] = t1; }
     }
     const int64_t per_item = (int64_t)T * e->Mp;
-    const int64_t nstate = (int64_t)B * per_item;
-    {
+    const int64_t bct = (int64_t)e->M * T;        // elements per utterance of a (B, n_feats, T) boundary tensor
+    for (auto& pt : parts) {      // boundary conversions (caller's layouts -> engine operands), on the caller's stream
+        const Plan& p = pt.p;
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, launch_set_values(p.tvals, tv.data(), (int)tv.size(), s));   // by kernel argument: no copy, no sync
-        HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
-        HIPCHK(e, launch_cvec_prep(mask, nullptr, B, T, p.maskbuf, s));      // plain copy of the (B,1,T) mask
-        mask = p.maskbuf;
-        HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, s));
-        HIPCHK(e, launch_to_time_major(e->dt, z, B, e->M, T, e->Mp, p.xstate, p.x16, s));
-        HIPCHK(e, launch_cvec_prep(c, use_cfg ? fake_speaker : nullptr, B, e->G, p.cvec, s));
+        HIPCHK(e, launch_mask_prep(mask + (int64_t)pt.b0 * T, pt.nb, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
+        HIPCHK(e, launch_cvec_prep(mask + (int64_t)pt.b0 * T, nullptr, pt.nb, T, p.maskbuf, s));      // plain copy of the (B,1,T) mask
+        pt.mask = p.maskbuf;
+        HIPCHK(e, launch_to_time_major(e->dt, mu + pt.b0 * bct, pt.nb, e->M, T, e->Mp, nullptr, p.mu16, nullptr, s));
+        HIPCHK(e, launch_to_time_major(e->dt, z + pt.b0 * bct, pt.nb, e->M, T, e->Mp, p.xstate, p.x16, p.x16lo, s));
+        HIPCHK(e, launch_cvec_prep(c + (int64_t)pt.b0 * e->G, use_cfg ? fake_speaker : nullptr, pt.nb, e->G, p.cvec, s));
         if (use_cfg) {
             // uncond branch inputs (flow_matching.py:59-60): fake_content over ALL frames, fake_speaker per item
             HIPCHK(e, launch_fill_rows16(e->dt, fake_content, e->M, e->Mp, T,
-                                         (char*)p.mu16 + (size_t)B * per_item * 2, s));
+                                         (char*)p.mu16 + (size_t)pt.nb * per_item * 2, s));
         }
     }
     e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive ? 0 : n_steps; e->last_rejects = 0;
 
-    // Everything between the boundary conversions above and below touches engine memory only, so for the fixed-grid
-    // solvers it is a static launch sequence: `body` enqueues it, either directly or once into a HIP graph.
-    auto body = [&](hipStream_t s) -> int {      // (the parameter shadows the caller's stream on purpose)
-    int rc;
-    if ((rc = run_prenet(e, p, s))) return rc;
-    if ((rc = run_adaln(e, p, s))) return rc;
-    if (!adaptive && (rc = run_time_tables(e, p, s))) return rc;
-    if (adaptive) {
-        if ((rc = solve_adaptive(e, p, mask, use_cfg, cfg_strength, tableau, s))) return rc;
-    } else
-    for (int i = 0; i < n_steps; ++i) {
+    // One solver step of one part (fixed grid): estimator evaluation(s) + state update.
+    auto step_fixed = [&](const Part& pt, int i, hipStream_t ps_) -> int {
+        const Plan& p = pt.p;
+        const int Bp = pt.nb;
+        const int64_t nstate = (int64_t)Bp * per_item;
         const float dt = dts[i];
+        int rc;
         if (solver == ST_SOLVER_EULER) {
-            if ((rc = run_estimator(e, p, mask, i, s))) return rc;
-            ProfScope ps(e, s, PC_ODE, 0);
-            HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, nullptr, p.xstate, p.x16, dt, s));
+            if ((rc = run_estimator(e, p, pt.mask, i, ps_))) return rc;
+            ProfScope ps(e, ps_, PC_ODE, 0);
+            HIPCHK(e, launch_cfg_combine(e->dt, p.v32, Bp, per_item, use_cfg, cfg_strength, nullptr, p.xstate, p.x16, p.x16lo, dt, ps_));
         } else if (solver == ST_SOLVER_MIDPOINT) {
-            if ((rc = run_estimator(e, p, mask, 2 * i, s))) return rc;
+            if ((rc = run_estimator(e, p, pt.mask, 2 * i, ps_))) return rc;
             {
-                ProfScope ps(e, s, PC_ODE, 0);
-                HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, p.kbuf[0], nullptr, nullptr, 0.f, s));
+                ProfScope ps(e, ps_, PC_ODE, 0);
+                HIPCHK(e, launch_cfg_combine(e->dt, p.v32, Bp, per_item, use_cfg, cfg_strength, p.kbuf[0], nullptr, nullptr, nullptr, 0.f, ps_));
                 const float* ks[1] = {p.kbuf[0]}; const float cf[1] = {0.5f * dt};
-                HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 1, nstate, nullptr, p.x16, s));
+                HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 1, nstate, nullptr, p.x16, p.x16lo, ps_));
             }
-            if ((rc = run_estimator(e, p, mask, 2 * i + 1, s))) return rc;
-            ProfScope ps(e, s, PC_ODE, 0);
-            HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, nullptr, p.xstate, p.x16, dt, s));
+            if ((rc = run_estimator(e, p, pt.mask, 2 * i + 1, ps_))) return rc;
+            ProfScope ps(e, ps_, PC_ODE, 0);
+            HIPCHK(e, launch_cfg_combine(e->dt, p.v32, Bp, per_item, use_cfg, cfg_strength, nullptr, p.xstate, p.x16, p.x16lo, dt, ps_));
         } else {   // rk4 = torchdiffeq's 3/8 rule
             for (int st = 0; st < 4; ++st) {
-                if ((rc = run_estimator(e, p, mask, 4 * i + st, s))) return rc;
-                ProfScope ps(e, s, PC_ODE, 0);
-                HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, p.kbuf[st], nullptr, nullptr, 0.f, s));
+                if ((rc = run_estimator(e, p, pt.mask, 4 * i + st, ps_))) return rc;
+                ProfScope ps(e, ps_, PC_ODE, 0);
+                HIPCHK(e, launch_cfg_combine(e->dt, p.v32, Bp, per_item, use_cfg, cfg_strength, p.kbuf[st], nullptr, nullptr, nullptr, 0.f, ps_));
                 if (st == 0) {
                     const float* ks[1] = {p.kbuf[0]}; const float cf[1] = {dt / 3.0f};
-                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 1, nstate, nullptr, p.x16, s));
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 1, nstate, nullptr, p.x16, p.x16lo, ps_));
                 } else if (st == 1) {
                     const float* ks[2] = {p.kbuf[1], p.kbuf[0]}; const float cf[2] = {dt, -dt / 3.0f};
-                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 2, nstate, nullptr, p.x16, s));
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 2, nstate, nullptr, p.x16, p.x16lo, ps_));
                 } else if (st == 2) {
                     const float* ks[3] = {p.kbuf[0], p.kbuf[1], p.kbuf[2]}; const float cf[3] = {dt, -dt, dt};
-                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 3, nstate, nullptr, p.x16, s));
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 3, nstate, nullptr, p.x16, p.x16lo, ps_));
                 } else {
                     const float* ks[4] = {p.kbuf[0], p.kbuf[1], p.kbuf[2], p.kbuf[3]};
                     const float cf[4] = {dt * 0.125f, dt * 0.375f, dt * 0.375f, dt * 0.125f};
-                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 4, nstate, p.xstate, p.x16, s));
+                    HIPCHK(e, launch_lincomb(e->dt, p.xstate, ks, cf, 4, nstate, p.xstate, p.x16, p.x16lo, ps_));
                 }
             }
         }
-    }
-    return ST_OK;
-    };   // body
+        return ST_OK;
+    };
+
+    // Everything between the boundary conversions above and below touches engine memory only, so for the fixed-grid
+    // solvers it is a static launch sequence: `body` enqueues it, either directly or once into a HIP graph.  With two
+    // parts the second one runs on the engine's second stream (forked from / joined back into `cs` with events) and
+    // the host interleaves the parts step by step, so part 1 trails part 0 by about one evaluation's enqueue time.
+    auto body = [&](hipStream_t cs) -> int {
+        int rc;
+        e->conc = nparts;
+        if (nparts > 1) {
+            HIPCHK(e, hipEventRecord(e->ev_fork, cs));
+            HIPCHK(e, hipStreamWaitEvent(e->s2, e->ev_fork, 0));
+        }
+        for (int k = 0; k < nparts; ++k) parts[k].s = k == 0 ? cs : e->s2;
+        for (auto& pt : parts) {
+            if ((rc = run_prenet(e, pt.p, pt.s))) return rc;
+            if ((rc = run_adaln(e, pt.p, pt.s))) return rc;
+            if (!adaptive && (rc = run_time_tables(e, pt.p, pt.s))) return rc;
+        }
+        if (adaptive) {
+            if ((rc = solve_adaptive(e, parts[0].p, parts[0].mask, use_cfg, cfg_strength, tableau, cs))) return rc;
+        } else {
+            for (int i = 0; i < n_steps; ++i)
+                for (auto& pt : parts)
+                    if ((rc = step_fixed(pt, i, pt.s))) return rc;
+        }
+        if (nparts > 1) {
+            HIPCHK(e, hipEventRecord(e->ev_join, e->s2));
+            HIPCHK(e, hipStreamWaitEvent(cs, e->ev_join, 0));
+        }
+        return ST_OK;
+    };
 
     // ST_HIP_GRAPH=1 (read per call): the fixed-grid solve body (~45 launches per evaluation) is captured into a HIP
     // graph the second time a solve signature is seen (the first run is eager: it also performs the one-time
@@ -1134,14 +1172,15 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     const char* genv = getenv("ST_HIP_GRAPH");
     const bool want_graph = genv && atoi(genv) == 1 && !adaptive && !e->prof && !e->capture;
     bool done = false;
+    int brc = ST_OK;
     if (want_graph) {
         st_engine::SolveGraph* g = nullptr;
         for (auto& q : e->graphs)
             if (q.B == B && q.T == T && q.n_steps == n_steps && q.solver == solver && q.use_cfg == (use_cfg != 0) &&
-                q.cfg_strength == cfg_strength && q.ws == e->ws) g = &q;
+                q.cfg_strength == cfg_strength && q.ws == e->ws && q.parts == nparts) g = &q;
         if (!g) {
             if (e->graphs.size() >= 16) e->drop_graphs();
-            e->graphs.push_back({B, T, n_steps, solver, use_cfg != 0, cfg_strength, e->ws, 0, nullptr});
+            e->graphs.push_back({B, T, n_steps, solver, use_cfg != 0, cfg_strength, e->ws, nparts, 0, nullptr});
             g = &e->graphs.back();
         }
         if (g->seen >= 1 && !g->exec) {
@@ -1150,8 +1189,9 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
             if (!e->gstream) HIPCHK(e, hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
             hipGraph_t graph = nullptr;
             HIPCHK(e, hipStreamBeginCapture(e->gstream, hipStreamCaptureModeRelaxed));
-            const int brc = body(e->gstream);
+            brc = body(e->gstream);
             const hipError_t ec = hipStreamEndCapture(e->gstream, &graph);
+            e->conc = 1;
             if (brc) { if (graph) hipGraphDestroy(graph); return brc; }
             if (ec != hipSuccess || !graph) return e->fail(ST_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
             const hipError_t ei = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
@@ -1161,10 +1201,10 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         g->seen += 1;
         if (g->exec) { HIPCHK(e, hipGraphLaunch(g->exec, s)); done = true; }
     }
-    if (!done && (rc = body(s))) return rc;
-    {
+    if (!done) { brc = body(s); e->conc = 1; if (brc) return brc; }
+    for (auto& pt : parts) {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_from_time_major(adaptive ? p.ynew : p.xstate, B, e->M, T, e->Mp, out, s));
+        HIPCHK(e, launch_from_time_major(adaptive ? pt.p.ynew : pt.p.xstate, pt.nb, e->M, T, e->Mp, out + pt.b0 * bct, s));
     }
     return ST_OK;
 }

@@ -17,6 +17,8 @@ enum { GF_SILU = 1, GF_MASK = 2 };
 struct ConvGemmArgs {
     const void* a0; const void* a1;   // activation sources [items][T][c0], [items][T][c1]
     int c0, c1;                       // channels per source (multiples of 64; c1 may be 0)
+    int c2;                           // further K channels that re-read a0 from its channel 0 (split-precision operands:
+                                      // K = [a0 | a1 | a0] against packed weights [W_hi | W_hi | W_lo]); gen-2 kernels only
     int a0_mod, a1_mod;               // activation item of output item n is n % mod
     const void* w;                    // packed weights [cout][TAPS][c0 + c1], 16-bit
     const float* bias;                // [cout] or nullptr
@@ -25,6 +27,7 @@ struct ConvGemmArgs {
     const float* mask; int mask_mod;  // [mask_mod][T] float 0/1, item n -> n % mask_mod
     int flags;                        // GF_*
     void* out16; float* out32;        // [items][T][cout]
+    void* out16_lo;                   // optional (with out16, fp32-staged epilogues): 16-bit residual x - float(out16)
     const float* add32; int add_clamp;  // EPI_F32: + add32[min(n, add_clamp)][t][ch]
     const float* gate; int gate_stride; // EPI_RESGATE: out32 += gate[n*gate_stride + ch]*((acc+b)*mask)
     // EPI_QKV (cout = 3*C, head_dim 64): q,k -> [item][H][T][64], vT -> [item][H][64][Tp]
@@ -41,10 +44,8 @@ struct ConvGemmArgs {
     unsigned long long* dbg;          // diagnostics (ST_STAGE_TIMING builds of tools/gemm2_bench only), else nullptr
 };
 
-hipError_t launch_conv_gemm_bf16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
-hipError_t launch_conv_gemm_f16(int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
-// second generation (conv_gemm2_impl.h): cfg 0 = 128x128 tile, cfg 1 = row-complete 256x128 tile (cout % 256 == 0,
-// may carry the fused FiLM + LayerNorm + modulate of the next op through the ln_* fields)
+// tile configurations (conv_gemm2_impl.h): T128 = 128x128 tile, RC = row-complete 256x128 tile (cout % 256 == 0,
+// may carry the fused FiLM + LayerNorm + modulate of the next op through the ln_* fields; also the QKV epilogue)
 enum { G2_T128 = 0, G2_RC = 1, G2_K3PIPE = 2,   // K3PIPE: k=3 only, three weight buffers, counted vmcnt
        G2_BIG = 3 };                             // 256 x 256 tile, 8 waves of 128 x 64 (cout % 256 == 0)
 hipError_t launch_conv_gemm2_bf16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
@@ -82,9 +83,10 @@ hipError_t launch_linear(const float* in, int n, int k, const float* W, const fl
                          float* out, int silu_in, int silu_out, hipStream_t s);
 hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, hipStream_t s);
 
-// (B, C, T) fp32 -> time-major (B, T, Cp): fp32 and/or 16-bit, channels >= C zero-filled; scale applied
+// (B, C, T) fp32 -> time-major (B, T, Cp): fp32 and/or 16-bit (+ optional 16-bit rounding residual out16lo),
+// channels >= C zero-filled
 hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T, int Cp,
-                                float* out32, void* out16, hipStream_t s);
+                                float* out32, void* out16, void* out16lo, hipStream_t s);
 // time-major (B, T, Cp) fp32 -> (B, C, T) fp32
 hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s);
 // dst16[t][c] = vec[c] for all t (uncond prenet input: fake_content broadcast, flow_matching.py:60)
@@ -95,17 +97,19 @@ hipError_t launch_cvec_prep(const float* c, const float* fake_or_null, int B, in
 hipError_t launch_fill_rows16(int dtype, const float* vec, int C, int Cp, int T, void* out16, hipStream_t s);
 
 // v: [N2][T][Cp] estimator outputs. If use_cfg: vv = v[B+b] + s*(v[b] - v[B+b]) else vv = v[b].
-// kout (optional) = vv ; if xio: xio += dt*vv and x16 = xio (Euler step fused).
+// kout (optional) = vv ; if xio: xio += dt*vv and (x16, x16lo) = split-precision operand pair of xio (Euler step fused).
 hipError_t launch_cfg_combine(int dtype, const float* v, int B, int64_t per_item, int use_cfg, float s,
-                              float* kout, float* xio, void* x16, float dt, hipStream_t stream);
-// y = x + sum_i coef[i]*k[i] (i < nk <= 7); writes y32 and/or y16
+                              float* kout, float* xio, void* x16, void* x16lo, float dt, hipStream_t stream);
+// y = x + sum_i coef[i]*k[i] (i < nk <= 7); writes y32 and/or the operand pair (y16, y16lo)
 hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, const float* coef, int nk,
-                          int64_t n, float* y32, void* y16, hipStream_t s);
+                          int64_t n, float* y32, void* y16, void* y16lo, hipStream_t s);
 
-// weight packing: src fp32 (cout, cin_total, K) -> dst16 [cout_p][K][cin_p] taking source channels
-// [ci_off, ci_off + ci_cnt); everything else zero.  dst row offset `row_off` (QKV concat).
+// weight packing: src fp32 (cout, cin_total, K) -> dst16 [cout_p][K][cin_p], columns [col_off, col_off + slice_w):
+// source channels [ci_off, ci_off + ci_cnt) then zeros.  dst row offset `row_off` (QKV concat).  lo != 0 packs the
+// rounding residual W - float(to16(W)) instead of W (split-precision weights).
 hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_total, int K, int ci_off,
-                              int ci_cnt, void* dst, int row_off, int cin_p, hipStream_t s);
+                              int ci_cnt, void* dst, int row_off, int cin_p, int col_off, int slice_w, int lo,
+                              hipStream_t s);
 hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- adaptive dopri5 support (adaptive_ode.hip)

@@ -134,7 +134,7 @@ hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full
 // boundary layout changes: (B, C, T) <-> time-major (B, T, Cp), 32x32 tiles through LDS
 template <class P>
 __global__ __launch_bounds__(256) void to_time_major_kernel(const float* in, int C, int T, int Cp,
-                                                            float* out32, typename P::elem* out16) {
+                                                            float* out32, typename P::elem* out16, typename P::elem* out16lo) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -154,17 +154,18 @@ __global__ __launch_bounds__(256) void to_time_major_kernel(const float* in, int
             const size_t o = ((size_t)b * T + t) * Cp + c;
             if (out32) out32[o] = v;
             if (out16) out16[o] = to16<P>(v);
+            if (out16lo) out16lo[o] = to16<P>(v - (float)to16<P>(v));
         }
     }
 }
 
 hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T, int Cp,
-                                float* out32, void* out16, hipStream_t s) {
+                                float* out32, void* out16, void* out16lo, hipStream_t s) {
     dim3 grid((T + 31) / 32, (Cp + 31) / 32, B);
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL((to_time_major_kernel<OpBF16>), grid, dim3(256), 0, s, in, C, T, Cp, out32, (__bf16*)out16);
+        hipLaunchKernelGGL((to_time_major_kernel<OpBF16>), grid, dim3(256), 0, s, in, C, T, Cp, out32, (__bf16*)out16, (__bf16*)out16lo);
     else
-        hipLaunchKernelGGL((to_time_major_kernel<OpF16>), grid, dim3(256), 0, s, in, C, T, Cp, out32, (_Float16*)out16);
+        hipLaunchKernelGGL((to_time_major_kernel<OpF16>), grid, dim3(256), 0, s, in, C, T, Cp, out32, (_Float16*)out16, (_Float16*)out16lo);
     return hipGetLastError();
 }
 
@@ -270,11 +271,18 @@ hipError_t launch_embed_tokens(const long long* tokens, const long long* lengths
     return hipGetLastError();
 }
 
+// rounding residual of a 4-vector against its 16-bit image: the "lo" half of a split-precision MFMA operand
+template <class P>
+__device__ __forceinline__ uint2 pack4_lo(float a, float b, float c, float d) {
+    return pack4<P>(a - (float)to16<P>(a), b - (float)to16<P>(b), c - (float)to16<P>(c), d - (float)to16<P>(d));
+}
+
 // ------------------------------------------------------------------------------------------
 // CFG combine (flow_matching.py:66) + optional fused Euler update (torchdiffeq euler step)
 template <class P>
 __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* v, int64_t half, int use_cfg, float s,
-                                                          float* kout, float* xio, typename P::elem* x16, float dt) {
+                                                          float* kout, float* xio, typename P::elem* x16,
+                                                          typename P::elem* x16lo, float dt) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= half) return;
     float4 vc = *(const float4*)(v + i);
@@ -289,22 +297,23 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* v, int64_
         x.x += dt * vc.x; x.y += dt * vc.y; x.z += dt * vc.z; x.w += dt * vc.w;
         *(float4*)(xio + i) = x;
         if (x16) *(uint2*)(x16 + i) = pack4<P>(x.x, x.y, x.z, x.w);
+        if (x16lo) *(uint2*)(x16lo + i) = pack4_lo<P>(x.x, x.y, x.z, x.w);
     }
 }
 
 hipError_t launch_cfg_combine(int dtype, const float* v, int B, int64_t per_item, int use_cfg, float s,
-                              float* kout, float* xio, void* x16, float dt, hipStream_t stream) {
+                              float* kout, float* xio, void* x16, void* x16lo, float dt, hipStream_t stream) {
     const int64_t half = (int64_t)B * per_item;   // multiple of 4
     const int grid = (int)((half / 4 + 255) / 256);
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL((cfg_combine_kernel<OpBF16>), dim3(grid), dim3(256), 0, stream, v, half, use_cfg, s, kout, xio, (__bf16*)x16, dt);
+        hipLaunchKernelGGL((cfg_combine_kernel<OpBF16>), dim3(grid), dim3(256), 0, stream, v, half, use_cfg, s, kout, xio, (__bf16*)x16, (__bf16*)x16lo, dt);
     else
-        hipLaunchKernelGGL((cfg_combine_kernel<OpF16>), dim3(grid), dim3(256), 0, stream, v, half, use_cfg, s, kout, xio, (_Float16*)x16, dt);
+        hipLaunchKernelGGL((cfg_combine_kernel<OpF16>), dim3(grid), dim3(256), 0, stream, v, half, use_cfg, s, kout, xio, (_Float16*)x16, (_Float16*)x16lo, dt);
     return hipGetLastError();
 }
 
 constexpr int kMaxComb = 7;   // dopri5 has 7 stage derivatives
-struct LinCombArgs { const float* x; const float* k[kMaxComb]; float coef[kMaxComb]; int nk; int64_t n; float* y32; void* y16; };
+struct LinCombArgs { const float* x; const float* k[kMaxComb]; float coef[kMaxComb]; int nk; int64_t n; float* y32; void* y16; void* y16lo; };
 
 template <class P>
 __global__ __launch_bounds__(256) void lincomb_kernel(const LinCombArgs a) {
@@ -321,12 +330,13 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinCombArgs a) {
     }
     if (a.y32) *(float4*)(a.y32 + i) = y;
     if (a.y16) *(uint2*)((typename P::elem*)a.y16 + i) = pack4<P>(y.x, y.y, y.z, y.w);
+    if (a.y16lo) *(uint2*)((typename P::elem*)a.y16lo + i) = pack4_lo<P>(y.x, y.y, y.z, y.w);
 }
 
 hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, const float* coef, int nk,
-                          int64_t n, float* y32, void* y16, hipStream_t s) {
+                          int64_t n, float* y32, void* y16, void* y16lo, hipStream_t s) {
     LinCombArgs a;
-    a.x = x; a.nk = nk; a.n = n; a.y32 = y32; a.y16 = y16;
+    a.x = x; a.nk = nk; a.n = n; a.y32 = y32; a.y16 = y16; a.y16lo = y16lo;
     for (int j = 0; j < kMaxComb; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.coef[j] = j < nk ? coef[j] : 0.f; }
     const int grid = (int)((n / 4 + 255) / 256);
     if (dtype == DT_BF16) hipLaunchKernelGGL((lincomb_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, a);
@@ -335,29 +345,31 @@ hipError_t launch_lincomb(int dtype, const float* x, const float* const* k, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// weight packing: (cout, cin_total, K) fp32 -> [row_off + co][K][cin_p] 16-bit
+// weight packing: (cout, cin_total, K) fp32 -> [row_off + co][K][cin_p] 16-bit, columns [col_off, col_off + slice_w)
 template <class P>
 __global__ void pack_weight_kernel(const float* src, int cout, int cin_total, int K, int ci_off, int ci_cnt,
-                                   typename P::elem* dst, int row_off, int cin_p) {
+                                   typename P::elem* dst, int row_off, int cin_p, int col_off, int slice_w, int lo) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)cout * K * cin_p;
+    const size_t total = (size_t)cout * K * slice_w;
     if (idx >= total) return;
-    const int ci = (int)(idx % cin_p);
-    const int j = (int)((idx / cin_p) % K);
-    const int co = (int)(idx / ((size_t)cin_p * K));
+    const int ci = (int)(idx % slice_w);
+    const int j = (int)((idx / slice_w) % K);
+    const int co = (int)(idx / ((size_t)slice_w * K));
     float v = 0.f;
     if (ci < ci_cnt) v = src[((size_t)co * cin_total + ci_off + ci) * K + j];
-    dst[((size_t)(row_off + co) * K + j) * cin_p + ci] = to16<P>(v);
+    if (lo) v -= (float)to16<P>(v);
+    dst[((size_t)(row_off + co) * K + j) * cin_p + col_off + ci] = to16<P>(v);
 }
 
 hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_total, int K, int ci_off,
-                              int ci_cnt, void* dst, int row_off, int cin_p, hipStream_t s) {
-    const size_t total = (size_t)cout * K * cin_p;
+                              int ci_cnt, void* dst, int row_off, int cin_p, int col_off, int slice_w, int lo,
+                              hipStream_t s) {
+    const size_t total = (size_t)cout * K * slice_w;
     const int grid = (int)((total + 255) / 256);
     if (dtype == DT_BF16)
-        hipLaunchKernelGGL((pack_weight_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (__bf16*)dst, row_off, cin_p);
+        hipLaunchKernelGGL((pack_weight_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (__bf16*)dst, row_off, cin_p, col_off, slice_w, lo);
     else
-        hipLaunchKernelGGL((pack_weight_kernel<OpF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (_Float16*)dst, row_off, cin_p);
+        hipLaunchKernelGGL((pack_weight_kernel<OpF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (_Float16*)dst, row_off, cin_p, col_off, slice_w, lo);
     return hipGetLastError();
 }
 

@@ -78,7 +78,9 @@ class Decoder(nn.Module):
     """Same constructor as the reference Decoder (models/estimator.py:66); forward is native.
 
     forward(t, x, mask, mu, c) -> (B, out_channels, T): one vector-field evaluation
-    (models/estimator.py:103-138), inference only (no autograd graph is recorded).
+    (models/estimator.py:103-138).  Under torch.no_grad()/inference_mode it is the plain native launch sequence;
+    when gradients are required it goes through stabletts_amd/autograd.py (native forward that keeps the
+    activations + native backward), so DDP / AdamW see ordinary parameter gradients.
     """
 
     def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels,
@@ -126,6 +128,24 @@ class Decoder(nn.Module):
         return st
 
     # ------------------------------------------------------------------ native engine plumbing
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def sync_weights(self):
+        """Force the engine to re-read the parameters at the next call.  Needed only after writes that bypass
+        autograd's version counter (``p.data.copy_(ema)``, ``m.weight.data.normal_()``, as some EMA / weight-swap
+        utilities do); in-place ops on the parameters themselves, optimizer steps, ``load_state_dict`` and
+        ``.to()`` are detected automatically."""
+        self._engine_key = None
+
+    def _apply(self, fn, *a, **k):            # .to() / .cuda() / .half(): storage changes
+        self._engine_key = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._engine_key = None
+        return super()._load_from_state_dict(*a, **k)
+
     def engine(self):
         """The st_engine bound to the device of the parameters, with weights in sync."""
         p0 = next(self.parameters())
@@ -139,7 +159,7 @@ class Decoder(nn.Module):
             self._engine = _lib.Engine(self.noise_channels, self.hidden_channels, self.filter_channels, self.n_heads,
                                        self.n_layers, self.kernel_size, self.gin_channels, self.operand_dtype, dev)
             self._engine_key = None
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = self._param_key()
         if key != self._engine_key:
             with torch.no_grad():
                 torch.cuda.synchronize(dev)
@@ -147,23 +167,37 @@ class Decoder(nn.Module):
             self._engine_key = key
         return self._engine
 
-    @staticmethod
-    def _prep(t, dev):
-        return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    def device(self):
+        return next(self.parameters()).device
 
-    @torch.no_grad()
+    def _prep(self, t, dev=None, name="input"):
+        """fp32 contiguous view of a caller tensor ON THE ENGINE'S DEVICE.  Like the reference modules, a tensor on
+        another device is an error (raw pointers cross the C ABI: a CPU tensor would otherwise fault the GPU)."""
+        dev = self.device() if dev is None else dev
+        if t.device != dev:
+            raise ValueError(f"{name} is on {t.device}, the estimator's parameters are on {dev}")
+        return t.detach().to(dtype=torch.float32).contiguous()
+
     def forward(self, t, x, mask, mu, c):
-        eng = self.engine()
-        dev = x.device
-        B, M, T = x.shape
-        t = self._prep(t.reshape(-1) if torch.is_tensor(t) else torch.tensor([float(t)]), dev)
-        if t.numel() not in (1, B):
-            raise ValueError("t must be a scalar or have one entry per batch item")
-        x, mu, c = self._prep(x, dev), self._prep(mu, dev), self._prep(c, dev)
-        mask = self._prep(mask, dev)
-        if mu.shape != x.shape or mask.shape != (B, 1, T) or c.shape != (B, self.gin_channels):
-            raise ValueError("shape mismatch: x/mu (B,M,T), mask (B,1,T), c (B,gin)")
-        out = torch.empty_like(x)
-        with torch.cuda.device(dev):
-            eng.estimator_forward(t, x, mu, mask, c, out, torch.cuda.current_stream(dev).cuda_stream)
-        return out
+        dev = self.device()
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or any(
+            torch.is_tensor(v) and v.requires_grad for v in (x, mu, c)))
+        if needs_grad:
+            from .autograd import estimator_apply
+            return estimator_apply(self, t, x, mask, mu, c)
+        with torch.no_grad():
+            eng = self.engine()
+            B, M, T = x.shape
+            if not torch.is_tensor(t):
+                t = torch.tensor([float(t)], device=dev)
+            t = self._prep(t.reshape(-1), dev, "t")
+            if t.numel() not in (1, B):
+                raise ValueError("t must be a scalar or have one entry per batch item")
+            x, mu, c = self._prep(x, dev, "x"), self._prep(mu, dev, "mu"), self._prep(c, dev, "c")
+            mask = self._prep(mask, dev, "mask")
+            if mu.shape != x.shape or mask.shape != (B, 1, T) or c.shape != (B, self.gin_channels):
+                raise ValueError("shape mismatch: x/mu (B,M,T), mask (B,1,T), c (B,gin)")
+            out = torch.empty_like(x)
+            with torch.cuda.device(dev):
+                eng.estimator_forward(t, x, mu, mask, c, out, torch.cuda.current_stream(dev).cuda_stream)
+            return out

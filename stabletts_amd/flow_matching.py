@@ -46,24 +46,24 @@ class CFMDecoder(nn.Module):
         if c is None:
             raise ValueError("c (speaker embedding, (B, gin_channels)) is required")
         eng = self.estimator.engine()
-        dev = mu.device
+        dev = self.estimator.device()
         prep = self.estimator._prep
-        mu = prep(mu, dev)
+        mu = prep(mu, dev, "mu")
         B, M, T = mu.shape
-        mask = prep(mask, dev)
-        c = prep(c, dev)
+        mask = prep(mask, dev, "mask")
+        c = prep(c, dev, "c")
         if z is None:
             z = torch.randn_like(mu) * temperature
         else:
-            z = prep(z, dev) * temperature
+            z = prep(z, dev, "z") * temperature
         if mask.shape != (B, 1, T) or z.shape != mu.shape or c.shape != (B, self.gin_channels):
             raise ValueError("shape mismatch: mu/z (B,M,T), mask (B,1,T), c (B,gin)")
         use_cfg = cfg_kwargs is not None
         fs = fc = None
         strength = 0.0
         if use_cfg:
-            fs = prep(cfg_kwargs["fake_speaker"], dev).reshape(-1)
-            fc = prep(cfg_kwargs["fake_content"], dev).reshape(-1)
+            fs = prep(cfg_kwargs["fake_speaker"], dev, "fake_speaker").reshape(-1)
+            fc = prep(cfg_kwargs["fake_content"], dev, "fake_content").reshape(-1)
             strength = float(cfg_kwargs["cfg_strength"])
             if fs.numel() != self.gin_channels or fc.numel() != M:
                 raise ValueError("fake_speaker must be (1, gin) and fake_content (1, n_feats, 1)")
@@ -111,16 +111,13 @@ class CFMDecoder(nn.Module):
     def compute_loss(self, x1, mask, mu, c, t_rand=None, z=None):
         """models/flow_matching.py:69-100: CFM training loss and the interpolant ``y``.
 
-        The forward arithmetic is native: cosine-warped per-item ``t``, ``y = (1-(1-sigma)t) z + t x1``,
-        ``u = x1 - (1-sigma) z`` (elementwise torch ops on the device), ONE native estimator evaluation with a
-        per-item ``t`` (st_estimator_forward, t_len = B) and the masked-sum MSE -- including the reference's quirk
-        that ``u`` is not masked (:99).  The result carries NO autograd graph: the backward kernels are not built
-        yet, so this serves validation / parity, and calling it while gradients are required
-        raises instead of silently training nothing.  ``t_rand`` (B,1,1) and ``z`` may be passed to fix the draws.
+        Cosine-warped per-item ``t``, ``y = (1-(1-sigma)t) z + t x1``, ``u = x1 - (1-sigma) z`` (elementwise torch ops
+        on the device), ONE native estimator evaluation with a per-item ``t`` (t_len = B) and the masked-sum MSE --
+        including the reference's quirk that ``u`` is not masked (:99).  With autograd enabled the estimator call goes
+        through ``stabletts_amd.autograd`` (native forward + native backward), so ``loss.backward()`` fills
+        ``.grad`` of every estimator parameter and of ``mu`` / ``c`` exactly like the reference module does (DDP
+        hooks fire as usual).  ``t_rand`` (B,1,1) and ``z`` may be passed to fix the draws.
         """
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.estimator.parameters()):
-            raise NotImplementedError("compute_loss: native backward kernels are not implemented yet; call it under "
-                                      "torch.no_grad() for the (native) forward value, see DESIGN.md 'what comes next'")
         b = mu.shape[0]
         if t_rand is None:
             t_rand = torch.rand([b, 1, 1], device=mu.device, dtype=mu.dtype)

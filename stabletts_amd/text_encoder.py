@@ -45,6 +45,18 @@ class TextEncoder(nn.Module):
         st["_engine_key"] = None
         return st
 
+    def sync_weights(self):
+        """Force a weight re-upload at the next call (after writes through ``p.data`` that bypass the version counter)."""
+        self._engine_key = None
+
+    def _apply(self, fn, *a, **k):
+        self._engine_key = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._engine_key = None
+        return super()._load_from_state_dict(*a, **k)
+
     def engine(self):
         """The native handle bound to the device of the parameters, with weights in sync."""
         p0 = next(self.parameters())
@@ -67,12 +79,23 @@ class TextEncoder(nn.Module):
             self._engine_key = key
         return self._engine
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor, c: torch.Tensor, x_lengths: torch.Tensor):
         """x: (B, T) phoneme ids, c: (B, gin) speaker vectors, x_lengths: (B,) ->
         (x (B, hidden, T), mu_x (B, out, T), x_mask (B, 1, T)) exactly as models/text_encoder.py:34-44."""
+        if self.emb.weight.device.type != "cuda":
+            self.engine()      # raises: no CPU fallback
+        if torch.is_grad_enabled() and (c.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("the native TextEncoder is inference-only (no backward kernels): call it under "
+                                      "torch.no_grad(), or train with the reference module and load its checkpoint")
+        with torch.no_grad():
+            return self._forward(x, c, x_lengths)
+
+    def _forward(self, x, c, x_lengths):
         eng = self.engine()
         dev = self.emb.weight.device
+        for name, t in (("x", x), ("c", c), ("x_lengths", x_lengths)):
+            if t.device != dev:
+                raise ValueError(f"{name} is on {t.device}, the encoder's parameters are on {dev}")
         if x.dim() != 2 or c.shape != (x.shape[0], self.gin_channels) or x_lengths.shape != (x.shape[0],):
             raise ValueError("shape mismatch: x (B,T) ids, c (B,gin), x_lengths (B,)")
         B, T = x.shape

@@ -23,6 +23,20 @@ _limit_torch_threads()
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "grad: the test needs autograd enabled (training path)")
+
+
+@pytest.fixture(autouse=True)
+def _inference_by_default(request):
+    """The reference's inference entry points run under torch.inference_mode (models/model.py:59, flow_matching.py:24);
+    parity tests therefore run with autograd off unless they are marked ``grad`` (with autograd on, a module whose
+    parameters require grad takes the training path: native forward that keeps activations + native backward)."""
+    import torch
+    if request.node.get_closest_marker("grad") or not request.node.get_closest_marker("gpu"):
+        yield
+    else:
+        with torch.no_grad():
+            yield
 
 
 @pytest.fixture(scope="session")

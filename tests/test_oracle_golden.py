@@ -162,3 +162,86 @@ def test_oracle_gradients_match_reference_fixture(sd, golden):
             assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 1e-9, key
     for got, want in ((mu.grad.numpy(), g["grad_mu"]), (c.grad.numpy(), g["grad_c"])):
         assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+
+
+def _order_conditions(b, c, A, order, theta=1.0):
+    """Residuals of the Runge-Kutta order conditions up to ``order`` (<= 4) for weights b (at abscissa theta),
+    nodes c and stage matrix A: a method y(t + theta h) = y + h sum b_i k_i of that order satisfies all of them."""
+    import numpy as np
+    b, c, A = (np.asarray(v, dtype=np.float64) for v in (b, c, A))
+    res = [b.sum() - theta]
+    if order >= 2:
+        res.append(b @ c - theta ** 2 / 2)
+    if order >= 3:
+        res += [b @ c ** 2 - theta ** 3 / 3, b @ (A @ c) - theta ** 3 / 6]
+    if order >= 4:
+        res += [b @ c ** 3 - theta ** 4 / 4, (b * c) @ (A @ c) - theta ** 4 / 8, b @ (A @ c ** 2) - theta ** 4 / 12,
+                b @ (A @ (A @ c)) - theta ** 4 / 24]
+    return np.abs(np.array(res)).max()
+
+
+def test_adaptive_tableaus_pinned_against_scipy_and_order_conditions():
+    """torchdiffeq is absent offline, so its adaptive tableaus (oracle.ADAPTIVE_TABLEAUS, restated from the published
+    algorithm) are pinned against an independent implementation and against the algebra that defines them:
+      * nodes, stage matrix and propagating weights of dopri5 / bosh3 == scipy.integrate RK45 / RK23 (Dormand-Prince
+        5(4), Bogacki-Shampine 3(2)); bosh3's error weights == -RK23.E;
+      * the embedded lower-order weights (c_sol - c_error) of every pair satisfy the order conditions of order
+        (order - 1); dopri5's are the Shampine (ode45) variant torchdiffeq uses, which differs from scipy's
+        Dormand-Prince b* by design, so they are pinned by the order conditions instead;
+      * the dense-output midpoint weights c_mid (torchdiffeq DPS_C_MID) satisfy the order conditions at theta = 1/2
+        (order 4 for dopri5; the half-step Euler/stage value for the low-order pairs);
+      * FSAL structure: dopri5 / bosh3's last stage row equals c_sol."""
+    import numpy as np
+    from scipy.integrate._ivp import rk
+    import oracle
+    for name, ref in (("dopri5", rk.RK45), ("bosh3", rk.RK23)):
+        alpha, beta, c_sol, c_err, c_mid, order = oracle.ADAPTIVE_TABLEAUS[name]
+        n = len(alpha)                        # stages after k0
+        A = np.zeros((n + 1, n + 1))
+        for i, row in enumerate(beta):
+            A[i + 1, :len(row)] = row
+        c = np.array([0.0] + list(alpha))
+        ns = ref.n_stages
+        assert np.abs(c[:ns] - ref.C).max() < 1e-15
+        assert np.abs(A[:ns, :ns - 1] - ref.A[:, :ns - 1]).max() < 1e-15
+        assert np.abs(np.array(c_sol[:ns]) - ref.B).max() < 1e-15 and c_sol[ns] == 0.0
+        assert np.abs(A[ns, :ns] - ref.B).max() < 1e-15               # FSAL: last stage input is y1
+        assert ref.order == order
+        if name == "bosh3":
+            assert np.abs(np.array(c_err) + ref.E).max() < 1e-15
+    for name, (alpha, beta, c_sol, c_err, c_mid, order) in oracle.ADAPTIVE_TABLEAUS.items():
+        n = len(alpha)
+        A = np.zeros((n + 1, n + 1))
+        for i, row in enumerate(beta):
+            A[i + 1, :len(row)] = row
+        c = np.array([0.0] + list(alpha))
+        assert _order_conditions(c_sol, c, A, min(order, 4)) < 1e-14, name
+        emb = np.array(c_sol) - np.array(c_err)
+        assert _order_conditions(emb, c, A, min(order - 1, 4)) < 1e-14, name
+        assert abs(sum(c_err)) < 1e-15, name
+        mid_order = 4 if name == "dopri5" else 1
+        assert _order_conditions(c_mid, c, A, mid_order, theta=0.5) < 1e-12, name
+    # dopri5 propagating weights are 5th order: the additional order-5 quadrature condition
+    alpha, beta, c_sol, *_ = oracle.ADAPTIVE_TABLEAUS["dopri5"]
+    c = np.array([0.0] + list(alpha))
+    assert abs(np.array(c_sol) @ c ** 4 - 1 / 5) < 1e-15
+
+
+def test_fixed_grid_rules_have_their_classical_order():
+    """euler / midpoint / rk4 (3/8 rule) of oracle.odeint_fixed, written as Butcher tableaus, satisfy the order
+    conditions of order 1 / 2 / 4 -- and the rk4 one is the 3/8 rule torchdiffeq uses (rk4_alt_step_func), checked on
+    y' = y where one step must equal the degree-4 Taylor polynomial."""
+    import math
+    import numpy as np
+    import torch
+    import oracle
+    A38 = np.array([[0, 0, 0, 0], [1 / 3, 0, 0, 0], [-1 / 3, 1, 0, 0], [1, -1, 1, 0]], dtype=np.float64)
+    assert _order_conditions([1 / 8, 3 / 8, 3 / 8, 1 / 8], [0, 1 / 3, 2 / 3, 1], A38, 4) < 1e-15
+    assert _order_conditions([0, 1], [0, 1 / 2], np.array([[0, 0], [1 / 2, 0]]), 2) < 1e-15
+    h = 0.25
+    t_span = torch.tensor([0.0, h], dtype=torch.float64)
+    y0 = torch.ones(3, dtype=torch.float64)
+    for method, deg in (("euler", 1), ("midpoint", 2), ("rk4", 4)):
+        y = oracle.odeint_fixed(lambda t, y: y, y0, t_span, method)
+        taylor = sum(h ** k / math.factorial(k) for k in range(deg + 1))
+        assert abs(float(y[0]) - taylor) < 1e-14, method
