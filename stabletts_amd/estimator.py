@@ -189,8 +189,8 @@ class Decoder(nn.Module):
             eng = self.engine()
             B, M, T = x.shape
             if not torch.is_tensor(t):
-                t = torch.tensor([float(t)], device=dev)
-            t = self._prep(t.reshape(-1), dev, "t")
+                t = torch.tensor([float(t)])
+            t = self._prep(t.reshape(-1).to(dev), dev, "t")      # the time is a scalar (or B scalars): host values are fine
             if t.numel() not in (1, B):
                 raise ValueError("t must be a scalar or have one entry per batch item")
             x, mu, c = self._prep(x, dev, "x"), self._prep(mu, dev, "mu"), self._prep(c, dev, "c")

@@ -1,0 +1,123 @@
+"""Engine behaviour on a real MI355X that is not numerics-vs-oracle: solve-part splitting, HIP-graph replay across
+table reallocations, weight synchronisation, device checks, and the multi-process utterance-sharded path
+(2 ranks sharing the one visible GPU).  Run with ``-m gpu``."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import oracle
+from oracle.inputs import make_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dec(sd):
+    from stabletts_amd.flow_matching import CFMDecoder
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="bf16")
+    d.estimator.load_state_dict(sd)
+    return d.to("cuda:0")
+
+
+def _kw(cfg_params, s):
+    fs, fc = cfg_params
+    return dict(fake_speaker=fs.cuda(), fake_content=fc.cuda(), cfg_strength=s)
+
+
+def _solve(d, inp, n, solver, kw):
+    return d(inp["mu"].cuda(), inp["mask"].cuda(), n, 1.0, inp["c"].cuda(), solver, kw, z=inp["z"].cuda()).cpu()
+
+
+@pytest.mark.parametrize("solver,n,cfg", [("euler", 4, 3.0), ("rk4", 2, None), ("midpoint", 3, 2.0)])
+def test_two_part_solve_is_bitwise_identical(dec, cfg_params, monkeypatch, solver, n, cfg):
+    """ST_SPLIT=2: the batch is solved as two parts on two streams (MFMA-bound kernels of one part overlap the
+    HBM-bound epilogues of the other).  Utterances never share a tile, so every output must equal the one-part
+    solve bit for bit -- odd batch sizes, ragged lengths, with and without CFG, eager and graph replay."""
+    kw = _kw(cfg_params, cfg) if cfg is not None else None
+    for B, T, lengths in ((5, 200, [200, 133, 64, 200, 7]), (2, 70, [70, 51])):
+        inp = make_inputs(B, T, seed=80 + B, lengths=lengths)
+        monkeypatch.setenv("ST_SPLIT", "1")
+        one = _solve(dec, inp, n, solver, kw)
+        monkeypatch.setenv("ST_SPLIT", "2")
+        two = _solve(dec, inp, n, solver, kw)
+        assert torch.equal(one, two)
+        monkeypatch.setenv("ST_HIP_GRAPH", "1")
+        for _ in range(3):                      # eager, capture, replay
+            assert torch.equal(_solve(dec, inp, n, solver, kw), one)
+        monkeypatch.delenv("ST_HIP_GRAPH")
+
+
+def test_graph_replay_survives_rope_table_growth(dec, cfg_params, monkeypatch):
+    """the RoPE tables are reallocated when T grows; instantiated graphs that baked the old pointers
+    into the QKV kernel arguments must be dropped.  Sequence: capture a graph at T=200, then a longer-T solve with a
+    smaller batch (workspace does not grow, tables do), then replay the first signature."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="bf16")
+    d.estimator.load_state_dict(dec.estimator.state_dict())
+    d = d.cuda()                                 # fresh engine: rope_T starts at 0
+    kw = _kw(cfg_params, 2.0)
+    a = make_inputs(8, 200, seed=90, lengths=[200, 190, 180, 170, 160, 150, 140, 130])
+    b = make_inputs(1, 500, seed=91)
+    monkeypatch.delenv("ST_HIP_GRAPH", raising=False)
+    ref_a, ref_b = _solve(d, a, 3, "euler", kw), None
+    monkeypatch.setenv("ST_HIP_GRAPH", "1")
+    for _ in range(3):
+        assert torch.equal(_solve(d, a, 3, "euler", kw), ref_a)       # eager, capture, replay (rope_T = 256)
+    ref_b = _solve(d, b, 3, "euler", kw)                              # T=500 -> tables reallocated
+    for _ in range(3):
+        assert torch.equal(_solve(d, a, 3, "euler", kw), ref_a)       # must not replay a graph with dangling pointers
+    assert torch.equal(_solve(d, b, 3, "euler", kw), ref_b)
+
+
+def test_inputs_on_the_wrong_device_raise(dec):
+    inp = make_inputs(2, 16, seed=1)
+    with pytest.raises(ValueError, match="is on cpu"):
+        dec(inp["mu"], inp["mask"].cuda(), 2, 1.0, inp["c"].cuda(), "euler")
+    with pytest.raises(ValueError, match="is on cpu"):
+        dec.estimator(torch.tensor(0.1).cuda(), inp["z"].cuda(), inp["mask"], inp["mu"].cuda(), inp["c"].cuda())
+
+
+def test_sync_weights_after_data_writes(sd):
+    """Writes through ``p.data`` do not bump the version counter (EMA / weight-swap utilities): sync_weights()."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+    d.estimator.load_state_dict(sd)
+    d = d.cuda()
+    inp = make_inputs(1, 32, seed=2)
+    args = (torch.tensor(0.2).cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+    a = d.estimator(*args)
+    d.estimator.final_proj.bias.data.add_(1.0)          # invisible to the version counter
+    d.estimator.sync_weights()
+    b = d.estimator(*args)
+    assert float((b - a).mean()) == pytest.approx(1.0, abs=1e-3)
+    d.estimator.load_state_dict(sd)                      # load_state_dict is picked up without sync_weights()
+    c = d.estimator(*args)
+    assert torch.equal(c, a)
+
+
+def test_two_ranks_sharing_one_gpu_equal_single_process(tmp_path):
+    """SURVEY section 4 item 6 / BASELINE config 4 in miniature: 2 processes (torch.distributed.run, gloo for the
+    bookkeeping, BENCH_SHARE_GPU=1 so both use the one visible GPU) shard 12 ragged utterances with
+    sharding.assign_batches, solve their batches natively, and rank 0 gathers; the result must be bitwise equal to one
+    process solving the same batches.  No data-path collective is involved."""
+    out = tmp_path / "shard.pt"
+    env = dict(os.environ, BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "shard_solve.py"), "--out", str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shard_solve.py"), "--out", str(tmp_path / "one.pt")],
+                        env=dict(os.environ), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    want = torch.load(tmp_path / "one.pt")
+    assert got["world"] == 2 and want["world"] == 1
+    assert sorted(got["mel"]) == sorted(want["mel"]) == list(range(12))
+    for i in range(12):
+        assert torch.equal(got["mel"][i], want["mel"][i]), i
+    assert got["imbalance"][0] < 1.5

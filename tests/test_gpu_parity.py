@@ -1,12 +1,15 @@
 """Parity of the native gfx950 path (through the C ABI / ctypes shim) against the oracle and the
 committed reference fixtures.  Needs a real MI355X: run with ``-m gpu``.
 
-Tolerances (max |native - ref| / max |ref| over the whole tensor, fixed noise):
-  * full ODE solve, final mel: 1e-3 for BOTH operand types -- the bar BASELINE.json's north_star states;
-  * one vector-field evaluation: bf16 operands 1e-2, f16 operands 1.5e-3 (16-bit MFMA operands with
-    fp32 accumulation vs the fp32 reference; measured 4.5e-3 / 5.6e-4);
-  * stricter "displacement" metric max|native - ref| / max|ref - z| for solves: bf16 1.5e-2, f16 2e-3
-    (the mel itself is dominated by the noise z at random weights, so this is the honest signal).
+Gates (fixed noise, max over the whole tensor):
+  * one vector-field evaluation: max|v - v_ref| / max|v_ref|;
+  * full ODE solve: the DISPLACEMENT metric max|out - ref| / max|ref - z| -- what the decoder actually computes.
+    (max|out - ref| / max|ref| is also asserted, but at random weights the mel is ~95 % the input noise z, so that
+    number alone would tolerate a 2 % error of the decoder's own contribution.)
+  north_star's bar is 1e-3.  **f16 operands meet it** on both metrics (gates 1e-3, measured 4-6e-4) and are the
+  parity-gated configuration.  **bf16 operands do not**: 8 mantissa bits give ~4e-3 per evaluation / displacement
+  (2^-9 per operand rounding through ~40 GEMMs; the split-precision operands of in_proj / final_proj remove only
+  the un-gated part); their gates below are regression guards, not a claim of meeting 1e-3.
 """
 import math
 
@@ -19,13 +22,17 @@ from oracle.inputs import make_inputs
 
 pytestmark = pytest.mark.gpu
 
-NFE_TOL = {"bf16": 1e-2, "f16": 1.5e-3}
+NFE_TOL = {"bf16": 1e-2, "f16": 1e-3}
 MEL_TOL = 1e-3
-DISP_TOL = {"bf16": 1.5e-2, "f16": 2e-3}
+DISP_TOL = {"bf16": 1e-2, "f16": 1e-3}
 
 
 def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def _disp(out, ref, z):
+    return float((out.double() - ref.double()).abs().max() / (ref.double() - z.double()).abs().max())
 
 
 @pytest.fixture(scope="module")
@@ -105,7 +112,7 @@ def test_solve_vs_reference_fixture(decoders, cfg_params, golden, dt, name, B, T
     out = _solve(decoders[dt], inp, n, solver, _cfg(cfg_params, cfg, True), z)
     assert torch.isfinite(out).all()
     assert _rel(out, ref) <= MEL_TOL
-    assert float((out - ref).abs().max() / (ref - z).abs().max()) <= DISP_TOL[dt]
+    assert _disp(out, ref, z) <= DISP_TOL[dt]
 
 
 # ---------------------------------------------------------------- BASELINE config 1 (B=1, T=500, n=10, CFG off)
@@ -115,16 +122,38 @@ def test_config1_b1_t500_euler10(decoders, sd, dt):
     ref = oracle.cfm_forward(sd, inp["mu"], inp["mask"], 10, inp["z"], inp["c"], "euler", None)
     out = _solve(decoders[dt], inp, 10, "euler", None, inp["z"])
     assert _rel(out, ref) <= MEL_TOL
-    assert float((out - ref).abs().max() / (ref - inp["z"]).abs().max()) <= DISP_TOL[dt]
+    assert _disp(out, ref, inp["z"]) <= DISP_TOL[dt]
 
 
-# ---------------------------------------------------------------- long ODE (config 3 shape, reduced batch)
+# ---------------------------------------------------------------- long ODE (BASELINE config 3)
 def test_long_ode_50_steps_state_drift(decoders, sd, cfg_params):
     inp = make_inputs(1, 128, seed=3)
     kw = _cfg(cfg_params, 3.0, False)
     ref = oracle.cfm_forward(sd, inp["mu"], inp["mask"], 50, inp["z"], inp["c"], "euler", kw)
-    out = _solve(decoders["bf16"], inp, 50, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
-    assert _rel(out, ref) <= MEL_TOL
+    for dt in ("bf16", "f16"):
+        out = _solve(decoders[dt], inp, 50, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
+        assert _rel(out, ref) <= MEL_TOL
+        assert _disp(out, ref, inp["z"]) <= DISP_TOL[dt], dt
+
+
+@pytest.mark.parametrize("solver,n", [("euler", 50), ("rk4", 12)])
+def test_config3_at_size_long_ode(decoders, sd, cfg_params, solver, n):
+    """BASELINE config 3 at size: B=8 x T=1000 (ragged), CFG 3.0, n=50 Euler (100 evaluations) and rk4-3/8 n=12 (96
+    evaluations) -- fp32-state drift over a long ODE with the production 256x256-tile kernels.  Utterances are
+    independent, so two rows (the longest and a ragged one) are checked against the oracle run on those alone."""
+    inp = make_inputs(8, 1000, seed=70, ragged=True)
+    lens = inp["mask"][:, 0].sum(-1)
+    rows = [int(lens.argmax()), int(lens.argmin())]
+    sub = {k: v[rows] for k, v in inp.items() if k != "lengths"}
+    ref = oracle.cfm_forward(sd, sub["mu"], sub["mask"], n, sub["z"], sub["c"], solver, _cfg(cfg_params, 3.0, False))
+    for dt in ("bf16", "f16"):
+        out = _solve(decoders[dt], inp, n, solver, _cfg(cfg_params, 3.0, True), inp["z"])
+        assert torch.isfinite(out).all()
+        pad = ~inp["mask"].bool().expand_as(out)
+        assert torch.equal(out[pad], inp["z"][pad])
+        got = out[rows]
+        assert _rel(got, ref) <= MEL_TOL, dt
+        assert _disp(got, ref, sub["z"]) <= DISP_TOL[dt], dt
 
 
 # ---------------------------------------------------------------- full-size (BASELINE config 2) properties
@@ -167,7 +196,80 @@ def test_c2_batch_rows_match_oracle(sd, cfg_params, c2):
     ref = oracle.cfm_forward(sd, sub["mu"], sub["mask"], 10, sub["z"], sub["c"], "euler", _cfg(cfg_params, 3.0, False))
     got = out[rows]
     assert _rel(got, ref) <= MEL_TOL
-    assert float((got - ref).abs().max() / (ref - sub["z"]).abs().max()) <= DISP_TOL["bf16"]
+    assert _disp(got, ref, sub["z"]) <= DISP_TOL["bf16"]
+
+
+def test_c2_all_ones_mask_rows_match_oracle(decoders, sd, cfg_params):
+    """BASELINE config 2 exactly as benchmarked (B=32 x T=1000, ALL-ONES mask, n=10 Euler, CFG 3.0), both operand
+    types: two rows against the oracle run on those utterances alone."""
+    inp = make_inputs(32, 1000, seed=0)
+    rows = [3, 29]
+    sub = {k: v[rows] for k, v in inp.items() if k != "lengths"}
+    ref = oracle.cfm_forward(sd, sub["mu"], sub["mask"], 10, sub["z"], sub["c"], "euler", _cfg(cfg_params, 3.0, False))
+    for dt in ("bf16", "f16"):
+        out = _solve(decoders[dt], inp, 10, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
+        got = out[rows]
+        assert _rel(got, ref) <= MEL_TOL, dt
+        assert _disp(got, ref, sub["z"]) <= DISP_TOL[dt], dt
+
+
+def test_mask_with_interior_zeros(decoders, sd):
+    """Non-prefix masks (holes): the reference builds its attention mask from mask x mask^T and multiplies frames by
+    the mask (diffusion_transformer.py:107-108), so any 0/1 pattern is legal.  One evaluation + exact zeros."""
+    inp = make_inputs(3, 300, seed=61, lengths=[300, 300, 211])
+    mask = inp["mask"].clone()
+    mask[0, 0, 40:75] = 0; mask[0, 0, 128] = 0; mask[0, 0, 0] = 0            # holes incl. frame 0 and a tile boundary
+    mask[1, 0, 64:128] = 0                                                    # one whole 64-key tile masked
+    mask[2, 0, 0:70] = 0                                                      # FIRST key tile fully masked, valid keys later
+    inp["mask"] = mask
+    inp["mu"] = inp["mu"] * mask
+    t = torch.tensor(0.45)
+    with torch.inference_mode():
+        ref = oracle.decoder_forward(sd, t, inp["z"], mask, inp["mu"], inp["c"])
+    for dt in ("bf16", "f16"):
+        out = decoders[dt].estimator(t.cuda(), inp["z"].cuda(), mask.cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+        assert _rel(out, ref) <= NFE_TOL[dt], dt
+        assert float(out[~mask.bool().expand_as(out)].abs().max()) == 0.0
+
+
+def test_length_one_and_zero_items_inside_a_long_batch(decoders, sd, cfg_params):
+    """A length-1 utterance and a fully padded (length-0) row inside a T=1000 batch: per-row kv_end / n_full
+    bookkeeping, tiles without a valid key, exact zeros on padding."""
+    inp = make_inputs(4, 1000, seed=62, lengths=[1000, 1, 517, 0])
+    t = torch.tensor(0.8)
+    with torch.inference_mode():
+        ref = oracle.decoder_forward(sd, t, inp["z"], inp["mask"], inp["mu"], inp["c"])
+    for dt in ("bf16", "f16"):
+        out = decoders[dt].estimator(t.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+        assert torch.isfinite(out).all()
+        assert _rel(out[:3], ref[:3]) <= NFE_TOL[dt], dt
+        assert float(out[3].abs().max()) == 0.0 and float(out[1, :, 1:].abs().max()) == 0.0
+    ref2 = oracle.cfm_forward(sd, inp["mu"][:3], inp["mask"][:3], 2, inp["z"][:3], inp["c"][:3], "euler", _cfg(cfg_params, 3.0, False))
+    out2 = _solve(decoders["f16"], inp, 2, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
+    assert _disp(out2[:3], ref2, inp["z"][:3]) <= DISP_TOL["f16"]
+    assert torch.equal(out2[3], inp["z"][3])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_strong_gates_ada_std_015(dt):
+    """The parity weights draw the adaLN-Zero output layers N(0, 0.02): gates ~0.02-0.2, so attention / FFN errors
+    enter the residual stream attenuated.  A trained checkpoint has gates of O(1).  This case uses std 0.15 (gates
+    and scales ~1) so the attention and FFN branches carry full weight in the end-to-end gate (measured numbers are
+    recorded in DESIGN.md: 6.1e-4 f16 / 5.1e-3 bf16 -- the same as with weak gates, i.e. the f16 configuration keeps
+    meeting north_star's 1e-3 when every branch contributes un-attenuated)."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    sd2 = oracle.make_state_dict(1234, ada_std=0.15)
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dt)
+    dec.estimator.load_state_dict(sd2)
+    dec = dec.cuda()
+    inp = make_inputs(2, 300, seed=63, lengths=[300, 233])
+    t = torch.tensor(0.3)
+    with torch.inference_mode():
+        ref = oracle.decoder_forward(sd2, t, inp["z"], inp["mask"], inp["mu"], inp["c"])
+    out = dec.estimator(t.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+    r = _rel(out, ref)
+    print(f"ada_std=0.15 one-NFE rel err [{dt}]: {r:.3e}")
+    assert r <= NFE_TOL[dt]
 
 
 def test_c2_items_match_oracle_at_full_length(decoders, sd, cfg_params):
@@ -177,7 +279,7 @@ def test_c2_items_match_oracle_at_full_length(decoders, sd, cfg_params):
     for dt in ("bf16", "f16"):
         out = _solve(decoders[dt], inp, 2, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
         assert _rel(out, ref) <= MEL_TOL
-        assert float((out - ref).abs().max() / (ref - inp["z"]).abs().max()) <= DISP_TOL[dt]
+        assert _disp(out, ref, inp["z"]) <= DISP_TOL[dt]
 
 
 def test_padded_batch_equals_unpadded_up_to_pad_leak(decoders, sd):
