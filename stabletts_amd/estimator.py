@@ -13,6 +13,20 @@ import torch.nn as nn
 from . import _lib
 
 
+def _param_key(module):
+    """(storage address, version counter) of every parameter: changes whenever autograd-visible code rewrites a
+    weight.  Inference tensors (a module built or moved under torch.inference_mode) carry no version counter; they
+    key on the address alone and need sync_weights() after an in-place update."""
+    key = []
+    for p in module.parameters():
+        try:
+            ver = p._version
+        except RuntimeError:
+            ver = -1
+        key.append((p.data_ptr(), ver))
+    return tuple(key)
+
+
 class _ParamsOnly(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover
         raise RuntimeError("parameter container: the computation runs in the native HIP engine")
@@ -129,7 +143,7 @@ class Decoder(nn.Module):
 
     # ------------------------------------------------------------------ native engine plumbing
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return _param_key(self)
 
     def sync_weights(self):
         """Force the engine to re-read the parameters at the next call.  Needed only after writes that bypass

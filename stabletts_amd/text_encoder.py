@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .estimator import DiTConVBlock
+from .estimator import DiTConVBlock, _param_key
 
 
 class TextEncoder(nn.Module):
@@ -45,6 +45,9 @@ class TextEncoder(nn.Module):
         st["_engine_key"] = None
         return st
 
+    def _param_key(self):
+        return _param_key(self)
+
     def sync_weights(self):
         """Force a weight re-upload at the next call (after writes through ``p.data`` that bypass the version counter)."""
         self._engine_key = None
@@ -71,7 +74,7 @@ class TextEncoder(nn.Module):
                                        self.n_layers, self.kernel_size, self.gin_channels, self.operand_dtype, dev,
                                        text_encoder_vocab=self.n_vocab)
             self._engine_key = None
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = self._param_key()
         if key != self._engine_key:
             with torch.no_grad():
                 torch.cuda.synchronize(dev)
