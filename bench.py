@@ -97,7 +97,7 @@ CLASS_KERNEL = {
     "ffn_conv1": "conv_gemm2_kernel<st::Op{DT}, 3, 0, 256, 256, 2, 4>",
     "ffn_conv2": "conv_gemm2_kernel<st::Op{DT}, 3, 2, 256, 256, 2, 4>",
     "lsc_conv": "conv_gemm2_kernel<st::Op{DT}, 3, 1, 256, 256, 2, 4>",
-    "attention": "attention_kernel<st::Op{DT}>",
+    "attention": "attention_kernel<st::Op{DT}, false>",
     "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 256, 2, 4>",
     "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4>",
 }

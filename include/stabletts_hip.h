@@ -128,6 +128,25 @@ int st_create_text_encoder(const st_config* cfg, int n_vocab, int device, st_eng
 int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* lengths, const float* c,
                             float* x_out, float* mu_out, float* mask_out, int B, int T, void* stream);
 
+/* ---- training: autograd counterpart of Decoder.forward ------------------------------------------- */
+
+/* Replaces Decoder.forward(t, x, mask, mu, c) UNDER AUTOGRAD as CFMDecoder.compute_loss calls it (models/flow_matching.py:99,
+ * train.py:78-81): one vector-field evaluation with a per-item t (B values) that keeps every activation the backward
+ * pass needs in the engine.  Train-mode dropout of the reference (p_dropout on the FFN activations and on the attention
+ * probabilities, models/diffusion_transformer.py:22,52,77) is counter-based: the same (seed, element) hash is
+ * re-evaluated by the backward kernels, nothing is stored.  Pointers as for st_estimator_forward. */
+int st_train_forward(st_engine* e, const float* t, const float* x, const float* mu, const float* mask, const float* c,
+                     float* out, int B, int T, float p_dropout, uint64_t seed, void* stream);
+
+/* Replaces torch.autograd's backward of that call.  grad_out: d loss / d out (B, n_feats, T).  Writes d loss / d x,
+ * d loss / d mu (B, n_feats, T) and d loss / d c (B, gin) where the pointer is not NULL, and the gradient of every
+ * parameter into engine-owned fp32 buffers in the reference shapes (fetch with st_param_grad).  Must follow an
+ * st_train_forward on the same engine (one forward may be followed by one backward). */
+int st_train_backward(st_engine* e, const float* grad_out, float* grad_x, float* grad_mu, float* grad_c, void* stream);
+
+/* Copies the gradient of one parameter (reference state_dict name, `numel` fp32 values) to the device pointer dst. */
+int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, void* stream);
+
 /* Function evaluations, attempted steps and rejected steps of the last st_cfm_solve (adaptive solvers vary). */
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects);
 

@@ -58,7 +58,7 @@ def rope(x, d=32, base=10000):
     return torch.cat((x_rope, x_pass), dim=-1)
 
 
-def attention(q, k, v, mask, n_heads=4):
+def attention(q, k, v, mask, n_heads=4, drop=None):
     """models/diffusion_transformer.py:67-79 + mask construction :107-108.
 
     q,k,v: (B, C, T) conv outputs; mask (B,1,T) float 0/1. Returns (B, C, T) and the
@@ -77,27 +77,32 @@ def attention(q, k, v, mask, n_heads=4):
     am = torch.zeros_like(am).masked_fill(am == 0, -torch.finfo(q.dtype).max)
     s = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + am
     p = torch.softmax(s, dim=-1)
+    if drop is not None:        # train-mode SDPA dropout_p (:77) with an explicit keep/(1-p) factor tensor (B,H,T,T)
+        p = p * drop
     o = torch.matmul(p, vh)
     out = o.transpose(2, 3).contiguous().view(B, C, T)
     return out, (qh, kh, vh)
 
 
-def mha(sd, prefix, x, mask, n_heads=4, taps=None):
+def mha(sd, prefix, x, mask, n_heads=4, taps=None, drop=None):
     """models/diffusion_transformer.py:58-65 (MultiHeadAttention.forward)."""
     q = F.conv1d(x, sd[prefix + "conv_q.weight"], sd[prefix + "conv_q.bias"])
     k = F.conv1d(x, sd[prefix + "conv_k.weight"], sd[prefix + "conv_k.bias"])
     v = F.conv1d(x, sd[prefix + "conv_v.weight"], sd[prefix + "conv_v.bias"])
-    a, (qh, kh, vh) = attention(q, k, v, mask, n_heads)
+    a, (qh, kh, vh) = attention(q, k, v, mask, n_heads, drop)
     if taps is not None:
         taps["q"], taps["k"], taps["v"], taps["attn"] = qh, kh, vh, a
     return F.conv1d(a, sd[prefix + "conv_o.weight"], sd[prefix + "conv_o.bias"])
 
 
-def ffn(sd, prefix, x, mask, k=3, taps=None):
-    """models/diffusion_transformer.py:25-30 (FFN.forward); dropout is identity in eval."""
+def ffn(sd, prefix, x, mask, k=3, taps=None, drop=None):
+    """models/diffusion_transformer.py:25-30 (FFN.forward); dropout is identity in eval (drop: explicit train-mode
+    keep/(1-p) factor tensor (B,F,T), :28)."""
     p = k // 2
     h = F.conv1d(x * mask, sd[prefix + "conv_1.weight"], sd[prefix + "conv_1.bias"], padding=p)
     h = F.silu(h)
+    if drop is not None:
+        h = h * drop
     if taps is not None:
         taps["u"] = h * mask
     h = F.conv1d(h * mask, sd[prefix + "conv_2.weight"], sd[prefix + "conv_2.bias"], padding=p)
@@ -110,7 +115,7 @@ def layer_norm_c(x):
     return F.layer_norm(x.transpose(1, 2), (x.shape[1],), eps=1e-5).transpose(1, 2)
 
 
-def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None):
+def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None, drop=None):
     """DitWrapper.forward (models/estimator.py:15-18) + DiTConVBlock.forward
     (models/diffusion_transformer.py:98-117); arithmetic order of SURVEY.md 3.3."""
     p = f"blocks.{i}."
@@ -128,13 +133,13 @@ def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None):
     h = layer_norm_c(x) * (1 + sc_a) + sh_a
     if taps is not None:
         taps["h1"] = h
-    x = x + g_a * mha(sd, p + "block.attn.", h, mask, n_heads, taps) * mask
+    x = x + g_a * mha(sd, p + "block.attn.", h, mask, n_heads, taps, None if drop is None else drop["attn"][i]) * mask
     if taps is not None:
         taps["x2"] = x
     h = layer_norm_c(x) * (1 + sc_m) + sh_m
     if taps is not None:
         taps["h2"] = h * mask
-    x = x + g_m * ffn(sd, p + "block.mlp.", h, mask, k, taps)
+    x = x + g_m * ffn(sd, p + "block.mlp.", h, mask, k, taps, None if drop is None else drop["ffn"][i])
     if taps is not None:
         taps["x3"] = x
     return x
@@ -185,7 +190,7 @@ def text_encoder_forward(sd, tokens, c, lengths, n_heads=4, k=3, taps=None):
 
 
 # ----------------------------------------------------------------------------- estimator
-def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None):
+def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None, drop=None):
     """models/estimator.py:103-138 (Decoder.forward): one vector-field evaluation.
 
     t: () or (B,), x/mu: (B,M,T), mask: (B,1,T), c: (B,gin).  taps: optional dict that
@@ -212,7 +217,7 @@ def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None):
             if taps is not None:
                 taps[f"lsc{i - n_lsc}"] = x
         bt = {} if taps is not None else None
-        x = dit_block(sd, i, x, c, tau, mask, n_heads, k, bt)
+        x = dit_block(sd, i, x, c, tau, mask, n_heads, k, bt, drop)
         if taps is not None:
             for kk, vv in bt.items():
                 taps[f"b{i}.{kk}"] = vv

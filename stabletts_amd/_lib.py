@@ -26,7 +26,7 @@ EXPORTS = [
     "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
-    "st_device_bytes",
+    "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad",
 ]
 
 
@@ -109,6 +109,12 @@ def load():
     lib.st_profile_read.restype = c_int
     lib.st_device_bytes.argtypes = [c_void_p]
     lib.st_device_bytes.restype = ctypes.c_int64
+    lib.st_train_forward.argtypes = [c_void_p] + [c_void_p] * 6 + [c_int, c_int, c_float, ctypes.c_uint64, c_void_p]
+    lib.st_train_forward.restype = c_int
+    lib.st_train_backward.argtypes = [c_void_p] + [c_void_p] * 4 + [c_void_p]
+    lib.st_train_backward.restype = c_int
+    lib.st_param_grad.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64, c_void_p]
+    lib.st_param_grad.restype = c_int
     if lib.st_abi_version() != 1:
         raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
     _lib = lib
@@ -195,6 +201,21 @@ class Engine:
         self._check(self.lib.st_text_encoder_forward(self.handle, tokens.data_ptr(), lengths.data_ptr(), c.data_ptr(),
                                                      x_out.data_ptr(), mu_out.data_ptr(), mask_out.data_ptr(), B, T,
                                                      ctypes.c_void_p(stream)))
+
+    # ---- training: forward that keeps activations + backward (include/stabletts_hip.h, "training")
+    def train_forward(self, t, x, mu, mask, c, out, p_dropout, seed, stream):
+        B, _, T = x.shape
+        self._check(self.lib.st_train_forward(self.handle, t.data_ptr(), x.data_ptr(), mu.data_ptr(), mask.data_ptr(),
+                                              c.data_ptr(), out.data_ptr(), B, T, float(p_dropout), int(seed),
+                                              ctypes.c_void_p(stream)))
+
+    def train_backward(self, grad_out, grad_x, grad_mu, grad_c, stream):
+        ptr = lambda v: v.data_ptr() if v is not None else None      # noqa: E731
+        self._check(self.lib.st_train_backward(self.handle, grad_out.data_ptr(), ptr(grad_x), ptr(grad_mu), ptr(grad_c),
+                                               ctypes.c_void_p(stream)))
+
+    def param_grad(self, name, dst, stream):
+        self._check(self.lib.st_param_grad(self.handle, name.encode(), dst.data_ptr(), dst.numel(), ctypes.c_void_p(stream)))
 
     def last_solve_stats(self):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()

@@ -33,7 +33,9 @@
 
 namespace st {
 
-template <class P>
+// TRAIN: also writes the log2-sum-exp of every query row (for the backward's recomputation of P) and applies
+// dropout to the probabilities that enter P.V (not to the normaliser), as SDPA's dropout_p does.
+template <class P, bool TRAIN>
 __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) void attention_kernel(const AttnArgs a) {
     constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW;      // waves and queries per block
     using vec8 = typename P::vec8;
@@ -174,8 +176,12 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+                float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
                 psum += p;
+                if constexpr (TRAIN) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    p *= drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key);
+                }
                 pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p);
             }
         l_run += psum;
@@ -194,6 +200,9 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
 
     const float l_tot = xor32_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if constexpr (TRAIN) {
+        if (hi == 0 && query < T) a.lse[(size_t)nh * T + query] = l_tot > 0.f ? m_run + log2f(l_tot) : 0.f;
+    }
     // Output through LDS: each wave parks its 32 x 64 tile as [query][d] (144-B pitch) in its own slice of the K/V
     // buffers (free after the loop's last barrier) and writes it out as 128-B rows, 16 B per lane -- 4 wide stores
     // per lane instead of 16 scattered 8-B ones (the row-per-lane epilogue is store-issue bound, guide T21).
@@ -219,8 +228,13 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     const int qtiles = (a.T + 32 * ST_ATTN_WAVES - 1) / (32 * ST_ATTN_WAVES);
     const int total = a.n_items * a.H * qtiles;
     const int grid = ((total + 7) / 8) * 8;
-    if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
-    else                  hipLaunchKernelGGL((attention_kernel<OpF16>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+    if (a.lse) {
+        if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+        else                  hipLaunchKernelGGL((attention_kernel<OpF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+        return hipGetLastError();
+    }
+    if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, false>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+    else                  hipLaunchKernelGGL((attention_kernel<OpF16, false>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
     return hipGetLastError();
 }
 

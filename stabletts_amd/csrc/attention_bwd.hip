@@ -1,0 +1,594 @@
+// Flash-attention backward for gfx950 (training path): recomputes P from q, k and the forward's log2-sum-exp,
+// never materialises a T x T tensor.  Autograd counterpart of attention.hip, i.e. of
+// F.scaled_dot_product_attention(q, k, v, attn_mask, dropout_p) at models/diffusion_transformer.py:77.
+//
+// Math per (item, head), scores in natural units S = q_r k_r^T / 8 (q_r, k_r post-RoPE), P = softmax(S + mask):
+//     dV = Pd^T dO          Pd = P * keep / (1 - p)                       (dropout on the probabilities)
+//     dP = (dO V^T) * keep / (1 - p)
+//     dS = P * (dP - D)     D[q] = sum_d dO[q][d] O[q][d]
+//     d q_r = dS k_r / 8 ,  d k_r = dS^T q_r / 8
+// The forward stores q pre-scaled: q_s = q_r * log2(e)/8, so P = exp2(q_s k_r^T + bias - lse2) with lse2 the
+// forward's log2-sum-exp.  The kernels accumulate dq_acc = dS k_r and dk_acc = dS^T q_s; the pack kernel applies
+// d q_r = dq_acc / 8 and d k_r = dk_acc * ln 2, the inverse rotation of RoPE, and the 16-bit time-major packing.
+//
+// Precision: dS = P (dP - D) subtracts two numbers that share a large common part whenever V has a component that is
+// constant over the keys (bias, adaLN shift): 16-bit rounding of dO, V and of the stored output O would then be
+// amplified ~100x in dq / dk.  Two measures keep the backward at operand precision:
+//   * V is centred: V' = V - c, c = mean of V over the positions (fp32 mean, then one 16-bit rounding of the small
+//     centred value).  Without dropout dS is exactly invariant to c (sum_k P = 1); with dropout the extra term
+//     P a (f - F), a = dO . c, F = sum_k P f restores exactness (f = dropout factor of the (query, key) pair).
+//   * q and k have such components too, and the two accumulations dq = sum_k dS k, dk = sum_q dS q multiply them
+//     by sums of dS that (nearly) cancel.  The 16-bit A operands K^T, Q^T are therefore centred as well, and the
+//     mean part is added back in fp32 from fp32 row / column sums of dS: dq += kmean * sum_k dS, dk += qmean * sum_q dS.
+//   * the centred V enters dP = dO V'^T as a hi + lo pair of 16-bit operands (two MFMAs): what is left of dP after the
+//     subtraction of D is a small fraction of dP at weakly correlated V / K, so V's rounding would otherwise dominate;
+//   * dS is rescaled by a power of two before it is rounded to 16 bits: its magnitude falls by orders of magnitude
+//     from the last block to the first (f16 would go subnormal).  The dQ kernel bounds |dS| per query during its
+//     first pass (each lane scales its own column), and publishes the per-(item, head) maximum for the dK/dV kernel;
+//   * D is not taken from the stored 16-bit O: the dQ kernel makes a first pass over the keys that accumulates
+//     D' = sum_k P f dP' and F with the SAME P and dP' the second pass uses, and publishes them for the dK/dV kernel.
+//
+// As in the forward kernel every MFMA is arranged so that no operand ever crosses lanes:
+//   dQ kernel  (block = 256 queries, lane = query):   S^T = K Q^T and dP^T = V dO^T accumulate as [key][query]; their
+//              element-wise product dS^T is the B operand of dQ^T[d][query] += K^T[d][key] dS^T[key][query].
+//   dKV kernel (block = 128 keys, lane = key):        S = Q K^T and dP = dO V^T accumulate as [query][key]; P and dS
+//              are the B operands of dV^T[d][key] += dO^T[d][query] P[query][key] and dK^T += Q^T dS.
+// An accumulator used as a B operand presents its rows in the k-slot order "bits 2 <-> 3 swapped inside every 16";
+// the matching A operands (K^T, Q^T, dO^T) therefore come from "T-layout" copies [item][H][64][Tp] that store the
+// positions in exactly that order -- the layout the forward already uses for V^T (launch_attn_to_T builds them).
+#include "common.h"
+#include "train_launch.h"
+
+namespace st {
+
+namespace {
+
+constexpr int kTile = 64 * 128;      // one 64 x 64 16-bit tile, dense 128-B rows, XOR-swizzled like attention.hip
+constexpr int kDkvLds = 8 * kTile + 4 * 2 * 64 * 4;      // dK/dV kernel: 4 tiles x 2 buffers + lse / D' / F / a rows
+
+// natural-layout tile: 8 rows x 128 B per 1-KiB piece; rows >= T come from the zero page
+__device__ __forceinline__ void dma_rows(const unsigned char* base, size_t row_stride, int row0, int T, const unsigned char* zeros,
+                                         unsigned char* lds_tile, int piece, int lane) {
+    const int row = piece * 8 + (lane >> 3);
+    const int seg = (lane & 7) ^ ((row >> 1) & 7);
+    const int pos = row0 + row;
+    const unsigned char* src = pos < T ? base + (size_t)pos * row_stride + seg * 16 : zeros;
+    glds16b(src, lds_tile + piece * 1024);
+}
+// T-layout tile: row = head dim, 64 consecutive (permuted) positions starting at col0, always inside Tp
+__device__ __forceinline__ void dma_cols(const unsigned char* base, int Tp, int col0, unsigned char* lds_tile, int piece, int lane) {
+    const int row = piece * 8 + (lane >> 3);
+    const int seg = (lane & 7) ^ ((row >> 1) & 7);
+    glds16b(base + ((size_t)row * Tp + col0 + seg * 8) * 2, lds_tile + piece * 1024);
+}
+
+template <class P>
+__device__ __forceinline__ typename P::vec8 frag(const unsigned char* tile, int row_off, int swz, int slot) {
+    return as_vec8<P>(*(const uint4*)(tile + row_off + ((slot ^ swz) << 4)));
+}
+
+__device__ __forceinline__ void store_acc_rows(float* dst_row, const f32x16_t (&o)[2], int hi) {
+    // lane = one position; o[d2][r] = value for head dim d2*32 + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+    for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            *(float4*)(dst_row + d2 * 32 + 8 * q4 + 4 * hi) =
+                make_float4(o[d2][4 * q4 + 0], o[d2][4 * q4 + 1], o[d2][4 * q4 + 2], o[d2][4 * q4 + 3]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ dQ
+template <class P, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    constexpr int NW = 8, QB = 32 * NW;
+    using vec8 = typename P::vec8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * kTile];
+    unsigned char* Ks = smem;                 // K natural, 2 buffers
+    unsigned char* Vs = smem + 2 * kTile;     // V' natural (hi)
+    unsigned char* VLs = smem + 4 * kTile;    // V' natural (lo)
+    unsigned char* KTs = smem + 6 * kTile;    // K'^T (T layout)
+
+    const int T = a.T, Tp = a.Tp, H = a.H;
+    const int qtiles = (T + QB - 1) / QB;
+    const int total = a.n_items * H * qtiles;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int qt = lin % qtiles;
+    const int nh = lin / qtiles;
+    const int n = nh / H, h = nh % H;
+    const int mb = n % a.mask_mod;
+    const int kvend = a.kv_end[mb];
+    const float* kbias = a.kbias + (size_t)mb * Tp;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int query = qt * QB + wave * 32 + l31;
+    const bool qok = query < T;
+
+    const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
+    const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
+    const unsigned char* vbase = (const unsigned char*)a.v + ((size_t)nh * T) * 128;
+    const unsigned char* vlbase = (const unsigned char*)a.vlo + ((size_t)nh * T) * 128;
+    const unsigned char* ktbase = (const unsigned char*)a.kT + ((size_t)nh * 64) * Tp * 2;
+    const unsigned char* dobase = (const unsigned char*)a.dO + ((size_t)n * T) * a.dO_row_stride * 2 + (size_t)h * 128;
+    const unsigned char* zeros = (const unsigned char*)a.zeros;
+
+    vec8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+        if (qok) {
+            v = *(const uint4*)(qbase + (size_t)query * 128 + ks * 32 + hi * 16);
+            w = *(const uint4*)(dobase + (size_t)query * a.dO_row_stride * 2 + ks * 32 + hi * 16);
+        }
+        qf[ks] = as_vec8<P>(v); dof[ks] = as_vec8<P>(w);
+    }
+    const float lse_q = qok ? a.lse[(size_t)nh * T + query] : 0.f;
+    // a = dO[q] . c (c = the mean that was subtracted from V): this lane holds 32 of the 64 head dims, lane^32 the others
+    float a_q = 0.f;
+    {
+        const float* cm = a.vmean + (size_t)nh * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) a_q += (float)dof[ks][e2] * cm[ks * 16 + hi * 8 + e2];
+        a_q = xor32_sum(a_q);
+    }
+    constexpr bool dropping = DROP;
+
+    const int ntiles = (kvend + 63) >> 6;
+    auto issue = [&](int kt, int buf) {     // 8 pieces per tile, one per wave
+        dma_rows(kbase, 128, kt * 64, T, zeros, Ks + buf * kTile, wave, lane);
+        dma_rows(vbase, 128, kt * 64, T, zeros, Vs + buf * kTile, wave, lane);
+        dma_rows(vlbase, 128, kt * 64, T, zeros, VLs + buf * kTile, wave, lane);
+        dma_cols(ktbase, Tp, kt * 64, KTs + buf * kTile, wave, lane);
+    };
+    int row_off[2], swz[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { const int row = b * 32 + l31; row_off[b] = row * 128; swz[b] = (row >> 1) & 7; }
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float Dacc = 0.f, Facc = 0.f, D_q = 0.f, F_q = 1.f, rs = 0.f;       // rs = sum_k dS[q][k] (fp32)
+    float mxpd = 0.f, mxp = 0.f, alpha = 1.f;      // bounds for |dS| (first pass) -> power-of-two operand scale of this lane's column
+
+    if (ntiles > 0) issue(0, 0);
+    ST_DMA_WAIT(0);
+    __syncthreads();
+    // pass 0 over the key tiles: D' and F;  pass 1: dS and dQ
+    for (int it = 0; it < 2 * ntiles; ++it) {
+        const bool second = it >= ntiles;
+        const int kt = second ? it - ntiles : it;
+        const int buf = it & 1;
+        if (it + 1 < 2 * ntiles) issue(it + 1 >= ntiles ? it + 1 - ntiles : it + 1, buf ^ 1);
+        f32x16_t s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s[kb] = P::mfma(frag<P>(Ks + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), qf[ks], s[kb]);
+                dp[kb] = P::mfma(frag<P>(Vs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
+                dp[kb] = P::mfma(frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
+            }
+        }
+        vec8 dsf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bz = *(const float4*)(kbias + kt * 64 + kb * 32 + 8 * g4 + 4 * hi);
+                const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int key = kt * 64 + kb * 32 + 8 * g4 + 4 * hi + e;
+                    const float p = __builtin_amdgcn_exp2f(s[kb][r] + bzv[e] - lse_q);
+                    const float f = DROP ? drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key) : 1.0f;
+                    if (!second) {
+                        Dacc += p * f * dp[kb][r]; Facc += p * f;
+                        mxpd = fmaxf(mxpd, fabsf(p * f * dp[kb][r])); mxp = fmaxf(mxp, p);
+                    } else {
+                        float ds = p * (f * dp[kb][r] - D_q);
+                        if (dropping) ds += p * a_q * (f - F_q);
+                        rs += ds;
+                        dsf[kb * 2 + (r >> 3)][r & 7] = to16<P>(ds * alpha);
+                    }
+                }
+            }
+        if (!second) {
+            if (it == ntiles - 1) {
+                D_q = xor32_sum(Dacc); F_q = xor32_sum(Facc);
+                // |dS| <= max p|f dP| + max p (|D| + |a| (1/(1-p) + F)): scale this query's column to ~2^10
+                float bound = xor32_max(mxpd) + xor32_max(mxp) * (fabsf(D_q) + (dropping ? fabsf(a_q) * (a.drop.scale + F_q) : 0.f));
+                if (!(bound > 0.f) || !qok) bound = 0.f;
+                if (bound > 0.f) {
+                    int ex = 10 - (int)ceilf(log2f(bound));
+                    ex = ex < -40 ? -40 : (ex > 80 ? 80 : ex);
+                    alpha = exp2f((float)ex);
+                }
+                // per-(item, head) maximum for the dK/dV kernel (order-independent: max of non-negative floats via their bits)
+                float wmax = bound;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+                if (lane == 0) atomicMax(a.dsmax + nh, __float_as_uint(wmax));
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    o[d] = P::mfma(frag<P>(KTs + buf * kTile, row_off[d], swz[d], g * 2 + hi), dsf[g], o[d]);
+        }
+        ST_DMA_WAIT(0);
+        __syncthreads();
+    }
+    if (qok && hi == 0) {
+        a.Dq[(size_t)nh * T + query] = D_q; a.Fq[(size_t)nh * T + query] = F_q; a.aq[(size_t)nh * T + query] = a_q;
+    }
+    {   // undo the operand scale; K^T was centred: add kmean[d] * sum_k dS back (fp32)
+        rs = xor32_sum(rs);
+        const float inv_alpha = 1.0f / alpha;
+        const float* km = a.kmean + (size_t)nh * 64;
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d2][r] = o[d2][r] * inv_alpha + km[d2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] * rs;
+    }
+    if (qok) store_acc_rows(a.dq + ((size_t)nh * T + query) * 64, o, hi);
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+template <class P, bool DROP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+    constexpr int NW = 4, KB = 32 * NW;
+    using vec8 = typename P::vec8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // kDkvLds bytes
+    unsigned char* Qs = smem;                  // Q natural, 2 buffers
+    unsigned char* dOs = smem + 2 * kTile;     // dO natural (time-major rows)
+    unsigned char* QTs = smem + 4 * kTile;     // Q^T  (T layout)
+    unsigned char* dOTs = smem + 6 * kTile;    // dO^T (T layout)
+    float* lse_t = (float*)(smem + 8 * kTile);         // [2][64] each
+    float* D_t = lse_t + 2 * 64;
+    float* F_t = D_t + 2 * 64;
+    float* a_t = F_t + 2 * 64;
+    constexpr bool dropping = DROP;
+
+    const int T = a.T, Tp = a.Tp, H = a.H;
+    const int ktiles = (T + KB - 1) / KB;
+    const int total = a.n_items * H * ktiles;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int kblk = lin % ktiles;
+    const int nh = lin / ktiles;
+    const int n = nh / H, h = nh % H;
+    const int mb = n % a.mask_mod;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int key = kblk * KB + wave * 32 + l31;
+    const bool kok = key < T;
+
+    const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
+    const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
+    const unsigned char* vbase = (const unsigned char*)a.v + ((size_t)nh * T) * 128;
+    const unsigned char* vlbase = (const unsigned char*)a.vlo + ((size_t)nh * T) * 128;
+    const unsigned char* qtbase = (const unsigned char*)a.qT + ((size_t)nh * 64) * Tp * 2;
+    const unsigned char* dotbase = (const unsigned char*)a.dOT + ((size_t)nh * 64) * Tp * 2;
+    const unsigned char* dobase = (const unsigned char*)a.dO + ((size_t)n * T) * a.dO_row_stride * 2 + (size_t)h * 128;
+    const unsigned char* zeros = (const unsigned char*)a.zeros;
+
+    vec8 kf[4], vf[4], vlf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0), wl = make_uint4(0, 0, 0, 0);
+        if (kok) {
+            v = *(const uint4*)(kbase + (size_t)key * 128 + ks * 32 + hi * 16);
+            w = *(const uint4*)(vbase + (size_t)key * 128 + ks * 32 + hi * 16);
+            wl = *(const uint4*)(vlbase + (size_t)key * 128 + ks * 32 + hi * 16);
+        }
+        kf[ks] = as_vec8<P>(v); vf[ks] = as_vec8<P>(w); vlf[ks] = as_vec8<P>(wl);
+    }
+    float alpha = 1.f;      // power-of-two operand scale of dS for this (item, head), from the dQ kernel's bound
+    {
+        const float bound = __uint_as_float(a.dsmax[nh]);
+        if (bound > 0.f) {
+            int ex = 10 - (int)ceilf(log2f(bound));
+            ex = ex < -40 ? -40 : (ex > 80 ? 80 : ex);
+            alpha = exp2f((float)ex);
+        }
+    }
+    const float bias_k = kok ? a.kbias[(size_t)mb * Tp + key] : -1e30f;
+
+    const int nq = (T + 63) >> 6;
+    auto issue = [&](int qt, int buf) {     // 4 tiles x 8 pieces over 4 waves: each wave moves pieces 2*wave, 2*wave+1 of every tile
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = wave * 2 + k;
+            dma_rows(qbase, 128, qt * 64, T, zeros, Qs + buf * kTile, piece, lane);
+            dma_rows(dobase, (size_t)a.dO_row_stride * 2, qt * 64, T, zeros, dOs + buf * kTile, piece, lane);
+            dma_cols(qtbase, Tp, qt * 64, QTs + buf * kTile, piece, lane);
+            dma_cols(dotbase, Tp, qt * 64, dOTs + buf * kTile, piece, lane);
+        }
+        if (wave == 0) {
+            const int qq = qt * 64 + lane;
+            lse_t[buf * 64 + lane] = qq < T ? a.lse[(size_t)nh * T + qq] : 0.f;
+            D_t[buf * 64 + lane] = qq < T ? a.Dq[(size_t)nh * T + qq] : 0.f;
+            F_t[buf * 64 + lane] = qq < T ? a.Fq[(size_t)nh * T + qq] : 1.f;
+            a_t[buf * 64 + lane] = qq < T ? a.aq[(size_t)nh * T + qq] : 0.f;
+        }
+    };
+    int row_off[2], swz[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { const int row = b * 32 + l31; row_off[b] = row * 128; swz[b] = (row >> 1) & 7; }
+
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    float cs = 0.f;          // sum_q dS[q][key] (fp32)
+
+    issue(0, 0);
+    ST_DMA_WAIT(0);
+    __syncthreads();
+    for (int qt = 0; qt < nq; ++qt) {
+        const int buf = qt & 1;
+        if (qt + 1 < nq) issue(qt + 1, buf ^ 1);
+        f32x16_t s[2], dp[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[qb][r] = 0.f; dp[qb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s[qb] = P::mfma(frag<P>(Qs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), kf[ks], s[qb]);
+                dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vf[ks], dp[qb]);
+                dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vlf[ks], dp[qb]);
+            }
+        }
+        vec8 pdf[4], dsf[4];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 lz = *(const float4*)(lse_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
+                const float4 dz = *(const float4*)(D_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
+                const float4 fz = *(const float4*)(F_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
+                const float4 az = *(const float4*)(a_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
+                const float lv[4] = {lz.x, lz.y, lz.z, lz.w}, dvv[4] = {dz.x, dz.y, dz.z, dz.w};
+                const float fv[4] = {fz.x, fz.y, fz.z, fz.w}, av[4] = {az.x, az.y, az.z, az.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int query = qt * 64 + qb * 32 + 8 * g4 + 4 * hi + e;
+                    const float p = __builtin_amdgcn_exp2f(s[qb][r] + bias_k - lv[e]);
+                    const float f = DROP ? drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key) : 1.0f;
+                    pdf[qb * 2 + (r >> 3)][r & 7] = to16<P>(p * f);
+                    float ds = p * (dp[qb][r] * f - dvv[e]);
+                    if (dropping) ds += p * av[e] * (f - fv[e]);
+                    cs += ds;
+                    dsf[qb * 2 + (r >> 3)][r & 7] = to16<P>(ds * alpha);
+                }
+            }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                dv[d] = P::mfma(frag<P>(dOTs + buf * kTile, row_off[d], swz[d], g * 2 + hi), pdf[g], dv[d]);
+                dk[d] = P::mfma(frag<P>(QTs + buf * kTile, row_off[d], swz[d], g * 2 + hi), dsf[g], dk[d]);
+            }
+        ST_DMA_WAIT(0);
+        __syncthreads();
+    }
+    {   // undo the operand scale; Q^T was centred: add qmean[d] * sum_q dS back (fp32)
+        cs = xor32_sum(cs);
+        const float inv_alpha = 1.0f / alpha;
+        const float* qm = a.qmean + (size_t)nh * 64;
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dk[d2][r] = dk[d2][r] * inv_alpha + qm[d2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] * cs;
+    }
+    if (kok) {
+        store_acc_rows(a.dk + ((size_t)nh * T + key) * 64, dk, hi);
+        store_acc_rows(a.dv + ((size_t)nh * T + key) * 64, dv, hi);
+    }
+}
+
+hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s) {
+    if (!a.zeros || !a.kbias || !a.lse || !a.Dq || !a.Fq || !a.aq || !a.vmean || !a.kmean || !a.vlo || !a.dsmax) return hipErrorInvalidValue;
+    if (hipMemsetAsync(a.dsmax, 0, (size_t)a.n_items * a.H * 4, s) != hipSuccess) return hipErrorInvalidValue;
+    const int qtiles = (a.T + 255) / 256;
+    const int total = a.n_items * a.H * qtiles;
+    const int grid = ((total + 7) / 8) * 8;
+    const bool drop = a.drop.thresh != 0;
+    if (dtype == DT_BF16) {
+        if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, true>), dim3(grid), dim3(512), 0, s, a);
+        else      hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, false>), dim3(grid), dim3(512), 0, s, a);
+    } else {
+        if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, true>), dim3(grid), dim3(512), 0, s, a);
+        else      hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, false>), dim3(grid), dim3(512), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s) {
+    if (!a.zeros || !a.kbias || !a.lse || !a.Dq || !a.Fq || !a.aq || !a.qmean || !a.vlo || !a.dsmax) return hipErrorInvalidValue;
+    const int ktiles = (a.T + 127) / 128;
+    const int total = a.n_items * a.H * ktiles;
+    const int grid = ((total + 7) / 8) * 8;
+    // 66 KB of dynamic LDS: above the 64 KB default, the opt-in is per device and per kernel
+    static bool attr_done_dev[64][4] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    const bool drop = a.drop.thresh != 0;
+    const int di = (dtype == DT_BF16 ? 0 : 1) * 2 + (drop ? 1 : 0);
+    const void* fns[4] = {(const void*)attn_bwd_dkv_kernel<OpBF16, false>, (const void*)attn_bwd_dkv_kernel<OpBF16, true>,
+                          (const void*)attn_bwd_dkv_kernel<OpF16, false>, (const void*)attn_bwd_dkv_kernel<OpF16, true>};
+    if (!attr_done_dev[dev_][di]) {
+        hipError_t e = hipFuncSetAttribute(fns[di], hipFuncAttributeMaxDynamicSharedMemorySize, kDkvLds);
+        if (e != hipSuccess) return e;
+        attr_done_dev[dev_][di] = true;
+    }
+    if (di == 0)      hipLaunchKernelGGL((attn_bwd_dkv_kernel<OpBF16, false>), dim3(grid), dim3(256), kDkvLds, s, a);
+    else if (di == 1) hipLaunchKernelGGL((attn_bwd_dkv_kernel<OpBF16, true>), dim3(grid), dim3(256), kDkvLds, s, a);
+    else if (di == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<OpF16, false>), dim3(grid), dim3(256), kDkvLds, s, a);
+    else              hipLaunchKernelGGL((attn_bwd_dkv_kernel<OpF16, true>), dim3(grid), dim3(256), kDkvLds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ operand copies
+// natural rows -> T layout.  Source rows may be strided (time-major dO: row stride H*64, head offset h*64).
+// mean[nh][d] = mean over t < T of nat[t][d]  (natural [item][H][T][64])
+template <class P>
+__global__ __launch_bounds__(256) void attn_mean_nat_kernel(const typename P::elem* nat, int T, float* mean) {
+    __shared__ float part[4][64];
+    const int nh = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float v = 0.f;
+    for (int t = ty; t < T; t += 4) v += (float)nat[((size_t)nh * T + t) * 64 + tx];
+    part[ty][tx] = v;
+    __syncthreads();
+    if (ty == 0) mean[(size_t)nh * 64 + tx] = (part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]) / (float)T;
+}
+
+hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, int T, float* mean, hipStream_t s) {
+    if (dtype == DT_BF16) hipLaunchKernelGGL((attn_mean_nat_kernel<OpBF16>), dim3(n_heads_total), dim3(256), 0, s, (const __bf16*)nat, T, mean);
+    else                  hipLaunchKernelGGL((attn_mean_nat_kernel<OpF16>), dim3(n_heads_total), dim3(256), 0, s, (const _Float16*)nat, T, mean);
+    return hipGetLastError();
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void attn_to_T_kernel(const typename P::elem* nat, int64_t item_stride, int64_t head_stride,
+                                                        int row_stride, int H, int T, int Tp, const float* mean,
+                                                        typename P::elem* outT) {
+    __shared__ typename P::elem tile[64][64 + 2];
+    const int p0 = blockIdx.x * 64, nh = blockIdx.y;
+    const int n = nh / H, h = nh % H;
+    const typename P::elem* src = nat + (size_t)n * item_stride + (size_t)h * head_stride;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int pos = p0 + rr;
+        tile[rr][tx] = pos < T ? src[(size_t)pos * row_stride + tx] : (typename P::elem)0.0f;
+    }
+    __syncthreads();
+    // column c of the output holds position perm(c): bits 2 <-> 3 swapped inside every 16
+    const int c = tx;
+    const int pc = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);
+    for (int d = ty; d < 64; d += 4) {
+        float v = (float)tile[pc][d];
+        if (mean && p0 + pc < T) v -= mean[(size_t)nh * 64 + d];        // centred copy (zero tail stays zero)
+        outT[((size_t)nh * 64 + d) * Tp + p0 + c] = to16<P>(v);
+    }
+}
+
+hipError_t launch_attn_to_T(int dtype, const void* nat, int64_t item_stride, int64_t head_stride, int row_stride,
+                            int n_items, int H, int T, int Tp, const float* mean, void* outT, hipStream_t s) {
+    dim3 grid(Tp / 64, n_items * H);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((attn_to_T_kernel<OpBF16>), grid, dim3(256), 0, s, (const __bf16*)nat, item_stride, head_stride, row_stride, H, T, Tp, mean, (__bf16*)outT);
+    else                  hipLaunchKernelGGL((attn_to_T_kernel<OpF16>), grid, dim3(256), 0, s, (const _Float16*)nat, item_stride, head_stride, row_stride, H, T, Tp, mean, (_Float16*)outT);
+    return hipGetLastError();
+}
+
+// c[nh][d] = mean over the positions t < T of V[t][d]  (V^T in the T layout: the zero tail adds nothing)
+template <class P>
+__global__ __launch_bounds__(256) void attn_vmean_kernel(const typename P::elem* inT, int T, int Tp, float* vmean) {
+    // one block per (item, head); wave w handles head dims w, w+4, ...; lanes stride over the positions
+    const int nh = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = wave; d < 64; d += 4) {
+        const typename P::elem* row = inT + ((size_t)nh * 64 + d) * Tp;
+        float v = 0.f;
+        for (int c = lane; c < Tp; c += 64) v += (float)row[c];
+        v = wave_sum(v);
+        if (lane == 0) vmean[(size_t)nh * 64 + d] = v / (float)T;
+    }
+}
+
+// T layout -> natural rows, centred: nat[t][d] = V^T[d][perm(t)] - c[d]
+template <class P>
+__global__ __launch_bounds__(256) void attn_from_T_kernel(const typename P::elem* inT, int T, int Tp, const float* vmean,
+                                                          typename P::elem* nat, typename P::elem* nat_lo) {
+    __shared__ typename P::elem tile[64][64 + 2];
+    const int p0 = blockIdx.x * 64, nh = blockIdx.y;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int d = ty; d < 64; d += 4) tile[d][tx] = inT[((size_t)nh * 64 + d) * Tp + p0 + tx];      // column tx = position perm(tx)
+    __syncthreads();
+    const float cm = vmean ? vmean[(size_t)nh * 64 + tx] : 0.f;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int pos = p0 + rr;
+        const int c = (rr & ~12) | ((rr & 4) << 1) | ((rr & 8) >> 1);     // perm is an involution: position rr sits in column perm(rr)
+        if (pos < T) {
+            const float v = (float)tile[tx][c] - cm;
+            const typename P::elem hi16 = to16<P>(v);
+            nat[((size_t)nh * T + pos) * 64 + tx] = hi16;
+            if (nat_lo) nat_lo[((size_t)nh * T + pos) * 64 + tx] = to16<P>(v - (float)hi16);
+        }
+    }
+}
+
+hipError_t launch_attn_from_T(int dtype, const void* inT, int n_items, int H, int T, int Tp, float* vmean, void* nat, void* nat_lo,
+                              hipStream_t s) {
+    dim3 grid(Tp / 64, n_items * H);
+    if (dtype == DT_BF16) {
+        if (vmean) hipLaunchKernelGGL((attn_vmean_kernel<OpBF16>), dim3(n_items * H), dim3(256), 0, s, (const __bf16*)inT, T, Tp, vmean);
+        hipLaunchKernelGGL((attn_from_T_kernel<OpBF16>), grid, dim3(256), 0, s, (const __bf16*)inT, T, Tp, vmean, (__bf16*)nat, (__bf16*)nat_lo);
+    } else {
+        if (vmean) hipLaunchKernelGGL((attn_vmean_kernel<OpF16>), dim3(n_items * H), dim3(256), 0, s, (const _Float16*)inT, T, Tp, vmean);
+        hipLaunchKernelGGL((attn_from_T_kernel<OpF16>), grid, dim3(256), 0, s, (const _Float16*)inT, T, Tp, vmean, (_Float16*)nat, (_Float16*)nat_lo);
+    }
+    return hipGetLastError();
+}
+
+// dq_acc, dk_acc, dv (natural fp32 [item][H][T][64]) -> time-major 16-bit [item][T][3*H*64] = [dq | dk | dv] of the fused
+// QKV projection: d q_proj = R(-theta)(dq_acc / 8), d k_proj = R(-theta)(dk_acc ln2), d v_proj = dv, where R(theta) is the
+// partial rotary embedding of the forward (pairs (j, j+16), j < 16; models/diffusion_transformer.py:180-198).
+template <class P>
+__global__ __launch_bounds__(256) void qkv_grad_pack_kernel(const float* dq, const float* dk, const float* dv,
+                                                            const float* rope_cos, const float* rope_sin, int H, int T,
+                                                            int64_t total, typename P::elem* out) {
+    // one thread per (item, t, h, j < 16): handles dims j, j+16 (rotated pair) and j+32, j+48 (pass-through)
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 15);
+    const int h = (int)((idx >> 4) % H);
+    const int64_t row = (idx >> 4) / H;               // item * T + t
+    const int64_t n = row / T; const int t = (int)(row - n * T);
+    const float c = rope_cos[(size_t)t * 16 + j], sn = rope_sin[(size_t)t * 16 + j];
+    const size_t src = (((size_t)n * H + h) * T + t) * 64;
+    const int C = H * 64;
+    typename P::elem* o = out + (size_t)row * 3 * C + h * 64;
+    {   // y1 = x1 c - x2 s, y2 = x2 c + x1 s  =>  dx1 = dy1 c + dy2 s, dx2 = dy2 c - dy1 s
+        const float a1 = dq[src + j] * 0.125f, a2 = dq[src + j + 16] * 0.125f;
+        o[j] = to16<P>(a1 * c + a2 * sn); o[j + 16] = to16<P>(a2 * c - a1 * sn);
+        o[j + 32] = to16<P>(dq[src + j + 32] * 0.125f); o[j + 48] = to16<P>(dq[src + j + 48] * 0.125f);
+    }
+    {
+        const float ln2 = 0.6931471805599453f;
+        const float a1 = dk[src + j] * ln2, a2 = dk[src + j + 16] * ln2;
+        o[C + j] = to16<P>(a1 * c + a2 * sn); o[C + j + 16] = to16<P>(a2 * c - a1 * sn);
+        o[C + j + 32] = to16<P>(dk[src + j + 32] * ln2); o[C + j + 48] = to16<P>(dk[src + j + 48] * ln2);
+    }
+    o[2 * C + j] = to16<P>(dv[src + j]); o[2 * C + j + 16] = to16<P>(dv[src + j + 16]);
+    o[2 * C + j + 32] = to16<P>(dv[src + j + 32]); o[2 * C + j + 48] = to16<P>(dv[src + j + 48]);
+}
+
+hipError_t launch_qkv_grad_pack(int dtype, const float* dq, const float* dk, const float* dv, const float* rope_cos,
+                                const float* rope_sin, int n_items, int H, int T, void* dqkv16, hipStream_t s) {
+    const int64_t total = (int64_t)n_items * T * H * 16;
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((qkv_grad_pack_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, dq, dk, dv, rope_cos, rope_sin, H, T, total, (__bf16*)dqkv16);
+    else                  hipLaunchKernelGGL((qkv_grad_pack_kernel<OpF16>), dim3(grid), dim3(256), 0, s, dq, dk, dv, rope_cos, rope_sin, H, T, total, (_Float16*)dqkv16);
+    return hipGetLastError();
+}
+
+}  // namespace st

@@ -120,4 +120,20 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
 }
 #define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// counter-based dropout (DropCfg, launch.h): 32-bit murmur3-style mix of (seed, a, b) -- a, b = the two halves of the
+// element's coordinates (attention: row = (item*H + head)*T + query, key; FFN: low / high word of the element index)
+__host__ __device__ __forceinline__ unsigned drop_mix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned a, unsigned b) {
+    const unsigned h = drop_mix32((unsigned)seed ^ (a * 0x9E3779B1u));
+    return drop_mix32(h ^ (unsigned)(seed >> 32) ^ (b * 0x85ebca77u));
+}
+template <class D>
+__device__ __forceinline__ float drop_factor(const D& d, unsigned a, unsigned b) {
+    if (d.thresh == 0) return 1.0f;
+    return drop_hash(d.seed, a, b) >= d.thresh ? d.scale : 0.0f;
+}
+
 }  // namespace st

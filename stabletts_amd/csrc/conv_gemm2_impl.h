@@ -421,7 +421,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 
     const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
     const unsigned char* a1 = g.c1 ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;
-    const unsigned char* wsrc = (const unsigned char*)g.w;
+    const unsigned char* wsrc = (const unsigned char*)g.w + (size_t)n * g.w_item_stride;
 
     // LDS-DMA addressing.  The loop-invariant per-lane part of every source address is computed once (the
     // per-stage part is scalar arithmetic on an SGPR base): issuing a 1-KiB piece costs the issuing wave ~100

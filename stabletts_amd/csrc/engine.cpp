@@ -2,8 +2,7 @@
 // estimator launch sequence and the fixed-grid ODE loop behind the C ABI of
 // include/stabletts_hip.h.  Reference path: models/flow_matching.py:25-67 (CFMDecoder.forward,
 // cfg_wrapper), models/estimator.py:103-138 (Decoder.forward), torchdiffeq fixed-grid solvers.
-#include "../../include/stabletts_hip.h"
-#include "launch.h"
+#include "engine_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -15,116 +14,18 @@
 #include <vector>
 
 using namespace st;
+using namespace sthost;
 
-namespace {
+namespace sthost {
 
 std::string g_create_error;
 
 // Default of the two-part solve (see st_cfm_solve): -1 = automatic (large fixed-grid batches), 1 = never.
 constexpr int kDefaultSplit = 1;
 
-enum ProfClass {
-    PC_PREP = 0, PC_PRENET, PC_INPROJ, PC_FILM_LN1, PC_QKV, PC_ATTN, PC_OPROJ, PC_LN2, PC_FFN1, PC_FFN2,
-    PC_LSC, PC_FINAL, PC_ODE, PC_COUNT
-};
 const char* kProfNames[PC_COUNT] = {
     "prep", "prenet_conv", "in_proj", "film_ln1", "qkv_rope", "attention", "out_proj", "ln2",
-    "ffn_conv1", "ffn_conv2", "lsc_conv", "final_proj", "ode_update"};
-
-struct Param {
-    std::vector<int64_t> shape;
-    float* dev = nullptr;
-    bool loaded = false;
-    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
-};
-
-struct Conv {            // packed 16-bit weights [cout][taps][cin] + fp32 bias
-    void* w = nullptr;
-    float* bias = nullptr;
-    int cout = 0, cin = 0, taps = 0;
-    bool split = false;  // cin = 3 x the reference's: [W_hi | W_hi | W_lo] for a split-precision operand [x_hi | x_lo | x_hi]
-};
-
-struct Captured { void* dev = nullptr; int64_t n = 0; bool is16 = false; };
-
-struct ProfEvent { int cls; hipEvent_t a, b; double flops; };
-
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-}  // namespace
-
-struct st_engine {
-    st_config cfg{};
-    int device = 0;
-    int dt = DT_BF16;
-    int M = 0, Mp = 0, C = 0, F = 0, H = 0, L = 0, K = 0, G = 0;
-    int kind = 0;                       // 0: CFM decoder estimator, 1: TextEncoder (same DiT block kernels)
-    int n_vocab = 0;
-    // parameter-name prefix of DiT block i: estimator.py:13,79 "blocks.i.block." / text_encoder.py:25 "encoder.i."
-    std::string blk(int i) const {
-        return kind == 0 ? "blocks." + std::to_string(i) + ".block." : "encoder." + std::to_string(i) + ".";
-    }
-    std::map<std::string, Param> params;
-    bool finalized = false;
-    std::string err;
-    int64_t weight_bytes = 0;
-
-    // packed weights
-    std::vector<Conv> pre;              // 3 prenet convs
-    Conv inx, inc, fin;                 // in_proj x-part / cond-part, final_proj
-    std::vector<Conv> lsc, qkv, oproj, ffn1, ffn2;
-    std::vector<void*> owned;           // device allocations to free
-
-    float* rope_cos = nullptr; float* rope_sin = nullptr; int rope_T = 0;
-    void* zeros = nullptr;              // 256 zero bytes: halo source of the LDS-DMA conv path
-
-    // workspace arena
-    char* ws = nullptr; size_t ws_cap = 0;
-
-    // debug / profile
-    bool capture = false;
-    std::map<std::string, Captured> caps;
-    bool prof = false;
-    uint64_t prof_mask = ~0ull;
-    int prof_stride = 1;
-    int64_t prof_seen[PC_COUNT] = {0};
-    std::vector<ProfEvent> evs;
-    std::vector<hipEvent_t> ev_pool;
-    int64_t prof_launches[PC_COUNT] = {0};
-    double prof_ms[PC_COUNT] = {0};
-    double prof_flops[PC_COUNT] = {0};
-
-    int64_t last_nfe = 0, last_steps = 0, last_rejects = 0;   // statistics of the last solve
-
-    // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
-    // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
-    int big_min_blocks = 192;
-    int conc = 1;                       // solve parts in flight on separate streams (their launches share the chip)
-    hipStream_t s2 = nullptr;           // stream of the second solve part
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-
-    // HIP-graph replay of the fixed-grid solve body (ST_HIP_GRAPH=1): one instantiated graph per solve signature
-    struct SolveGraph {
-        int B, T, n_steps, solver, use_cfg; float cfg_strength; const char* ws; int parts; int seen; hipGraphExec_t exec;
-    };
-    std::vector<SolveGraph> graphs;
-    hipStream_t gstream = nullptr;      // capture stream
-    void drop_graphs() {
-        for (auto& g : graphs) if (g.exec) hipGraphExecDestroy(g.exec);
-        graphs.clear();
-    }
-
-    int fail(int code, const std::string& msg) { err = msg; return code; }
-};
-
-namespace {
-
-#define HIPCHK(e, call)                                                                         \
-    do {                                                                                        \
-        hipError_t _err = (call);                                                               \
-        if (_err != hipSuccess)                                                                 \
-            return (e)->fail(ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_err));  \
-    } while (0)
+    "ffn_conv1", "ffn_conv2", "lsc_conv", "final_proj", "ode_update", "train_forward", "train_backward"};
 
 int dev_alloc(st_engine* e, void** p, size_t bytes) {
     HIPCHK(e, hipMalloc(p, bytes ? bytes : 16));
@@ -207,22 +108,19 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
 }
 
 // ---- profiling helpers -----------------------------------------------------------------------
-struct ProfScope {
-    st_engine* e; hipStream_t s; int idx = -1;
-    ProfScope(st_engine* e_, hipStream_t s_, int cls, double flops) : e(e_), s(s_) {
-        if (!e->prof || !((e->prof_mask >> cls) & 1ull)) return;
-        if ((e->prof_seen[cls]++ % e->prof_stride) != 0) return;
-        ProfEvent ev; ev.cls = cls; ev.flops = flops;
-        for (hipEvent_t* h : {&ev.a, &ev.b}) {
-            if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
-            else if (hipEventCreate(h) != hipSuccess) return;
-        }
-        hipEventRecord(ev.a, s);
-        e->evs.push_back(ev);
-        idx = (int)e->evs.size() - 1;
+ProfScope::ProfScope(st_engine* e_, hipStream_t s_, int cls, double flops) : e(e_), s(s_) {
+    if (!e->prof || !((e->prof_mask >> cls) & 1ull)) return;
+    if ((e->prof_seen[cls]++ % e->prof_stride) != 0) return;
+    ProfEvent ev; ev.cls = cls; ev.flops = flops;
+    for (hipEvent_t* h : {&ev.a, &ev.b}) {
+        if (!e->ev_pool.empty()) { *h = e->ev_pool.back(); e->ev_pool.pop_back(); }
+        else if (hipEventCreate(h) != hipSuccess) return;
     }
-    ~ProfScope() { if (idx >= 0) hipEventRecord(e->evs[idx].b, s); }
-};
+    hipEventRecord(ev.a, s);
+    e->evs.push_back(ev);
+    idx = (int)e->evs.size() - 1;
+}
+ProfScope::~ProfScope() { if (idx >= 0) hipEventRecord(e->evs[idx].b, s); }
 
 void prof_collect(st_engine* e) {
     for (auto& ev : e->evs) {
@@ -798,7 +696,7 @@ std::vector<float> linspace01(int n) {
     return t;
 }
 
-}  // namespace
+}  // namespace sthost
 
 // ============================================================================================ C ABI
 extern "C" {
@@ -859,6 +757,7 @@ void st_destroy(st_engine* e) {
     hipSetDevice(e->device);
     hipDeviceSynchronize();
     e->drop_graphs();
+    train_destroy(e);
     if (e->gstream) hipStreamDestroy(e->gstream);
     if (e->s2) hipStreamDestroy(e->s2);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -970,6 +869,7 @@ int st_finalize(st_engine* e) {
         if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F, false))) return rc;
     }
     HIPCHK(e, hipDeviceSynchronize());
+    train_invalidate(e);
     e->finalized = true;
     return ST_OK;
 }

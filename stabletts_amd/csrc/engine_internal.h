@@ -1,0 +1,140 @@
+// Host-side internals shared by engine.cpp (inference: parameter store, packing, solve loop) and engine_train.cpp
+// (training: forward that keeps activations + backward).  Not part of the C ABI.
+#pragma once
+#include "../../include/stabletts_hip.h"
+#include "launch.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace sthost {
+
+enum ProfClass {
+    PC_PREP = 0, PC_PRENET, PC_INPROJ, PC_FILM_LN1, PC_QKV, PC_ATTN, PC_OPROJ, PC_LN2, PC_FFN1, PC_FFN2,
+    PC_LSC, PC_FINAL, PC_ODE, PC_TRAIN_FWD, PC_TRAIN_BWD, PC_COUNT
+};
+
+struct Param {
+    std::vector<int64_t> shape;
+    float* dev = nullptr;
+    bool loaded = false;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Conv {            // packed 16-bit weights [cout][taps][cin] + fp32 bias
+    void* w = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, taps = 0;
+    bool split = false;  // cin = 3 x the reference's: [W_hi | W_hi | W_lo] for a split-precision operand [x_hi | x_lo | x_hi]
+};
+
+struct Captured { void* dev = nullptr; int64_t n = 0; bool is16 = false; };
+
+struct ProfEvent { int cls; hipEvent_t a, b; double flops; };
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct TrainState;     // engine_train.cpp
+
+}  // namespace sthost
+
+struct st_engine {
+    st_config cfg{};
+    int device = 0;
+    int dt = st::DT_BF16;
+    int M = 0, Mp = 0, C = 0, F = 0, H = 0, L = 0, K = 0, G = 0;
+    int kind = 0;                       // 0: CFM decoder estimator, 1: TextEncoder (same DiT block kernels)
+    int n_vocab = 0;
+    // parameter-name prefix of DiT block i: estimator.py:13,79 "blocks.i.block." / text_encoder.py:25 "encoder.i."
+    std::string blk(int i) const {
+        return kind == 0 ? "blocks." + std::to_string(i) + ".block." : "encoder." + std::to_string(i) + ".";
+    }
+    std::map<std::string, sthost::Param> params;
+    bool finalized = false;
+    std::string err;
+    int64_t weight_bytes = 0;
+
+    // packed weights
+    std::vector<sthost::Conv> pre;              // 3 prenet convs
+    sthost::Conv inx, inc, fin;                 // in_proj x-part / cond-part, final_proj
+    std::vector<sthost::Conv> lsc, qkv, oproj, ffn1, ffn2;
+    std::vector<void*> owned;           // device allocations to free
+
+    float* rope_cos = nullptr; float* rope_sin = nullptr; int rope_T = 0;
+    void* zeros = nullptr;              // 256 zero bytes: halo source of the LDS-DMA conv path
+
+    // workspace arena
+    char* ws = nullptr; size_t ws_cap = 0;
+
+    // debug / profile
+    bool capture = false;
+    std::map<std::string, sthost::Captured> caps;
+    bool prof = false;
+    uint64_t prof_mask = ~0ull;
+    int prof_stride = 1;
+    int64_t prof_seen[sthost::PC_COUNT] = {0};
+    std::vector<sthost::ProfEvent> evs;
+    std::vector<hipEvent_t> ev_pool;
+    int64_t prof_launches[sthost::PC_COUNT] = {0};
+    double prof_ms[sthost::PC_COUNT] = {0};
+    double prof_flops[sthost::PC_COUNT] = {0};
+
+    int64_t last_nfe = 0, last_steps = 0, last_rejects = 0;   // statistics of the last solve
+
+    // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
+    // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
+    int big_min_blocks = 192;
+    int conc = 1;                       // solve parts in flight on separate streams (their launches share the chip)
+    hipStream_t s2 = nullptr;           // stream of the second solve part
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+    // HIP-graph replay of the fixed-grid solve body (ST_HIP_GRAPH=1): one instantiated graph per solve signature
+    struct SolveGraph {
+        int B, T, n_steps, solver, use_cfg; float cfg_strength; const char* ws; int parts; int seen; hipGraphExec_t exec;
+    };
+    std::vector<SolveGraph> graphs;
+    hipStream_t gstream = nullptr;      // capture stream
+    void drop_graphs() {
+        for (auto& g : graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
+
+    // training (engine_train.cpp): transposed dgrad weights, saved activations, gradient buffers
+    sthost::TrainState* train = nullptr;
+
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+};
+
+
+namespace sthost {
+
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t _err = (call);                                                               \
+        if (_err != hipSuccess)                                                                 \
+            return (e)->fail(ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_err));  \
+    } while (0)
+
+int dev_alloc(st_engine* e, void** p, size_t bytes);
+const float* P(st_engine* e, const std::string& name);
+hipError_t gemm(st_engine* e, int taps, int epi, const st::ConvGemmArgs& a, hipStream_t s);
+void prof_collect(st_engine* e);
+void capture(st_engine* e, const std::string& name, const void* dev, int64_t n, bool is16, hipStream_t s);
+int ensure_ws(st_engine* e, size_t bytes);
+int ensure_rope(st_engine* e, int T, hipStream_t s);
+int check_ready(st_engine* e, int B, int T);
+
+// HIP-event bracket around the launches of one kernel class (st_profile_*)
+struct ProfScope {
+    st_engine* e; hipStream_t s; int idx = -1;
+    ProfScope(st_engine* e_, hipStream_t s_, int cls, double flops);
+    ~ProfScope();
+};
+
+// engine_train.cpp
+int train_prepare(st_engine* e, hipStream_t s);       // packs the transposed (dgrad) weights if the parameters changed
+void train_invalidate(st_engine* e);                  // called by st_finalize
+void train_destroy(st_engine* e);
+
+}  // namespace sthost

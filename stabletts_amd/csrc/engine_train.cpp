@@ -1,0 +1,584 @@
+// Training side of libstabletts_hip.so: a forward evaluation of the estimator that keeps the activations and the
+// matching backward pass, both as launch sequences of hand-written gfx950 kernels.  Autograd counterpart of
+// models/estimator.py:103-138 (Decoder.forward) + models/diffusion_transformer.py:98-121 as exercised by
+// CFMDecoder.compute_loss (models/flow_matching.py:69-100) under DDP in train.py:78-81.
+//
+// Structure of the backward pass:
+//   * data gradients of every convolution run through the FORWARD implicit-GEMM kernel with transposed, tap-flipped
+//     weights (dX[t][ci] = sum_j sum_co W[co][ci][2-j] dY[t+j-1][co] is itself a k=3 convolution);
+//   * weight gradients run through the same kernel too: with K-contiguous transposed copies of the activations and
+//     of dY (train_kernels.hip) dW = dY^T X is the kernel's contraction with the frame axis as K, split over row
+//     chunks and reduced deterministically;
+//   * attention: flash-style recomputation (attention_bwd.hip);
+//   * FiLM / LayerNorm+adaLN / gated residuals / SiLU+dropout: one frame per wave, per-(item, channel) sums kept in
+//     registers and reduced without atomics;
+//   * the per-item vectors (time MLP, FiLM and adaLN linears) are tiny fp32 kernels.
+// The training forward uses plain GEMM epilogues + element-wise kernels (nothing fused across ops) because every
+// intermediate is needed again; the fused inference path of engine.cpp is untouched.
+#include "engine_internal.h"
+#include "train_launch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace st;
+
+namespace sthost {
+
+struct LayerAct {
+    float *lscout, *x1, *o32, *x2, *f32b, *x3;
+    void *h1, *q, *k, *vt, *attn16, *h2, *a16, *u16, *x3_16;
+    float* lse;
+};
+
+struct TrainState {
+    // transposed (dgrad) weights
+    Conv finT, inxT, incT, preT[3];
+    std::vector<Conv> ffn1T, ffn2T, oprojT, qkvT, lscTa, lscTb;
+    std::vector<void*> owned;
+    std::map<std::string, float*> grads;       // fp32 gradient buffers, reference shapes
+    // activation + scratch arena of the last train_forward
+    char* ws = nullptr; size_t ws_cap = 0;
+    int B = 0, T = 0, Tp = 0;
+    float p_drop = 0.f; unsigned long long seed = 0;
+    bool have_fwd = false;
+    bool packed = false;                       // dgrad weights match the current parameters
+    // saved tensors
+    void *mu16, *x16, *x16lo, *a1, *p1, *a2, *p2, *cond16, *cond16lo, *h0_16, *x3lo;
+    float *maskbuf, *kbias, *cvec, *tvals, *emb, *th_pre, *tau, *film, *ada, *cpart, *h0, *v32;
+    int *n_full, *kv_end;
+    std::vector<LayerAct> L;
+    // backward scratch
+    float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
+          *gin, *gsc;
+    unsigned *gbits, *dsmax;
+    void *g16a, *g16b, *vnat, *vnat_lo, *qT, *kT, *dOT, *xt, *dyt;
+    size_t partial_cap = 0, xt_cap = 0, dyt_cap = 0;
+};
+
+namespace {
+
+inline ConvGemmArgs cargs(const st_engine* e, const Conv& cv, int n_items, int T, int B) {
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = cv.w; a.bias = cv.bias; a.cout = cv.cout; a.T = T; a.n_items = n_items;
+    a.a0_mod = n_items; a.a1_mod = n_items; a.mask_mod = B;
+    a.zeros = e->zeros;
+    return a;
+}
+
+// dgrad weights of one forward convolution: rows = its input channels [ci_off, ci_off + ci_cnt) padded to cin_p,
+// K = taps x (its output channels, padded to ld)
+int pack_T(st_engine* e, TrainState* ts, Conv& cv, const std::string& wname, int cout, int cin_total, int taps, int ci_off,
+           int ci_cnt, int cin_p, int ld, hipStream_t s) {
+    cv.cout = cin_p; cv.cin = ld; cv.taps = taps; cv.split = false;
+    const size_t bytes = (size_t)cin_p * taps * ld * 2;
+    if (!cv.w) { HIPCHK(e, hipMalloc(&cv.w, bytes)); ts->owned.push_back(cv.w); }
+    HIPCHK(e, hipMemsetAsync(cv.w, 0, bytes, s));
+    HIPCHK(e, launch_pack_weight_t(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, cin_p, ld, 0, s));
+    cv.bias = nullptr;
+    return ST_OK;
+}
+
+}  // namespace
+
+void train_invalidate(st_engine* e) {
+    if (e->train) { e->train->packed = false; e->train->have_fwd = false; }
+}
+
+// (re)packs the transposed weights after a parameter update; lazy: inference-only users never pay for it
+int train_prepare(st_engine* e, hipStream_t s) {
+    if (e->kind != 0) return ST_OK;
+    if (!e->train) e->train = new TrainState();
+    TrainState* ts = e->train;
+    if (ts->packed) return ST_OK;
+    ts->have_fwd = false;
+    const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
+    int rc;
+    if ((rc = pack_T(e, ts, ts->finT, "final_proj.weight", M, C, 1, 0, C, C, Mp, s))) return rc;
+    if ((rc = pack_T(e, ts, ts->inxT, "in_proj.weight", C, C + M, 1, 0, M, Mp, C, s))) return rc;
+    if ((rc = pack_T(e, ts, ts->incT, "in_proj.weight", C, C + M, 1, M, C, C, C, s))) return rc;
+    if ((rc = pack_T(e, ts, ts->preT[0], "cond_proj.0.weight", F, M, K, 0, M, Mp, F, s))) return rc;
+    if ((rc = pack_T(e, ts, ts->preT[1], "cond_proj.2.weight", F, F, K, 0, F, F, F, s))) return rc;
+    if ((rc = pack_T(e, ts, ts->preT[2], "cond_proj.4.weight", C, F, K, 0, F, F, C, s))) return rc;
+    ts->ffn1T.resize(L); ts->ffn2T.resize(L); ts->oprojT.resize(L); ts->qkvT.resize(L);
+    ts->lscTa.resize(L / 2); ts->lscTb.resize(L / 2);
+    for (int i = 0; i < L; ++i) {
+        const std::string b = e->blk(i);
+        if ((rc = pack_T(e, ts, ts->ffn1T[i], b + "mlp.conv_1.weight", F, C, K, 0, C, C, F, s))) return rc;
+        if ((rc = pack_T(e, ts, ts->ffn2T[i], b + "mlp.conv_2.weight", C, F, K, 0, F, F, C, s))) return rc;
+        if ((rc = pack_T(e, ts, ts->oprojT[i], b + "attn.conv_o.weight", C, C, 1, 0, C, C, C, s))) return rc;
+        // fused q/k/v: K of the dgrad GEMM = [dq | dk | dv] (3C)
+        Conv& q = ts->qkvT[i];
+        q.cout = C; q.cin = 3 * C; q.taps = 1;
+        if (!q.w) { HIPCHK(e, hipMalloc(&q.w, (size_t)C * 3 * C * 2)); ts->owned.push_back(q.w); }
+        int r = 0;
+        for (const char* nm : {"q", "k", "v"}) {
+            HIPCHK(e, launch_pack_weight_t(e->dt, P(e, b + "attn.conv_" + nm + ".weight"), C, C, 1, 0, C, q.w, C, 3 * C, r * C, s));
+            ++r;
+        }
+    }
+    for (int j = 0; j < L / 2; ++j) {
+        const std::string n = "lsc_layers." + std::to_string(j) + ".weight";
+        if ((rc = pack_T(e, ts, ts->lscTa[j], n, C, 2 * C, K, 0, C, C, C, s))) return rc;
+        if ((rc = pack_T(e, ts, ts->lscTb[j], n, C, 2 * C, K, C, C, C, C, s))) return rc;
+    }
+    for (auto& kv : e->params) {
+        float*& g = ts->grads[kv.first];
+        if (!g) { HIPCHK(e, hipMalloc((void**)&g, (size_t)kv.second.numel() * 4)); ts->owned.push_back(g); }
+    }
+    ts->packed = true;
+    return ST_OK;
+}
+
+void train_destroy(st_engine* e) {
+    if (!e->train) return;
+    for (void* p : e->train->owned) hipFree(p);
+    if (e->train->ws) hipFree(e->train->ws);
+    delete e->train;
+    e->train = nullptr;
+}
+
+namespace {
+
+int layout_train(st_engine* e, TrainState* ts, int B, int T) {
+    const int C = e->C, F = e->F, Mp = e->Mp, L = e->L, H = e->H, G = e->G;
+    const int Tp = (T + 63) / 64 * 64;
+    const size_t N = B, TT = T, R = N * TT;
+    size_t off = 0;
+    struct Slot { void** dst; size_t off; };
+    std::vector<Slot> slots;
+    auto want = [&](void** dst, size_t bytes) { slots.push_back({dst, off}); off = align_up(off + bytes, 256); };
+    ts->L.assign(L, LayerAct());
+    want(&ts->mu16, R * Mp * 2); want(&ts->x16, R * Mp * 2); want(&ts->x16lo, R * Mp * 2);
+    want(&ts->a1, R * F * 2); want(&ts->p1, R * F * 2); want(&ts->a2, R * F * 2); want(&ts->p2, R * F * 2);
+    want(&ts->cond16, R * C * 2); want(&ts->cond16lo, R * C * 2); want(&ts->h0_16, R * C * 2); want(&ts->x3lo, R * C * 2);
+    want((void**)&ts->maskbuf, R * 4); want((void**)&ts->kbias, N * Tp * 4);
+    want((void**)&ts->n_full, N * 4); want((void**)&ts->kv_end, N * 4);
+    want((void**)&ts->cvec, N * G * 4); want((void**)&ts->tvals, N * 4);
+    want((void**)&ts->emb, N * C * 4); want((void**)&ts->th_pre, N * F * 4); want((void**)&ts->tau, N * C * 4);
+    want((void**)&ts->film, (size_t)L * N * 2 * C * 4); want((void**)&ts->ada, (size_t)L * N * 6 * C * 4);
+    want((void**)&ts->cpart, R * C * 4); want((void**)&ts->h0, R * C * 4); want((void**)&ts->v32, R * Mp * 4);
+    for (int i = 0; i < L; ++i) {
+        LayerAct& a = ts->L[i];
+        if (i >= L / 2) want((void**)&a.lscout, R * C * 4); else a.lscout = nullptr;
+        want((void**)&a.x1, R * C * 4); want((void**)&a.o32, R * C * 4); want((void**)&a.x2, R * C * 4);
+        want((void**)&a.f32b, R * C * 4); want((void**)&a.x3, R * C * 4);
+        want(&a.h1, R * C * 2); want(&a.q, R * C * 2); want(&a.k, R * C * 2); want(&a.vt, N * C * Tp * 2);
+        want(&a.attn16, R * C * 2); want(&a.h2, R * C * 2); want(&a.a16, R * F * 2); want(&a.u16, R * F * 2);
+        want(&a.x3_16, R * C * 2);
+        want((void**)&a.lse, N * H * TT * 4);
+    }
+    // backward scratch
+    want((void**)&ts->dX, R * C * 4);
+    for (int j = 0; j < L / 2; ++j) want((void**)&ts->dskip[j], R * C * 4);
+    want((void**)&ts->tmpC, R * C * 4); want((void**)&ts->tmpF, R * F * 4); want((void**)&ts->gin, R * Mp * 4);
+    want(&ts->g16a, R * F * 2); want(&ts->g16b, R * 3 * C * 2);
+    want(&ts->vnat, R * C * 2); want(&ts->vnat_lo, R * C * 2); want((void**)&ts->dsmax, N * H * 4); want(&ts->qT, N * C * Tp * 2); want(&ts->kT, N * C * Tp * 2); want(&ts->dOT, N * C * Tp * 2);
+    want((void**)&ts->Dbuf, N * H * TT * 4); want((void**)&ts->Fbuf, N * H * TT * 4); want((void**)&ts->abuf, N * H * TT * 4);
+    want((void**)&ts->vmean, N * H * 64 * 4); want((void**)&ts->qmean, N * H * 64 * 4); want((void**)&ts->kmean, N * H * 64 * 4);
+    want((void**)&ts->dq, R * C * 4); want((void**)&ts->dk, R * C * 4); want((void**)&ts->dv, R * C * 4);
+    // weight-gradient operands: the largest are (taps*Cin, Cout) = (3F, F) [cond_proj.2]; rows padded per split
+    const size_t Rpad = align_up(R, 64) + 64 * 64;           // every split rounds its rows up to a multiple of 64
+    ts->xt_cap = (size_t)3 * F * Rpad * 2; ts->dyt_cap = (size_t)F * Rpad * 2;
+    want(&ts->xt, ts->xt_cap); want(&ts->dyt, ts->dyt_cap);
+    ts->partial_cap = (size_t)64 * 3 * F * F * 4 / 4;        // S * taps*Cin * Cout fp32 with S chosen to fit (see wgrad())
+    want((void**)&ts->partial, ts->partial_cap);
+    want((void**)&ts->part_b, (Rpad / 64) * (size_t)std::max(F, 3 * C) * 4);
+    want((void**)&ts->red, N * (size_t)red_chunks(T) * 2 * 256 * 4);
+    want((void**)&ts->dada, (size_t)L * N * 6 * C * 4); want((void**)&ts->dfilm, (size_t)L * N * 2 * C * 4);
+    want((void**)&ts->dtau, N * C * 4); want((void**)&ts->dth, N * F * 4); want((void**)&ts->demb, N * C * 4);
+    want((void**)&ts->dcvec, N * G * 4);
+    want((void**)&ts->gsc, 16); want((void**)&ts->gbits, 16);
+    if (off > ts->ws_cap) {
+        if (ts->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(ts->ws)); ts->ws = nullptr; ts->ws_cap = 0; }
+        HIPCHK(e, hipMalloc((void**)&ts->ws, off));
+        ts->ws_cap = off;
+    }
+    for (auto& sl : slots) *sl.dst = ts->ws + sl.off;
+    ts->B = B; ts->T = T; ts->Tp = Tp;
+    return ST_OK;
+}
+
+inline const float* xpre_of(const TrainState* ts, int i, int L) {
+    return i == 0 ? ts->h0 : (i >= L / 2 ? ts->L[i].lscout : ts->L[i - 1].x3);
+}
+
+}  // namespace
+
+}  // namespace sthost
+
+using namespace sthost;
+
+extern "C" {
+
+int st_train_forward(st_engine* e, const float* t, const float* x, const float* mu, const float* mask, const float* c,
+                     float* out, int B, int T, float p_dropout, uint64_t seed, void* stream) {
+    int rc = check_ready(e, B, T); if (rc) return rc;
+    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
+    if (!t || !x || !mu || !mask || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+    if (e->G != e->C) return e->fail(ST_ERR_UNSUPPORTED, "training path is built for gin_channels == hidden_channels");
+    if (!(p_dropout >= 0.f && p_dropout < 1.f)) return e->fail(ST_ERR_INVALID, "p_dropout must be in [0, 1)");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = train_prepare(e, s))) return rc;
+    TrainState* ts = e->train;
+    ts->have_fwd = false;
+    if ((rc = layout_train(e, ts, B, T))) return rc;
+    if ((rc = ensure_rope(e, T, s))) return rc;
+    ProfScope prof(e, s, PC_TRAIN_FWD, 0);
+    const int C = e->C, F = e->F, Mp = e->Mp, L = e->L, H = e->H, N = B, Tp = ts->Tp;
+    const int64_t R = (int64_t)N * T;
+    ts->p_drop = p_dropout; ts->seed = seed;
+    HIPCHK(e, launch_mask_prep(mask, B, T, Tp, ts->n_full, ts->kv_end, ts->kbias, s));
+    HIPCHK(e, launch_cvec_prep(mask, nullptr, B, T, ts->maskbuf, s));
+    const float* m = ts->maskbuf;
+    HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, Mp, nullptr, ts->mu16, nullptr, s));
+    HIPCHK(e, launch_to_time_major(e->dt, x, B, e->M, T, Mp, nullptr, ts->x16, ts->x16lo, s));
+    HIPCHK(e, launch_cvec_prep(c, nullptr, B, e->G, ts->cvec, s));
+    HIPCHK(e, hipMemcpyAsync(ts->tvals, t, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    // per-item vectors: time embedding -> MLP (pre-activation kept) -> FiLM; adaLN
+    HIPCHK(e, launch_time_embed(ts->tvals, B, C, ts->emb, s));
+    HIPCHK(e, launch_linear(ts->emb, B, C, P(e, "time_mlp.layer.0.weight"), P(e, "time_mlp.layer.0.bias"), F, ts->th_pre, 0, 0, s));
+    HIPCHK(e, launch_linear(ts->th_pre, B, F, P(e, "time_mlp.layer.2.weight"), P(e, "time_mlp.layer.2.bias"), C, ts->tau, 1, 0, s));
+    for (int i = 0; i < L; ++i) {
+        const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
+        HIPCHK(e, launch_linear(ts->tau, B, C, P(e, pf + "weight"), P(e, pf + "bias"), 2 * C, ts->film + (size_t)i * N * 2 * C, 0, 0, s));
+        const std::string pa = e->blk(i) + "adaLN_modulation.2.";
+        HIPCHK(e, launch_linear(ts->cvec, N, C, P(e, pa + "weight"), P(e, pa + "bias"), 6 * C, ts->ada + (size_t)i * N * 6 * C, 1, 0, s));
+    }
+    const DropCfg nodrop = make_drop(0.f, 0, 0);
+    // cond prenet (estimator.py:83-89,118): pre-activations kept for SiLU'
+    {
+        ConvGemmArgs a = cargs(e, e->pre[0], N, T, B); a.a0 = ts->mu16; a.c0 = Mp; a.out16 = ts->a1;
+        HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+        HIPCHK(e, launch_silu_drop(e->dt, ts->a1, ts->p1, nullptr, 1, T, F, R, nodrop, s));
+        a = cargs(e, e->pre[1], N, T, B); a.a0 = ts->p1; a.c0 = F; a.out16 = ts->a2;
+        HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+        HIPCHK(e, launch_silu_drop(e->dt, ts->a2, ts->p2, nullptr, 1, T, F, R, nodrop, s));
+        a = cargs(e, e->pre[2], N, T, B); a.a0 = ts->p2; a.c0 = F; a.out16 = ts->cond16; a.out16_lo = ts->cond16lo;
+        HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+        a = cargs(e, e->inc, N, T, B); a.a0 = ts->cond16; a.c0 = C; a.a1 = ts->cond16lo; a.c1 = C; a.c2 = C; a.out32 = ts->cpart;
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    {   // in_proj (estimator.py:120-121): output kept in fp32 (FiLM input / long skip) and 16 bit (long-skip operand)
+        ConvGemmArgs a = cargs(e, e->inx, N, T, B);
+        a.a0 = ts->x16; a.c0 = Mp; a.a1 = ts->x16lo; a.c1 = Mp; a.c2 = Mp; a.bias = nullptr;
+        a.add32 = ts->cpart; a.add_clamp = N; a.out32 = ts->h0; a.out16 = ts->h0_16;
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    for (int i = 0; i < L; ++i) {
+        LayerAct& A = ts->L[i];
+        const float* ada_i = ts->ada + (size_t)i * N * 6 * C;
+        if (i >= L / 2) {   // long-skip merge (estimator.py:131-132)
+            const int j = i - L / 2;
+            const int src = L - 1 - i;      // 2, 1, 0 -> x3[1], x3[0], h0
+            ConvGemmArgs a = cargs(e, e->lsc[j], N, T, B);
+            a.a0 = ts->L[i - 1].x3_16; a.c0 = C; a.a1 = src == 0 ? ts->h0_16 : ts->L[src - 1].x3_16; a.c1 = C; a.out32 = A.lscout;
+            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+        }
+        {   // FiLM * mask -> x1 ; LN1 + modulate -> h1
+            TrainLnArgs a; memset(&a, 0, sizeof(a));
+            a.xin = xpre_of(ts, i, L); a.xout = A.x1; a.h16 = A.h1;
+            a.film = ts->film + (size_t)i * N * 2 * C; a.film_stride = 2 * C; a.film_mod = N;
+            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 0; a.scale_off = C;
+            a.mask = m; a.mask_mod = B; a.mask_out = 0; a.T = T; a.rows = (int)R;
+            HIPCHK(e, launch_train_ln(e->dt, a, s));
+        }
+        {
+            ConvGemmArgs a = cargs(e, e->qkv[i], N, T, B);
+            a.a0 = A.h1; a.c0 = C; a.q = A.q; a.k = A.k; a.vt = A.vt; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+            a.Tp = Tp; a.n_heads = H; a.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
+            HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
+        }
+        {
+            AttnArgs a; memset(&a, 0, sizeof(a));
+            a.q = A.q; a.k = A.k; a.vt = A.vt; a.out = A.attn16; a.kbias = ts->kbias; a.mask_mod = B; a.zeros = e->zeros;
+            a.kv_end = ts->kv_end; a.n_full = ts->n_full; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
+            a.lse = A.lse; a.drop = make_drop(p_dropout, seed, 2 * i + 1);
+            HIPCHK(e, launch_attention(e->dt, a, s));
+        }
+        {   // o = (Wo attn + b) * mask
+            ConvGemmArgs a = cargs(e, e->oproj[i], N, T, B);
+            a.a0 = A.attn16; a.c0 = C; a.mask = m; a.flags = GF_MASK; a.out32 = A.o32;
+            HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+        }
+        {   // x2 = x1 + g_msa * o ; LN2 + modulate, masked -> h2
+            TrainLnArgs a; memset(&a, 0, sizeof(a));
+            a.xin = A.x1; a.xout = A.x2; a.h16 = A.h2;
+            a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.branch = A.o32;
+            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
+            a.mask = m; a.mask_mod = B; a.mask_out = 1; a.T = T; a.rows = (int)R;
+            HIPCHK(e, launch_train_ln(e->dt, a, s));
+        }
+        {   // FFN (diffusion_transformer.py:25-30)
+            ConvGemmArgs a = cargs(e, e->ffn1[i], N, T, B); a.a0 = A.h2; a.c0 = C; a.out16 = A.a16;
+            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+            HIPCHK(e, launch_silu_drop(e->dt, A.a16, A.u16, m, B, T, F, R, make_drop(p_dropout, seed, 2 * i), s));
+            a = cargs(e, e->ffn2[i], N, T, B); a.a0 = A.u16; a.c0 = F; a.mask = m; a.flags = GF_MASK; a.out32 = A.f32b;
+            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+        }
+        {   // x3 = x2 + g_mlp * f  (+ 16-bit copies: long-skip / final_proj operands)
+            TrainLnArgs a; memset(&a, 0, sizeof(a));
+            a.xin = A.x2; a.xout = A.x3; a.x16 = A.x3_16; a.x16lo = i + 1 == L ? ts->x3lo : nullptr;
+            a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.branch = A.f32b;
+            a.T = T; a.rows = (int)R;
+            HIPCHK(e, launch_train_ln(e->dt, a, s));
+        }
+    }
+    {
+        ConvGemmArgs a = cargs(e, e->fin, N, T, B);
+        a.a0 = ts->L[L - 1].x3_16; a.c0 = C; a.a1 = ts->x3lo; a.c1 = C; a.c2 = C; a.mask = m; a.flags = GF_MASK; a.out32 = ts->v32;
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    HIPCHK(e, launch_from_time_major(ts->v32, B, e->M, T, Mp, out, s));
+    if (e->capture) {
+        for (int i = 0; i < L; ++i) {
+            const std::string bn = "t" + std::to_string(i) + ".";
+            capture(e, bn + "x1", ts->L[i].x1, R * C, false, s); capture(e, bn + "x2", ts->L[i].x2, R * C, false, s);
+            capture(e, bn + "x3", ts->L[i].x3, R * C, false, s);
+            capture(e, bn + "q", ts->L[i].q, R * C, true, s); capture(e, bn + "k", ts->L[i].k, R * C, true, s);
+            capture(e, bn + "vt", ts->L[i].vt, (int64_t)N * C * Tp, true, s); capture(e, bn + "attn", ts->L[i].attn16, R * C, true, s);
+            capture(e, bn + "lse", ts->L[i].lse, (int64_t)N * H * T, false, s);
+            capture(e, bn + "u", ts->L[i].u16, R * F, true, s);
+        }
+    }
+    ts->have_fwd = true;
+    return ST_OK;
+}
+
+}  // extern "C"
+
+namespace sthost {
+namespace {
+
+// dW / db of one convolution through the forward kernel.  X: up to two 16-bit sources [R][c0 | c1]; dY: [R][cout16]
+// (16 bit, cout16 = padded channel count of the tensor); gradients go to the reference-layout fp32 tensors.
+struct WgradOut { float* dW; int cin_total; int ci_off; int ci_cnt; int co_start; int co_cnt; float* db; };
+int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, int c1, const void* dy, int cout16, int taps,
+          const WgradOut* outs, int n_outs, hipStream_t s) {
+    const int N = ts->B, T = ts->T;
+    const int64_t R = (int64_t)N * T;
+    const int cin = c0 + c1;
+    const int frames = taps * cin;
+    // splits: enough blocks for the chip, bounded by the scratch capacities
+    const int tiles = ((frames + 255) / 256) * std::max(1, cout16 / 256);
+    int S = std::max(1, std::min(64, (512 + tiles - 1) / tiles));
+    S = (int)std::min<int64_t>(S, (R + 63) / 64);
+    while (S > 1 && (size_t)S * frames * cout16 * 4 > ts->partial_cap) --S;
+    const int Rs = (int)(((R + S - 1) / S + 63) / 64 * 64);
+    if ((size_t)S * frames * Rs * 2 > ts->xt_cap || (size_t)S * cout16 * Rs * 2 > ts->dyt_cap ||
+        (size_t)S * frames * cout16 * 4 > ts->partial_cap)
+        return e->fail(ST_ERR_INVALID, "weight-gradient scratch too small");
+    HIPCHK(e, launch_wgrad_xt(e->dt, x0, c0, x1, c1, N, T, taps, S, Rs, ts->xt, s));
+    HIPCHK(e, launch_wgrad_dyt(e->dt, dy, cout16, R, S, Rs, ts->dyt, ts->part_b, s));
+    ConvGemmArgs a; memset(&a, 0, sizeof(a));
+    a.a0 = ts->xt; a.c0 = Rs; a.a0_mod = S; a.a1_mod = S;
+    a.w = ts->dyt; a.w_item_stride = (long long)cout16 * Rs * 2;
+    a.cout = cout16; a.T = frames; a.n_items = S; a.mask_mod = 1; a.zeros = e->zeros;
+    a.out32 = ts->partial;
+    HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    for (int k = 0; k < n_outs; ++k) {
+        const WgradOut& o = outs[k];
+        if (o.dW) HIPCHK(e, launch_wgrad_reduce(ts->partial, S, cin, cout16, taps, o.dW, o.cin_total, o.ci_off, o.ci_cnt, o.co_start, o.co_cnt, ts->gsc, s));
+        if (o.db) HIPCHK(e, launch_bias_reduce(ts->part_b, (int)((int64_t)S * Rs / 64), cout16, o.db, o.co_start, o.co_cnt, ts->gsc, s));
+    }
+    return ST_OK;
+}
+
+float* G(TrainState* ts, const std::string& name) { return ts->grads.at(name); }
+
+}  // namespace
+}  // namespace sthost
+
+extern "C" {
+
+int st_train_backward(st_engine* e, const float* grad_out, float* grad_x, float* grad_mu, float* grad_c, void* stream) {
+    if (!e) return ST_ERR_INVALID;
+    if (e->kind != 0 || !e->train || !e->train->have_fwd) return e->fail(ST_ERR_STATE, "st_train_backward needs a preceding st_train_forward");
+    if (!grad_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    TrainState* ts = e->train;
+    ProfScope prof(e, s, PC_TRAIN_BWD, 0);
+    const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, L = e->L, H = e->H, K = e->K, N = ts->B, B = ts->B, T = ts->T, Tp = ts->Tp;
+    const int64_t R = (int64_t)N * T;
+    const float* m = ts->maskbuf;
+    const int chunks = red_chunks(T);
+    int rc;
+    const bool cap = e->capture;
+    HIPCHK(e, hipMemsetAsync(ts->dada, 0, (size_t)L * N * 6 * C * 4, s));
+    HIPCHK(e, hipMemsetAsync(ts->dfilm, 0, (size_t)L * N * 2 * C * 4, s));
+    for (const char* nm : {"time_mlp.layer.0.weight", "time_mlp.layer.0.bias", "time_mlp.layer.2.weight", "time_mlp.layer.2.bias"})
+        HIPCHK(e, hipMemsetAsync(G(ts, nm), 0, (size_t)e->params.at(nm).numel() * 4, s));
+    // d v (time-major, masked: out = (W x + b) * mask), as the 16-bit operand of the first GEMMs
+    HIPCHK(e, launch_grad_scale(grad_out, (int64_t)B * M * T, ts->gbits, ts->gsc, s));
+    HIPCHK(e, launch_to_time_major(e->dt, grad_out, B, M, T, Mp, ts->gin, nullptr, nullptr, s));
+    HIPCHK(e, launch_cast16(e->dt, ts->gin, m, B, T, Mp, R, ts->gsc, ts->g16a, s));
+    {   // final_proj
+        WgradOut o = {G(ts, "final_proj.weight"), C, 0, C, 0, M, G(ts, "final_proj.bias")};
+        if ((rc = wgrad(e, ts, ts->L[L - 1].x3_16, C, nullptr, 0, ts->g16a, Mp, 1, &o, 1, s))) return rc;
+        ConvGemmArgs a = cargs(e, ts->finT, N, T, B); a.a0 = ts->g16a; a.c0 = Mp; a.mask = m; a.flags = GF_MASK; a.out32 = ts->dX;
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    if (cap) { capture(e, "g.scale", ts->gsc, 2, false, s); capture(e, "g.x3_" + std::to_string(L - 1), ts->dX, R * C, false, s); }
+    for (int i = L - 1; i >= 0; --i) {
+        LayerAct& A = ts->L[i];
+        const std::string b = e->blk(i);
+        const float* ada_i = ts->ada + (size_t)i * N * 6 * C;
+        float* dada_i = ts->dada + (size_t)i * N * 6 * C;
+        // ---- x3 = x2 + g_mlp * f
+        HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.f32b, ada_i + 5 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
+        { const int off[1] = {5 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 1, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        {   // conv_2
+            WgradOut o = {G(ts, b + "mlp.conv_2.weight"), F, 0, F, 0, C, G(ts, b + "mlp.conv_2.bias")};
+            if ((rc = wgrad(e, ts, A.u16, F, nullptr, 0, ts->g16b, C, K, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->ffn2T[i], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->tmpF;
+            HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+        }
+        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, A.a16, m, B, T, F, R, make_drop(ts->p_drop, ts->seed, 2 * i), ts->g16a, s));
+        {   // conv_1
+            WgradOut o = {G(ts, b + "mlp.conv_1.weight"), C, 0, C, 0, F, G(ts, b + "mlp.conv_1.bias")};
+            if ((rc = wgrad(e, ts, A.h2, C, nullptr, 0, ts->g16a, F, K, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->ffn1T[i], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->tmpC;
+            HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+        }
+        HIPCHK(e, launch_ln_bwd(A.x2, ts->tmpC, ada_i, 6 * C, 4 * C, m, B, 1, T, N, ts->dX, ts->red, s));
+        { const int off[2] = {4 * C, 3 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        if (cap) capture(e, "g.x2_" + std::to_string(i), ts->dX, R * C, false, s);
+        // ---- x2 = x1 + g_msa * o
+        HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.o32, ada_i + 2 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
+        { const int off[1] = {2 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 1, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        {   // out projection
+            WgradOut o = {G(ts, b + "attn.conv_o.weight"), C, 0, C, 0, C, G(ts, b + "attn.conv_o.bias")};
+            if ((rc = wgrad(e, ts, A.attn16, C, nullptr, 0, ts->g16b, C, 1, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->oprojT[i], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out16 = ts->g16a;      // d attn (16 bit)
+            HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+        }
+        {   // attention
+            HIPCHK(e, launch_attn_from_T(e->dt, A.vt, N, H, T, Tp, ts->vmean, ts->vnat, ts->vnat_lo, s));
+            HIPCHK(e, launch_attn_mean_nat(e->dt, A.q, N * H, T, ts->qmean, s));
+            HIPCHK(e, launch_attn_mean_nat(e->dt, A.k, N * H, T, ts->kmean, s));
+            HIPCHK(e, launch_attn_to_T(e->dt, A.q, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->qmean, ts->qT, s));
+            HIPCHK(e, launch_attn_to_T(e->dt, A.k, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->kmean, ts->kT, s));
+            HIPCHK(e, launch_attn_to_T(e->dt, ts->g16a, (int64_t)T * C, 64, C, N, H, T, Tp, nullptr, ts->dOT, s));
+            AttnBwdArgs a; memset(&a, 0, sizeof(a));
+            a.q = A.q; a.k = A.k; a.v = ts->vnat; a.vlo = ts->vnat_lo; a.dsmax = ts->dsmax; a.qT = ts->qT; a.kT = ts->kT; a.dOT = ts->dOT;
+            a.dO = ts->g16a; a.dO_row_stride = C; a.lse = A.lse; a.vmean = ts->vmean; a.qmean = ts->qmean; a.kmean = ts->kmean;
+            a.Dq = ts->Dbuf; a.Fq = ts->Fbuf; a.aq = ts->abuf; a.kbias = ts->kbias; a.mask_mod = B;
+            a.kv_end = ts->kv_end; a.dq = ts->dq; a.dk = ts->dk; a.dv = ts->dv; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
+            a.drop = make_drop(ts->p_drop, ts->seed, 2 * i + 1); a.zeros = e->zeros;
+            HIPCHK(e, launch_attn_bwd_dq(e->dt, a, s));
+            HIPCHK(e, launch_attn_bwd_dkv(e->dt, a, s));
+            HIPCHK(e, launch_qkv_grad_pack(e->dt, ts->dq, ts->dk, ts->dv, e->rope_cos, e->rope_sin, N, H, T, ts->g16b, s));
+        }
+        if (cap) { capture(e, "g.dq_" + std::to_string(i), ts->dq, R * C, false, s); capture(e, "g.dk_" + std::to_string(i), ts->dk, R * C, false, s);
+                   capture(e, "g.dv_" + std::to_string(i), ts->dv, R * C, false, s); capture(e, "g.dattn_" + std::to_string(i), ts->g16a, R * C, true, s); }
+        {   // fused q/k/v projection
+            WgradOut o[3];
+            int r = 0;
+            for (const char* nm : {"q", "k", "v"}) {
+                o[r] = {G(ts, b + "attn.conv_" + nm + ".weight"), C, 0, C, r * C, C, G(ts, b + "attn.conv_" + nm + ".bias")};
+                ++r;
+            }
+            if ((rc = wgrad(e, ts, A.h1, C, nullptr, 0, ts->g16b, 3 * C, 1, o, 3, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->qkvT[i], N, T, B); a.a0 = ts->g16b; a.c0 = 3 * C; a.out32 = ts->tmpC;
+            HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+        }
+        HIPCHK(e, launch_ln_bwd(A.x1, ts->tmpC, ada_i, 6 * C, C, m, B, 0, T, N, ts->dX, ts->red, s));
+        { const int off[2] = {C, 0}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        if (cap) capture(e, "g.x1_" + std::to_string(i), ts->dX, R * C, false, s);
+        // ---- x1 = (gamma * xpre + beta) * mask
+        HIPCHK(e, launch_film_bwd(e->dt, xpre_of(ts, i, L), ts->film + (size_t)i * N * 2 * C, 2 * C, N, m, B, T, N, ts->dX,
+                                  i >= L / 2 ? ts->g16b : nullptr, ts->red, s));
+        { const int off[2] = {0, C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, ts->dfilm + (size_t)i * N * 2 * C, 2 * C, off, 0, ts->gsc, s)); }
+        if (i >= L / 2) {   // long-skip conv: xpre_i = W [x3_{i-1} ; skip] + b
+            const int j = i - L / 2, src = L - 1 - i;
+            const std::string n = "lsc_layers." + std::to_string(j);
+            const void* skip16 = src == 0 ? ts->h0_16 : ts->L[src - 1].x3_16;
+            WgradOut o = {G(ts, n + ".weight"), 2 * C, 0, 2 * C, 0, C, G(ts, n + ".bias")};
+            if ((rc = wgrad(e, ts, ts->L[i - 1].x3_16, C, skip16, C, ts->g16b, C, K, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->lscTb[j], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->dskip[src];
+            HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+            a = cargs(e, ts->lscTa[j], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->dX;
+            HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+        }
+        // x3_{i-1} (or the in_proj output) is also a long-skip source of a later block: add that gradient
+        if (i < L / 2) HIPCHK(e, launch_add_inplace(ts->dX, ts->dskip[i], R * C, s));
+        if (cap) capture(e, "g.xin_" + std::to_string(i), ts->dX, R * C, false, s);
+    }
+    // ---- in_proj: h0 = Wx x + Wc cond + b
+    HIPCHK(e, launch_cast16(e->dt, ts->dX, nullptr, 1, T, C, R, nullptr, ts->g16b, s));
+    {
+        WgradOut ox = {G(ts, "in_proj.weight"), C + M, 0, M, 0, C, G(ts, "in_proj.bias")};
+        if ((rc = wgrad(e, ts, ts->x16, Mp, nullptr, 0, ts->g16b, C, 1, &ox, 1, s))) return rc;
+        WgradOut oc = {G(ts, "in_proj.weight"), C + M, M, C, 0, C, nullptr};
+        if ((rc = wgrad(e, ts, ts->cond16, C, nullptr, 0, ts->g16b, C, 1, &oc, 1, s))) return rc;
+        if (grad_x) {
+            ConvGemmArgs a = cargs(e, ts->inxT, N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->gin;
+            HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+            HIPCHK(e, launch_unscale_inplace(ts->gin, R * Mp, ts->gsc, s));
+            HIPCHK(e, launch_from_time_major(ts->gin, B, M, T, Mp, grad_x, s));
+        }
+        ConvGemmArgs a = cargs(e, ts->incT, N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out16 = ts->g16a;     // d cond (16 bit)
+        HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+    }
+    {   // cond prenet
+        const DropCfg nodrop = make_drop(0.f, 0, 0);
+        WgradOut o2 = {G(ts, "cond_proj.4.weight"), F, 0, F, 0, C, G(ts, "cond_proj.4.bias")};
+        if ((rc = wgrad(e, ts, ts->p2, F, nullptr, 0, ts->g16a, C, K, &o2, 1, s))) return rc;
+        ConvGemmArgs a = cargs(e, ts->preT[2], N, T, B); a.a0 = ts->g16a; a.c0 = C; a.out32 = ts->tmpF;
+        HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a2, nullptr, 1, T, F, R, nodrop, ts->g16a, s));
+        WgradOut o1 = {G(ts, "cond_proj.2.weight"), F, 0, F, 0, F, G(ts, "cond_proj.2.bias")};
+        if ((rc = wgrad(e, ts, ts->p1, F, nullptr, 0, ts->g16a, F, K, &o1, 1, s))) return rc;
+        a = cargs(e, ts->preT[1], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->tmpF;
+        HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a1, nullptr, 1, T, F, R, nodrop, ts->g16a, s));
+        WgradOut o0 = {G(ts, "cond_proj.0.weight"), M, 0, M, 0, F, G(ts, "cond_proj.0.bias")};
+        if ((rc = wgrad(e, ts, ts->mu16, Mp, nullptr, 0, ts->g16a, F, K, &o0, 1, s))) return rc;
+        if (grad_mu) {
+            a = cargs(e, ts->preT[0], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->gin;
+            HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+            HIPCHK(e, launch_unscale_inplace(ts->gin, R * Mp, ts->gsc, s));
+            HIPCHK(e, launch_from_time_major(ts->gin, B, M, T, Mp, grad_mu, s));
+        }
+    }
+    // ---- per-item vectors: adaLN (-> d c), FiLM (-> d tau), time MLP
+    HIPCHK(e, hipMemsetAsync(ts->dcvec, 0, (size_t)N * C * 4, s));
+    HIPCHK(e, hipMemsetAsync(ts->dtau, 0, (size_t)N * C * 4, s));
+    for (int i = 0; i < L; ++i) {
+        const std::string pa = e->blk(i) + "adaLN_modulation.2.";
+        float* gw = G(ts, pa + "weight"); float* gb = G(ts, pa + "bias");
+        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)6 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)6 * C * 4, s));
+        const float* dout = ts->dada + (size_t)i * N * 6 * C;
+        HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, s));
+        HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, 1, s));
+        const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
+        gw = G(ts, pf + "weight"); gb = G(ts, pf + "bias");
+        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)2 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)2 * C * 4, s));
+        const float* dfo = ts->dfilm + (size_t)i * N * 2 * C;
+        HIPCHK(e, launch_linear_bwd_w(ts->tau, dfo, N, C, 2 * C, 0, gw, gb, s));
+        HIPCHK(e, launch_linear_bwd_in(ts->tau, dfo, P(e, pf + "weight"), N, C, 2 * C, 0, ts->dtau, 1, s));
+    }
+    HIPCHK(e, launch_linear_bwd_w(ts->th_pre, ts->dtau, N, F, C, 1, G(ts, "time_mlp.layer.2.weight"), G(ts, "time_mlp.layer.2.bias"), s));
+    HIPCHK(e, launch_linear_bwd_in(ts->th_pre, ts->dtau, P(e, "time_mlp.layer.2.weight"), N, F, C, 1, ts->dth, 0, s));
+    HIPCHK(e, launch_linear_bwd_w(ts->emb, ts->dth, N, C, F, 0, G(ts, "time_mlp.layer.0.weight"), G(ts, "time_mlp.layer.0.bias"), s));
+    if (grad_c) HIPCHK(e, hipMemcpyAsync(grad_c, ts->dcvec, (size_t)N * C * 4, hipMemcpyDeviceToDevice, s));
+    return ST_OK;
+}
+
+int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, void* stream) {
+    if (!e || !name || !dst) return ST_ERR_INVALID;
+    if (!e->train) return e->fail(ST_ERR_STATE, "no training state");
+    auto it = e->train->grads.find(name);
+    auto pit = e->params.find(name);
+    if (it == e->train->grads.end() || pit == e->params.end()) return e->fail(ST_ERR_INVALID, std::string("unknown parameter: ") + name);
+    if (pit->second.numel() != numel) return e->fail(ST_ERR_INVALID, std::string("size mismatch for gradient of ") + name);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(dst, it->second, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ST_OK;
+}
+
+}  // extern "C"

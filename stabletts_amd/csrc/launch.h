@@ -20,7 +20,8 @@ struct ConvGemmArgs {
     int c2;                           // further K channels that re-read a0 from its channel 0 (split-precision operands:
                                       // K = [a0 | a1 | a0] against packed weights [W_hi | W_hi | W_lo]); gen-2 kernels only
     int a0_mod, a1_mod;               // activation item of output item n is n % mod
-    const void* w;                    // packed weights [cout][TAPS][c0 + c1], 16-bit
+    const void* w;                    // packed weights [cout][TAPS][c0 + c1 + c2], 16-bit
+    long long w_item_stride;          // bytes added to w per output item (0: shared weights; weight-gradient GEMMs use it)
     const float* bias;                // [cout] or nullptr
     int cout, T, n_items;
     int tiles_f, tiles_c;             // frame tiles per item, channel tiles
@@ -53,6 +54,11 @@ hipError_t launch_conv_gemm2_f16(int cfg, int taps, int epi, const ConvGemmArgs&
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 
+// ---------------------------------------------------------------- counter-based dropout (training; shared by forward and backward)
+// keep(seed, idx) = hash(seed, idx) >= thresh (= p * 2^32); kept values are scaled by 1 / (1 - p) like nn.Dropout and
+// SDPA's dropout_p.  thresh == 0: dropout off.
+struct DropCfg { unsigned long long seed; unsigned thresh; float scale; };
+
 // ---------------------------------------------------------------- attention
 struct AttnArgs {
     const void* q; const void* k; const void* vt; void* out;   // out: [item][T][H*64] 16-bit
@@ -60,6 +66,8 @@ struct AttnArgs {
     const int* kv_end; const int* n_full;  // per mask row: last valid key + 1, leading valid prefix length
     int T, Tp, H, n_items;
     const void* zeros;                     // >= 16 zero bytes in global memory (out-of-range K rows)
+    float* lse;                            // training: [item][H][T] log2-sum-exp of the scores (nullptr: inference kernel)
+    DropCfg drop;                          // training: dropout on the attention probabilities (diffusion_transformer.py:77)
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 

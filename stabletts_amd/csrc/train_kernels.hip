@@ -1,0 +1,554 @@
+// Training-only memory-bound kernels (gfx950): forward pieces that keep activations, backward of FiLM /
+// LayerNorm+adaLN / gated residual / SiLU+dropout, per-item channel reductions, the operand transposes that
+// turn the weight gradient into a call of the forward implicit-GEMM kernel, dgrad weight packing and the small
+// fp32 linears.  All fp32 arithmetic; 16-bit tensors are MFMA operands only.
+#include "common.h"
+#include "train_launch.h"
+
+namespace st {
+
+// ------------------------------------------------------------------------------------------ dropout configuration
+DropCfg make_drop(float p, unsigned long long seed, int salt) {
+    DropCfg d;
+    d.seed = seed * 0x100000001B3ull + (unsigned long long)(salt + 1) * 0xD6E8FEB86659FD93ull;
+    if (!(p > 0.f)) { d.thresh = 0; d.scale = 1.0f; return d; }
+    const double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (d.thresh == 0) d.thresh = 1;
+    d.scale = 1.0f / (1.0f - p);
+    return d;
+}
+
+__device__ __forceinline__ float silu_grad(float a) {      // d/da [a * sigmoid(a)] = s * (1 + a * (1 - s))
+    const float s = 1.0f / (1.0f + expf(-a));
+    return s * (1.0f + a * (1.0f - s));
+}
+
+template <class P>
+__device__ __forceinline__ float4 load4_16(const void* p) {
+    typedef __attribute__((ext_vector_type(4))) typename P::elem v4;
+    const v4 v = *(const v4*)p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+// ------------------------------------------------------------------------------------------ forward: FiLM / residual / LayerNorm
+template <class P>
+__global__ __launch_bounds__(256) void train_ln_kernel(const TrainLnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+        const int n = row / a.T, t = row - n * a.T;
+        const float m = a.mask ? a.mask[(size_t)(n % a.mask_mod) * a.T + t] : 1.0f;
+        const size_t o = (size_t)row * 256 + lane * 4;
+        float4 x = *(const float4*)(a.xin + o);
+        if (a.film) {
+            const float* f = a.film + (size_t)(n % a.film_mod) * a.film_stride + lane * 4;
+            const float4 ga = *(const float4*)f, be = *(const float4*)(f + 256);
+            x.x = (ga.x * x.x + be.x) * m; x.y = (ga.y * x.y + be.y) * m;
+            x.z = (ga.z * x.z + be.z) * m; x.w = (ga.w * x.w + be.w) * m;
+        } else if (a.gate) {
+            const float4 g = *(const float4*)(a.gate + (size_t)n * a.gate_stride + lane * 4);
+            const float4 b = *(const float4*)(a.branch + o);
+            x.x += g.x * b.x; x.y += g.y * b.y; x.z += g.z * b.z; x.w += g.w * b.w;
+        }
+        if (a.xout) *(float4*)(a.xout + o) = x;
+        if (a.x16) *(uint2*)((unsigned char*)a.x16 + o * 2) = pack4<P>(x.x, x.y, x.z, x.w);
+        if (a.x16lo)
+            *(uint2*)((unsigned char*)a.x16lo + o * 2) = pack4<P>(x.x - (float)to16<P>(x.x), x.y - (float)to16<P>(x.y),
+                                                                 x.z - (float)to16<P>(x.z), x.w - (float)to16<P>(x.w));
+        if (a.h16) {
+            const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / 256.0f);
+            const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+            const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            const float* ad = a.ada + (size_t)n * a.ada_stride + lane * 4;
+            const float4 sh = *(const float4*)(ad + a.shift_off), sc = *(const float4*)(ad + a.scale_off);
+            const float mm = a.mask_out ? m : 1.0f;
+            *(uint2*)((unsigned char*)a.h16 + o * 2) =
+                pack4<P>((d0 * rstd * (1.0f + sc.x) + sh.x) * mm, (d1 * rstd * (1.0f + sc.y) + sh.y) * mm,
+                         (d2 * rstd * (1.0f + sc.z) + sh.z) * mm, (d3 * rstd * (1.0f + sc.w) + sh.w) * mm);
+        }
+    }
+}
+
+hipError_t launch_train_ln(int dtype, const TrainLnArgs& a, hipStream_t s) {
+    int grid = (a.rows + 3) / 4;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (grid < 1) grid = 1;
+    if (dtype == DT_BF16) hipLaunchKernelGGL((train_ln_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL((train_ln_kernel<OpF16>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ forward: SiLU (+ dropout, mask)
+template <class P>
+__global__ __launch_bounds__(256) void silu_drop_kernel(const typename P::elem* a16, typename P::elem* u16, const float* mask,
+                                                        int mask_mod, int T, int F, int64_t rows, DropCfg drop) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * F) return;
+    const int64_t row = i / F;
+    float m = 1.0f;
+    if (mask) { const int64_t n = row / T; m = mask[(size_t)(n % mask_mod) * T + (row - n * T)]; }
+    const float4 a = load4_16<P>(a16 + i);
+    const float v0 = silu_f(a.x) * drop_factor(drop, (unsigned)i, (unsigned)(i >> 32)) * m;
+    const float v1 = silu_f(a.y) * drop_factor(drop, (unsigned)i + 1u, (unsigned)(i >> 32)) * m;
+    const float v2 = silu_f(a.z) * drop_factor(drop, (unsigned)i + 2u, (unsigned)(i >> 32)) * m;
+    const float v3 = silu_f(a.w) * drop_factor(drop, (unsigned)i + 3u, (unsigned)(i >> 32)) * m;
+    *(uint2*)(u16 + i) = pack4<P>(v0, v1, v2, v3);
+}
+
+hipError_t launch_silu_drop(int dtype, const void* a16, void* u16, const float* mask, int mask_mod, int T, int F,
+                            int64_t rows, DropCfg drop, hipStream_t s) {
+    const int64_t n4 = rows * F / 4;
+    const int grid = (int)((n4 + 255) / 256);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((silu_drop_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, (const __bf16*)a16, (__bf16*)u16, mask, mask_mod, T, F, rows, drop);
+    else
+        hipLaunchKernelGGL((silu_drop_kernel<OpF16>), dim3(grid), dim3(256), 0, s, (const _Float16*)a16, (_Float16*)u16, mask, mask_mod, T, F, rows, drop);
+    return hipGetLastError();
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* dU, const typename P::elem* a16, const float* mask,
+                                                       int mask_mod, int T, int F, int64_t rows, DropCfg drop,
+                                                       typename P::elem* dA16) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * F) return;
+    const int64_t row = i / F;
+    float m = 1.0f;
+    if (mask) { const int64_t n = row / T; m = mask[(size_t)(n % mask_mod) * T + (row - n * T)]; }
+    const float4 a = load4_16<P>(a16 + i);
+    const float4 g = *(const float4*)(dU + i);
+    *(uint2*)(dA16 + i) = pack4<P>(g.x * m * drop_factor(drop, (unsigned)i, (unsigned)(i >> 32)) * silu_grad(a.x),
+                                   g.y * m * drop_factor(drop, (unsigned)i + 1u, (unsigned)(i >> 32)) * silu_grad(a.y),
+                                   g.z * m * drop_factor(drop, (unsigned)i + 2u, (unsigned)(i >> 32)) * silu_grad(a.z),
+                                   g.w * m * drop_factor(drop, (unsigned)i + 3u, (unsigned)(i >> 32)) * silu_grad(a.w));
+}
+
+hipError_t launch_silu_bwd(int dtype, const float* dU, const void* a16, const float* mask, int mask_mod, int T, int F,
+                           int64_t rows, DropCfg drop, void* dA16, hipStream_t s) {
+    const int64_t n4 = rows * F / 4;
+    const int grid = (int)((n4 + 255) / 256);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((silu_bwd_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, dU, (const __bf16*)a16, mask, mask_mod, T, F, rows, drop, (__bf16*)dA16);
+    else
+        hipLaunchKernelGGL((silu_bwd_kernel<OpF16>), dim3(grid), dim3(256), 0, s, dU, (const _Float16*)a16, mask, mask_mod, T, F, rows, drop, (_Float16*)dA16);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ backward: per-item channel sums
+// Block = one item x one chunk of kRedRows frames, 4 waves; wave w takes frames chunk*kRedRows + w, +4, ...
+// K running sums per lane (4 channels each); combined over the 4 waves through LDS; written to part[n][chunk][k][256].
+template <int K>
+__device__ __forceinline__ void store_parts(float4 (&acc)[K], float* part, int n, int chunk, int chunks) {
+    __shared__ float4 red[4][K][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wave][k][lane] = acc[k];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float4 v = red[0][k][lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 u = red[w][k][lane];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            *(float4*)(part + (((size_t)n * chunks + chunk) * K + k) * 256 + lane * 4) = v;
+        }
+    }
+}
+
+struct RedOff { int off[4]; };
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int chunks, int K, float* out, int out_stride,
+                                                            RedOff off, int accumulate, const float* unscale) {
+    const int k = blockIdx.x, n = blockIdx.y, ch = threadIdx.x;
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += part[(((size_t)n * chunks + c) * K + k) * 256 + ch];
+    if (unscale) v *= unscale[1];
+    float* dst = out + (size_t)n * out_stride + off.off[k] + ch;
+    *dst = accumulate ? *dst + v : v;
+}
+
+hipError_t launch_reduce_parts(const float* part, int n_items, int chunks, int K, float* out, int out_stride,
+                               const int* out_off, int accumulate, const float* unscale, hipStream_t s) {
+    if (K < 1 || K > 4) return hipErrorInvalidValue;
+    RedOff off;
+    for (int k = 0; k < 4; ++k) off.off[k] = k < K ? out_off[k] : 0;     // out_off is a HOST array
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(K, n_items), dim3(256), 0, s, part, chunks, K, out, out_stride, off, accumulate, unscale);
+    return hipGetLastError();
+}
+
+// x_out = x_in + gate * branch
+template <class P>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* dX, const float* branch, const float* gate, int gate_stride,
+                                                       const float* mask, int mask_mod, int T, typename P::elem* dB16,
+                                                       float* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, n = blockIdx.y, chunks = gridDim.x;
+    const float4 g = *(const float4*)(gate + (size_t)n * gate_stride + lane * 4);
+    float4 acc[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int t = chunk * kRedRows + wave; t < T && t < (chunk + 1) * kRedRows; t += 4) {
+        const size_t o = ((size_t)n * T + t) * 256 + lane * 4;
+        const float m = mask ? mask[(size_t)(n % mask_mod) * T + t] : 1.0f;
+        const float4 d = *(const float4*)(dX + o);
+        const float4 b = *(const float4*)(branch + o);
+        acc[0].x += d.x * b.x; acc[0].y += d.y * b.y; acc[0].z += d.z * b.z; acc[0].w += d.w * b.w;
+        *(uint2*)(dB16 + o) = pack4<P>(d.x * g.x * m, d.y * g.y * m, d.z * g.z * m, d.w * g.w * m);
+    }
+    store_parts<1>(acc, part, n, chunk, chunks);
+}
+
+hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, const float* gate, int gate_stride,
+                           const float* mask, int mask_mod, int T, int n_items, void* dB16, float* part, hipStream_t s) {
+    dim3 grid(red_chunks(T), n_items);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((gate_bwd_kernel<OpBF16>), grid, dim3(256), 0, s, dX, branch, gate, gate_stride, mask, mask_mod, T, (__bf16*)dB16, part);
+    else
+        hipLaunchKernelGGL((gate_bwd_kernel<OpF16>), grid, dim3(256), 0, s, dX, branch, gate, gate_stride, mask, mask_mod, T, (_Float16*)dB16, part);
+    return hipGetLastError();
+}
+
+// h = (LN(x) * (1 + sc) + sh) [* mask]
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float* dH, const float* ada, int ada_stride,
+                                                     int scale_off, const float* mask, int mask_mod, int mask_out, int T,
+                                                     float* dX, float* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, n = blockIdx.y, chunks = gridDim.x;
+    const float4 sc = *(const float4*)(ada + (size_t)n * ada_stride + scale_off + lane * 4);
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int t = chunk * kRedRows + wave; t < T && t < (chunk + 1) * kRedRows; t += 4) {
+        const size_t o = ((size_t)n * T + t) * 256 + lane * 4;
+        const float mm = (mask_out && mask) ? mask[(size_t)(n % mask_mod) * T + t] : 1.0f;
+        const float4 xv = *(const float4*)(x + o);
+        float4 g = *(const float4*)(dH + o);
+        g.x *= mm; g.y *= mm; g.z *= mm; g.w *= mm;
+        const float mean = wave_sum(xv.x + xv.y + xv.z + xv.w) * (1.0f / 256.0f);
+        const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float n0 = d0 * rstd, n1 = d1 * rstd, n2 = d2 * rstd, n3 = d3 * rstd;
+        acc[0].x += g.x * n0; acc[0].y += g.y * n1; acc[0].z += g.z * n2; acc[0].w += g.w * n3;     // d scale
+        acc[1].x += g.x; acc[1].y += g.y; acc[1].z += g.z; acc[1].w += g.w;                         // d shift
+        const float e0 = g.x * (1.0f + sc.x), e1 = g.y * (1.0f + sc.y), e2 = g.z * (1.0f + sc.z), e3 = g.w * (1.0f + sc.w);
+        const float m1 = wave_sum(e0 + e1 + e2 + e3) * (1.0f / 256.0f);
+        const float m2 = wave_sum(e0 * n0 + e1 * n1 + e2 * n2 + e3 * n3) * (1.0f / 256.0f);
+        float4 d = *(const float4*)(dX + o);
+        d.x += rstd * (e0 - m1 - n0 * m2); d.y += rstd * (e1 - m1 - n1 * m2);
+        d.z += rstd * (e2 - m1 - n2 * m2); d.w += rstd * (e3 - m1 - n3 * m2);
+        *(float4*)(dX + o) = d;
+    }
+    store_parts<2>(acc, part, n, chunk, chunks);
+}
+
+hipError_t launch_ln_bwd(const float* x, const float* dH, const float* ada, int ada_stride, int scale_off,
+                         const float* mask, int mask_mod, int mask_out, int T, int n_items, float* dX, float* part,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(red_chunks(T), n_items), dim3(256), 0, s, x, dH, ada, ada_stride, scale_off,
+                       mask, mask_mod, mask_out, T, dX, part);
+    return hipGetLastError();
+}
+
+// x = (gamma * xpre + beta) * mask
+template <class P>
+__global__ __launch_bounds__(256) void film_bwd_kernel(const float* xpre, const float* film, int film_stride, int film_mod,
+                                                       const float* mask, int mask_mod, int T, float* dX,
+                                                       typename P::elem* dX16, float* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, n = blockIdx.y, chunks = gridDim.x;
+    const float4 ga = *(const float4*)(film + (size_t)(n % film_mod) * film_stride + lane * 4);
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int t = chunk * kRedRows + wave; t < T && t < (chunk + 1) * kRedRows; t += 4) {
+        const size_t o = ((size_t)n * T + t) * 256 + lane * 4;
+        const float m = mask ? mask[(size_t)(n % mask_mod) * T + t] : 1.0f;
+        float4 d = *(const float4*)(dX + o);
+        d.x *= m; d.y *= m; d.z *= m; d.w *= m;
+        const float4 xp = *(const float4*)(xpre + o);
+        acc[0].x += d.x * xp.x; acc[0].y += d.y * xp.y; acc[0].z += d.z * xp.z; acc[0].w += d.w * xp.w;   // d gamma
+        acc[1].x += d.x; acc[1].y += d.y; acc[1].z += d.z; acc[1].w += d.w;                               // d beta
+        d.x *= ga.x; d.y *= ga.y; d.z *= ga.z; d.w *= ga.w;
+        *(float4*)(dX + o) = d;
+        if (dX16) *(uint2*)(dX16 + o) = pack4<P>(d.x, d.y, d.z, d.w);
+    }
+    store_parts<2>(acc, part, n, chunk, chunks);
+}
+
+hipError_t launch_film_bwd(int dtype, const float* xpre, const float* film, int film_stride, int film_mod,
+                           const float* mask, int mask_mod, int T, int n_items, float* dX, void* dX16, float* part,
+                           hipStream_t s) {
+    dim3 grid(red_chunks(T), n_items);
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((film_bwd_kernel<OpBF16>), grid, dim3(256), 0, s, xpre, film, film_stride, film_mod, mask, mask_mod, T, dX, (__bf16*)dX16, part);
+    else
+        hipLaunchKernelGGL((film_bwd_kernel<OpF16>), grid, dim3(256), 0, s, xpre, film, film_stride, film_mod, mask, mask_mod, T, dX, (_Float16*)dX16, part);
+    return hipGetLastError();
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void cast16_kernel(const float* x, const float* mask, int mask_mod, int T, int C, int64_t rows,
+                                                     const float* scale, typename P::elem* y16) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= rows * C) return;
+    float m = scale ? scale[0] : 1.0f;
+    if (mask) { const int64_t row = i / C, n = row / T; m *= mask[(size_t)(n % mask_mod) * T + (row - n * T)]; }
+    const float4 v = *(const float4*)(x + i);
+    *(uint2*)(y16 + i) = pack4<P>(v.x * m, v.y * m, v.z * m, v.w * m);
+}
+
+hipError_t launch_cast16(int dtype, const float* x, const float* mask, int mask_mod, int T, int C, int64_t rows,
+                         const float* scale, void* y16, hipStream_t s) {
+    const int64_t n4 = rows * C / 4;
+    const int grid = (int)((n4 + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((cast16_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, x, mask, mask_mod, T, C, rows, scale, (__bf16*)y16);
+    else                  hipLaunchKernelGGL((cast16_kernel<OpF16>), dim3(grid), dim3(256), 0, s, x, mask, mask_mod, T, C, rows, scale, (_Float16*)y16);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ gradient scaling
+// 16-bit gradient operands need the dynamic range of the incoming gradient placed inside the operand type's: f16 has
+// 5 exponent bits (normal >= 6e-5) while d loss / d out is ~1 / (sum(mask) * n_feats) per element.  The whole backward
+// pass is linear in d loss / d out, so it is multiplied by a power of two on entry (max |g| -> ~2^8) and every fp32
+// result is multiplied by the inverse where it leaves the pass.  sc[0] = scale, sc[1] = 1 / scale (on the device: no
+// host synchronisation).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, int64_t n, unsigned* out_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        if (v == v && v < 3.0e38f) m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));        // non-negative floats order like their bits
+}
+__global__ void grad_scale_kernel(const unsigned* bits, float* sc) {
+    const float m = __uint_as_float(*bits);
+    float s = 1.0f;
+    if (m > 0.f) {
+        int ex = 8 - (int)floorf(log2f(m));           // max |g| * scale in [2^8, 2^9)
+        ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+        s = exp2f((float)ex);
+    }
+    sc[0] = s; sc[1] = 1.0f / s;
+}
+hipError_t launch_grad_scale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(bits, 0, 4, s);
+    if (e != hipSuccess) return e;
+    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, g, n, bits);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, s, bits, sc);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* a, int64_t n, const float* sc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] *= sc[1];
+}
+hipError_t launch_unscale_inplace(float* a, int64_t n, const float* sc, hipStream_t s) {
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, sc);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* a, const float* b, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 x = *(const float4*)(a + i);
+    const float4 y = *(const float4*)(b + i);
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    *(float4*)(a + i) = x;
+}
+hipError_t launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((int)((n / 4 + 255) / 256)), dim3(256), 0, s, a, b, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ wgrad operand transposes
+// XT[s][j*Cin + ci][rl] = X[n][t + j - taps/2][ci] for the global row r = s*Rs + rl = n*T + t (zero when r >= N*T or
+// the shifted frame leaves the item).  Block: 64 rows x 64 channels, through LDS (66 rows with the halo).
+template <class P>
+__global__ __launch_bounds__(256) void wgrad_xt_kernel(const typename P::elem* x0, int c0, const typename P::elem* x1, int c1,
+                                                       int n_items, int T, int taps, int Rs, typename P::elem* xt) {
+    __shared__ typename P::elem tile[66][64 + 2];
+    const int cin = c0 + c1;
+    const int64_t R = (int64_t)n_items * T;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;        // first padded-global row of the block: (s, rl0)
+    const int sidx = (int)(r0 / Rs), rl0 = (int)(r0 % Rs);
+    const int64_t g0 = (int64_t)sidx * Rs + rl0;         // == r0: rows are numbered contiguously across splits
+    const int ch0 = blockIdx.y * 64;
+    const typename P::elem* src; int cs, coff;
+    if (ch0 < c0) { src = x0; cs = c0; coff = ch0; } else { src = x1; cs = c1; coff = ch0 - c0; }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 channels x 4 rows per pass
+    for (int rr = ty; rr < 66; rr += 4) {
+        const int64_t r = g0 + rr - 1;                           // LDS row rr holds global row g0 + rr - 1
+        typename P::elem v = (typename P::elem)0.0f;
+        if (r >= 0 && r < R) v = src[(size_t)r * cs + coff + tx];
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    // output: for tap j, channel c (64), column rl (64): value = X[row g0 + rl + j - taps/2] if same item & valid
+    const int half = taps / 2;
+    for (int j = 0; j < taps; ++j)
+        for (int c = ty; c < 64; c += 4) {
+            const int rl = tx;
+            const int64_t r = g0 + rl;                           // the row this column stands for (n, t)
+            typename P::elem v = (typename P::elem)0.0f;
+            if (r < R) {
+                const int t = (int)(r % T) + j - half;
+                if (t >= 0 && t < T) v = tile[rl + 1 + j - half][c];
+            }
+            xt[((size_t)sidx * taps * cin + (size_t)j * cin + ch0 + c) * Rs + rl0 + rl] = v;
+        }
+}
+
+hipError_t launch_wgrad_xt(int dtype, const void* x0, int c0, const void* x1, int c1, int n_items, int T, int taps,
+                           int S, int Rs, void* xt, hipStream_t s) {
+    if ((c0 & 63) || (c1 & 63) || (Rs & 63)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((int64_t)S * Rs / 64), (unsigned)((c0 + c1) / 64));
+    if (dtype == DT_BF16)
+        hipLaunchKernelGGL((wgrad_xt_kernel<OpBF16>), grid, dim3(256), 0, s, (const __bf16*)x0, c0, (const __bf16*)x1, c1, n_items, T, taps, Rs, (__bf16*)xt);
+    else
+        hipLaunchKernelGGL((wgrad_xt_kernel<OpF16>), grid, dim3(256), 0, s, (const _Float16*)x0, c0, (const _Float16*)x1, c1, n_items, T, taps, Rs, (_Float16*)xt);
+    return hipGetLastError();
+}
+
+// dYT[s][co][rl] = dY[r = s*Rs + rl][co] (zero for r >= R);  part_b[rowblock][co] = sum over the block's 64 rows
+template <class P>
+__global__ __launch_bounds__(256) void wgrad_dyt_kernel(const typename P::elem* dy, int cout, int64_t R, int Rs,
+                                                        typename P::elem* dyt, float* part_b) {
+    __shared__ typename P::elem tile[64][64 + 2];
+    __shared__ float colsum[4][64];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int sidx = (int)(r0 / Rs), rl0 = (int)(r0 % Rs);
+    const int ch0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float cs = 0.f;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int64_t r = r0 + rr;
+        typename P::elem v = (typename P::elem)0.0f;
+        if (r < R) v = dy[(size_t)r * cout + ch0 + tx];
+        tile[rr][tx] = v;
+        cs += (float)v;
+    }
+    colsum[ty][tx] = cs;
+    __syncthreads();
+    if (ty == 0 && part_b) part_b[(size_t)blockIdx.x * cout + ch0 + tx] = colsum[0][tx] + colsum[1][tx] + colsum[2][tx] + colsum[3][tx];
+    for (int c = ty; c < 64; c += 4)
+        dyt[((size_t)sidx * cout + ch0 + c) * Rs + rl0 + tx] = tile[tx][c];
+}
+
+hipError_t launch_wgrad_dyt(int dtype, const void* dy, int cout, int64_t R, int S, int Rs, void* dyt, float* part_b,
+                            hipStream_t s) {
+    if ((cout & 63) || (Rs & 63)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((int64_t)S * Rs / 64), (unsigned)(cout / 64));
+    if (dtype == DT_BF16) hipLaunchKernelGGL((wgrad_dyt_kernel<OpBF16>), grid, dim3(256), 0, s, (const __bf16*)dy, cout, R, Rs, (__bf16*)dyt, part_b);
+    else                  hipLaunchKernelGGL((wgrad_dyt_kernel<OpF16>), grid, dim3(256), 0, s, (const _Float16*)dy, cout, R, Rs, (_Float16*)dyt, part_b);
+    return hipGetLastError();
+}
+
+// dW[co - co_start][ci_off + ci][j] = sum_s partial[s][j*cin + ci][co]  for co in [co_start, co_start + co_cnt), ci < ci_cnt
+// (partial: [S][taps*cin][cout] fp32; dW: reference layout (co_cnt, cin_total, taps))
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int S, int cin, int cout, int taps, float* dW,
+                                                           int cin_total, int ci_off, int ci_cnt, int co_start, int co_cnt,
+                                                           const float* unscale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (j*cin + ci) x co, co fastest
+    const int64_t total = (int64_t)taps * cin * cout;
+    if (idx >= total) return;
+    const int co = (int)(idx % cout);
+    const int jc = (int)(idx / cout);
+    const int j = jc / cin, ci = jc % cin;
+    if (ci >= ci_cnt || co < co_start || co >= co_start + co_cnt) return;
+    float v = 0.f;
+    for (int sI = 0; sI < S; ++sI) v += partial[(size_t)sI * total + idx];
+    if (unscale) v *= unscale[1];
+    dW[((size_t)(co - co_start) * cin_total + ci_off + ci) * taps + j] = v;
+}
+
+hipError_t launch_wgrad_reduce(const float* partial, int S, int cin, int cout, int taps, float* dW, int cin_total,
+                               int ci_off, int ci_cnt, int co_start, int co_cnt, const float* unscale, hipStream_t s) {
+    const int64_t total = (int64_t)taps * cin * cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, S, cin, cout, taps,
+                       dW, cin_total, ci_off, ci_cnt, co_start, co_cnt, unscale);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* part_b, int rowblocks, int cout, float* db, int co_start,
+                                                          int co_cnt, const float* unscale) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= cout || co < co_start || co >= co_start + co_cnt) return;
+    float v = 0.f;
+    for (int rb = 0; rb < rowblocks; ++rb) v += part_b[(size_t)rb * cout + co];
+    if (unscale) v *= unscale[1];
+    db[co - co_start] = v;
+}
+
+hipError_t launch_bias_reduce(const float* part_b, int rowblocks, int cout, float* db, int co_start, int co_cnt,
+                              const float* unscale, hipStream_t s) {
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, part_b, rowblocks, cout, db, co_start, co_cnt, unscale);
+    return hipGetLastError();
+}
+
+// dgrad weights: Wd[ci][j][col_off + co] = W[co][ci_off + ci][taps - 1 - j]; rows ci >= ci_cnt and columns co >= cout stay zero
+template <class P>
+__global__ void pack_weight_t_kernel(const float* src, int cout, int cin_total, int taps, int ci_off, int ci_cnt,
+                                     typename P::elem* dst, int ld, int col_off) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)ci_cnt * taps * cout;
+    if (idx >= total) return;
+    const int co = (int)(idx % cout);
+    const int j = (int)((idx / cout) % taps);
+    const int ci = (int)(idx / ((size_t)cout * taps));
+    const float v = src[((size_t)co * cin_total + ci_off + ci) * taps + (taps - 1 - j)];
+    dst[((size_t)ci * taps + j) * ld + col_off + co] = to16<P>(v);
+}
+
+hipError_t launch_pack_weight_t(int dtype, const float* src, int cout, int cin_total, int taps, int ci_off, int ci_cnt,
+                                void* dst, int cin_p, int ld, int col_off, hipStream_t s) {
+    (void)cin_p;
+    const size_t total = (size_t)ci_cnt * taps * cout;
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((pack_weight_t_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, taps, ci_off, ci_cnt, (__bf16*)dst, ld, col_off);
+    else                  hipLaunchKernelGGL((pack_weight_t_kernel<OpF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, taps, ci_off, ci_cnt, (_Float16*)dst, ld, col_off);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ small fp32 linears: backward
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* in, const float* dout, int n, int k, int o, int silu_in,
+                                                           float* dW, float* db) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over o x k, k fastest
+    if (idx >= (int64_t)o * k) return;
+    const int ki = (int)(idx % k), oi = (int)(idx / k);
+    float acc = 0.f, accb = 0.f;
+    for (int ni = 0; ni < n; ++ni) {
+        float x = in[(size_t)ni * k + ki];
+        if (silu_in) x = silu_f(x);
+        const float d = dout[(size_t)ni * o + oi];
+        acc += d * x; accb += d;
+    }
+    dW[idx] += acc;
+    if (ki == 0 && db) db[oi] += accb;
+}
+
+hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k, int o, int silu_in, float* dW, float* db,
+                               hipStream_t s) {
+    const int64_t total = (int64_t)o * k;
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, dout, n, k, o, silu_in, dW, db);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_in_kernel(const float* in, const float* dout, const float* W, int n, int k, int o,
+                                                            int silu_in, float* din, int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over n x k
+    if (idx >= (int64_t)n * k) return;
+    const int ki = (int)(idx % k), ni = (int)(idx / k);
+    float acc = 0.f;
+    for (int oi = 0; oi < o; ++oi) acc += dout[(size_t)ni * o + oi] * W[(size_t)oi * k + ki];
+    if (silu_in) acc *= silu_grad(in[idx]);
+    din[idx] = accumulate ? din[idx] + acc : acc;
+}
+
+hipError_t launch_linear_bwd_in(const float* in, const float* dout, const float* W, int n, int k, int o, int silu_in,
+                                float* din, int accumulate, hipStream_t s) {
+    const int64_t total = (int64_t)n * k;
+    hipLaunchKernelGGL(linear_bwd_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, dout, W, n, k, o, silu_in, din, accumulate);
+    return hipGetLastError();
+}
+
+}  // namespace st

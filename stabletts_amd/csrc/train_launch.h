@@ -1,0 +1,138 @@
+// Launcher interface of the training-only kernels (train_kernels.hip, attention_bwd.hip): the forward pieces
+// that keep activations, the backward elementwise / reduction kernels, the operand transposes that turn the
+// weight gradient into a call of the forward implicit-GEMM kernel, and flash-attention backward.
+// Reference: autograd through models/estimator.py:103-138 and models/diffusion_transformer.py:25-121 as driven by
+// CFMDecoder.compute_loss (models/flow_matching.py:69-100) under train.py:78-81.
+#pragma once
+#include "launch.h"
+
+namespace st {
+
+// DropCfg of one dropout site (salt = site index: FFN / attention of block i) for probability p
+DropCfg make_drop(float p, unsigned long long seed, int salt);
+
+// ---------------------------------------------------------------- forward pieces (one frame per wave, lane = 4 channels, C = 256)
+// x = FiLM:  (gamma * xin + beta) * mask      (estimator.py:16,31-33)
+//     RES :  xin + gate * branch              (diffusion_transformer.py:111-112; branch already masked)
+//     else:  xin
+// writes xout (fp32), optional 16-bit copies x16 (+ rounding residual x16lo), and, when h16 != nullptr,
+// h16 = (LayerNorm(x) * (1 + scale) + shift) [* mask if mask_out]
+struct TrainLnArgs {
+    const float* xin; float* xout; void* x16; void* x16lo; void* h16;
+    const float* film; int film_stride; int film_mod;
+    const float* gate; int gate_stride; const float* branch;
+    const float* ada; int ada_stride; int shift_off; int scale_off;
+    const float* mask; int mask_mod; int mask_out;
+    int T, rows;
+};
+hipError_t launch_train_ln(int dtype, const TrainLnArgs& a, hipStream_t s);
+
+// u16 = dropout(SiLU(a16)) * mask   over [rows][F]   (FFN: diffusion_transformer.py:26-28; prenet: mask == nullptr)
+hipError_t launch_silu_drop(int dtype, const void* a16, void* u16, const float* mask, int mask_mod, int T, int F,
+                            int64_t rows, DropCfg drop, hipStream_t s);
+
+// ---------------------------------------------------------------- backward elementwise + per-item channel reductions
+// Every kernel below walks blocks of kRedRows frames of one item; per-(item, channel) sums are accumulated in
+// registers (a lane owns the same 4 channels for every frame), combined per block and written to
+// part[item][chunk][k][256]; launch_reduce_parts adds the chunks in order (deterministic, no atomics).
+constexpr int kRedRows = 32;
+inline int red_chunks(int T) { return (T + kRedRows - 1) / kRedRows; }
+// out[n][k][256] (+)= sum_chunk part[n][chunk][k][256]
+hipError_t launch_reduce_parts(const float* part, int n_items, int chunks, int K, float* out, int out_stride,
+                               const int* out_off, int accumulate, const float* unscale, hipStream_t s);
+
+// Gradient scaling (see train_kernels.hip): sc[0] = power-of-two scale that puts max |g| at ~2^8, sc[1] = 1 / sc[0].
+// Kernels that take `scale` multiply by sc[0]; kernels that take `unscale` multiply by sc[1] (nullptr: 1).
+hipError_t launch_grad_scale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s);
+hipError_t launch_unscale_inplace(float* a, int64_t n, const float* sc, hipStream_t s);
+
+// x_out = x_in + gate * branch:   d branch16 = dX * gate * mask ; part[.][0] = sum_t dX * branch
+hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, const float* gate, int gate_stride,
+                           const float* mask, int mask_mod, int T, int n_items, void* dB16, float* part, hipStream_t s);
+// h = (LN(x) (1 + sc) + sh) [* mask]:  dX += LN'(dH ...) ; part[.][0] = d scale, part[.][1] = d shift
+hipError_t launch_ln_bwd(const float* x, const float* dH, const float* ada, int ada_stride, int scale_off,
+                         const float* mask, int mask_mod, int mask_out, int T, int n_items, float* dX, float* part,
+                         hipStream_t s);
+// x = (gamma * xpre + beta) * mask:  part[.][0] = d gamma, part[.][1] = d beta ; dX = dX * mask * gamma (in place) (+ 16-bit copy)
+hipError_t launch_film_bwd(int dtype, const float* xpre, const float* film, int film_stride, int film_mod,
+                           const float* mask, int mask_mod, int T, int n_items, float* dX, void* dX16, float* part,
+                           hipStream_t s);
+// dA16 = dU * mask * dropout * SiLU'(a16)   over [rows][F]
+hipError_t launch_silu_bwd(int dtype, const float* dU, const void* a16, const float* mask, int mask_mod, int T, int F,
+                           int64_t rows, DropCfg drop, void* dA16, hipStream_t s);
+// y16 = to16(x * mask?)  /  y = a + b  /  fp32 row-slices
+hipError_t launch_cast16(int dtype, const float* x, const float* mask, int mask_mod, int T, int C, int64_t rows,
+                         const float* scale, void* y16, hipStream_t s);
+hipError_t launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- weight gradient as a forward GEMM
+// dW[co][j][ci] = sum_{n,t} dY[n][t][co] * X[n][t + j - taps/2][ci].  With K-contiguous transposed copies
+//   XT [S][taps*Cin][Rs]  (row j*Cin + ci, column r_local; zero where the shifted frame leaves the item or r >= R)
+//   dYT[S][Cout][Rs]
+// split over S chunks of the N*T rows, it is exactly the forward kernel's contraction (taps = 1, "weights" = dYT
+// with a per-item stride, "activation frames" = the taps*Cin rows of XT): partial[S][taps*Cin][Cout] fp32.
+hipError_t launch_wgrad_xt(int dtype, const void* x0, int c0, const void* x1, int c1, int n_items, int T, int taps,
+                           int S, int Rs, void* xt, hipStream_t s);
+// also part_b[rowblock][Cout] = column sums of the 64-row block (bias gradient partials)
+hipError_t launch_wgrad_dyt(int dtype, const void* dy, int cout, int64_t R, int S, int Rs, void* dyt, float* part_b,
+                            hipStream_t s);
+// dW (reference layout (co_cnt, Cin_total, taps), fp32) [co - co_start][ci_off + ci][j] = sum_s partial[s][j*Cin + ci][co]
+// for co in [co_start, co_start + co_cnt) (a row block of a fused projection), ci < ci_cnt
+hipError_t launch_wgrad_reduce(const float* partial, int S, int cin, int cout, int taps, float* dW, int cin_total,
+                               int ci_off, int ci_cnt, int co_start, int co_cnt, const float* unscale, hipStream_t s);
+// db[co - co_start] = sum_rb part_b[rb][co]
+hipError_t launch_bias_reduce(const float* part_b, int rowblocks, int cout, float* db, int co_start, int co_cnt,
+                              const float* unscale, hipStream_t s);
+
+// dgrad weights: dst16 [Cin_p][taps][ld] columns [col_off, col_off + cout): Wd[ci][j][co] = W[co][ci_off + ci][taps - 1 - j]
+hipError_t launch_pack_weight_t(int dtype, const float* src, int cout, int cin_total, int taps, int ci_off, int ci_cnt,
+                                void* dst, int cin_p, int ld, int col_off, hipStream_t s);
+
+// ---------------------------------------------------------------- small fp32 linears (adaLN, FiLM, time MLP): backward
+// out = W act(in) + b:  dW[o][k] (+)= sum_n dout[n][o] act(in[n][k]);  db[o] (+)= sum_n dout[n][o]
+hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k, int o, int silu_in, float* dW, float* db,
+                               hipStream_t s);
+// din[n][k] (+)= (sum_o dout[n][o] W[o][k]) * act'(in[n][k])
+hipError_t launch_linear_bwd_in(const float* in, const float* dout, const float* W, int n, int k, int o, int silu_in,
+                                float* din, int accumulate, hipStream_t s);
+
+// ---------------------------------------------------------------- attention backward (attention_bwd.hip)
+// Operand copies for the backward kernels, per (item, head):
+//   "T" layout  [item][H][64][Tp]: head dim major, positions contiguous in the forward kernel's PV key order
+//               (bits 2 <-> 3 of the position swapped inside every 16), zero tail for positions >= T
+//   natural     [item][H][T][64]
+// (mean != nullptr: mean[item*H + h][64] is subtracted from the valid positions -- centred copy)
+hipError_t launch_attn_to_T(int dtype, const void* nat, int64_t item_stride, int64_t head_stride, int row_stride,
+                            int n_items, int H, int T, int Tp, const float* mean, void* outT, hipStream_t s);
+// mean[nh][64] over the T positions of a natural-layout tensor
+hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, int T, float* mean, hipStream_t s);
+// natural copy of a T-layout tensor, CENTRED when vmean != nullptr: vmean[item][H][64] = mean over the positions is
+// computed first and subtracted (attention_bwd.hip, "Precision")
+// nat_lo (optional): 16-bit rounding residual of the centred values (hi + lo operand pair)
+hipError_t launch_attn_from_T(int dtype, const void* inT, int n_items, int H, int T, int Tp, float* vmean, void* nat, void* nat_lo,
+                              hipStream_t s);
+struct AttnBwdArgs {
+    const void* q; const void* k; const void* v;       // natural [item][H][T][64] (q pre-scaled by log2e/8, RoPE applied; v CENTRED)
+    const void* vlo;                                   // rounding residual of the centred v (second operand of dP = dO v^T)
+    const float* vmean;                                // [item][H][64]: what was subtracted from v
+    unsigned* dsmax;                                   // [item][H]: bits of max |dS| bound (written by the dQ kernel, read by dK/dV)
+    const void* qT; const void* kT; const void* dOT;   // "T" layout; qT and kT CENTRED
+    const float* qmean; const float* kmean;            // [item][H][64]: what was subtracted from qT / kT
+    const void* dO; int dO_row_stride;                 // time-major [item][T][H*64] (row stride H*64)
+    const float* lse;                                  // [item][H][T]: log2-sum-exp of the forward
+    float* Dq; float* Fq; float* aq;                   // [item][H][T]: sum_k P f dP', sum_k P f, dO . vmean -- written by the dQ
+                                                       // kernel (first pass), read by the dK/dV kernel
+    const float* kbias; int mask_mod;                  // [mask_mod][Tp]
+    const int* kv_end;
+    float* dq; float* dk; float* dv;                   // natural [item][H][T][64] fp32: d(q_rope)*8, d(k_rope)/ln2, dv
+    int T, Tp, H, n_items;
+    DropCfg drop;
+    const void* zeros;
+};
+hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s);
+hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s);
+// RoPE^T on dq, dk, the 1/8 and ln2 factors, and packing into the time-major 16-bit operand [item][T][3*H*64]
+hipError_t launch_qkv_grad_pack(int dtype, const float* dq, const float* dk, const float* dv, const float* rope_cos,
+                                const float* rope_sin, int n_items, int H, int T, void* dqkv16, hipStream_t s);
+
+}  // namespace st

@@ -112,6 +112,7 @@ class Decoder(nn.Module):
         self.filter_channels, self.n_layers, self.n_heads = filter_channels, n_layers, n_heads
         self.kernel_size, self.gin_channels, self.use_lsc = kernel_size, gin_channels, use_lsc
         self.operand_dtype = operand_dtype
+        self.p_dropout = float(dropout)        # train-mode dropout of the FFN activations and attention probabilities
 
         self.time_mlp = TimestepEmbedding(hidden_channels, hidden_channels, filter_channels)
         self.in_proj = nn.Conv1d(hidden_channels + noise_channels, hidden_channels, 1)

@@ -79,7 +79,7 @@ def test_shim_mirrors_reference_interface():
         dec(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), "implicit_adams")
     with pytest.raises(AssertionError):
         CFMDecoder(128, 128, 256, 128, 1024, 4, 5, 3, 0.1, 256)       # n_layers % 2 (estimator.py:92)
-    with pytest.raises(NotImplementedError, match="backward"):        # training path: not native yet, fails loudly
+    with pytest.raises(RuntimeError, match="no CPU fallback"):        # training path is native too: no CPU fallback either
         dec.compute_loss(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), torch.zeros(1, 128, 8), torch.zeros(1, 256))
 
 
