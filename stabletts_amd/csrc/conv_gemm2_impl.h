@@ -148,7 +148,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
                 return;
             }
         }
-        if (g.out32) {
+        if (g.out32 && !(EPI == EPI_RESGATE && g.out32_readonly)) {
 #pragma unroll
             for (int u = 0; u < R; ++u)
                 if (ok[u]) store_row16(g.out32 + grow[u] * g.cout + ch, v[u]);

@@ -426,6 +426,9 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.out16 = copy16;
             if (i + 1 == L) a.out16_lo = p.cur16lo;        // operand pair of final_proj
             if (i + 1 < L / 2) fuse_ln1(a, i + 1);         // blocks >= L/2 start with the long-skip conv instead
+            // ... which rebuilds the residual stream from the 16-bit operands (and final_proj reads only those): from
+            // block L/2 - 1 on the fp32 copy of x3 is dead, so it is not written (40 % of this epilogue's HBM bytes)
+            else if (!cap) a.out32_readonly = 1;
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
             HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }

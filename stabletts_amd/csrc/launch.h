@@ -28,6 +28,7 @@ struct ConvGemmArgs {
     const float* mask; int mask_mod;  // [mask_mod][T] float 0/1, item n -> n % mask_mod
     int flags;                        // GF_*
     void* out16; float* out32;        // [items][T][cout]
+    int out32_readonly;               // EPI_RESGATE: 1 = out32 is only READ (the residual); the updated fp32 rows are not stored
     void* out16_lo;                   // optional (with out16, fp32-staged epilogues): 16-bit residual x - float(out16)
     const float* add32; int add_clamp;  // EPI_F32: + add32[min(n, add_clamp)][t][ch]
     const float* gate; int gate_stride; // EPI_RESGATE: out32 += gate[n*gate_stride + ch]*((acc+b)*mask)
