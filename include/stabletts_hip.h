@@ -128,6 +128,27 @@ int st_create_text_encoder(const st_config* cfg, int n_vocab, int device, st_eng
 int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* lengths, const float* c,
                             float* x_out, float* mu_out, float* mask_out, int B, int T, void* stream);
 
+/* ---- duration -> alignment -> mu_y: the caller side between TextEncoder and CFMDecoder ------------ */
+/* Stateless (no engine handle; a failure's message is st_last_error(NULL)); all pointers are device pointers.       */
+
+/* Replaces models/model.py:85-87 (synthesise): w = exp(logw) * x_mask; w_ceil = ceil(w) * length_scale;
+ * y_lengths = clamp_min(sum(w_ceil), 1).long().  logw, x_mask: (B, 1, Tx) fp32.  Outputs: w_ceil (B, Tx),
+ * cum (B, Tx) = cumsum(w_ceil) (generate_path's first step, :19; sequential fp32), y_lengths (B) int64.  The host
+ * reads y_lengths.max() to size the mel tensors, exactly as the reference does at :88. */
+int st_durations(const float* logw, const float* x_mask, float length_scale, int B, int Tx, float* w_ceil, float* cum,
+                 int64_t* y_lengths, void* stream);
+
+/* Replaces generate_path(duration, mask) (models/model.py:17-27): duration (B, Tx), mask (B, Tx, Ty) -> path (B, Tx, Ty)
+ * 0/1 monotonic alignment.  cum_scratch: (B, Tx) fp32 workspace. */
+int st_generate_path(const float* duration, const float* mask, int B, int Tx, int Ty, float* cum_scratch, float* path, void* stream);
+
+/* Replaces models/model.py:91-95: y_mask = sequence_mask(y_lengths, Ty); attn = generate_path(w_ceil, x_mask x y_mask);
+ * mu_y = attn^T mu_x -- as ONE gather (every mel frame copies the text position its 0/1 alignment column selects).
+ * cum (B, Tx) from st_durations; mu_x (B, M, Tx); outputs mu_y (B, M, Ty), y_mask (B, 1, Ty) (optional) and the
+ * alignment attn (B, Tx, Ty) (optional, NULL to skip: synthesise returns it, the decoder does not need it). */
+int st_align(const float* cum, const float* x_mask, const int64_t* y_lengths, const float* mu_x, int B, int M, int Tx, int Ty,
+             float* attn, float* mu_y, float* y_mask, void* stream);
+
 /* ---- training: autograd counterpart of Decoder.forward ------------------------------------------- */
 
 /* Replaces Decoder.forward(t, x, mask, mu, c) UNDER AUTOGRAD as CFMDecoder.compute_loss calls it (models/flow_matching.py:99,

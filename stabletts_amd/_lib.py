@@ -27,6 +27,7 @@ EXPORTS = [
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad",
+    "st_durations", "st_generate_path", "st_align",
 ]
 
 
@@ -115,6 +116,12 @@ def load():
     lib.st_train_backward.restype = c_int
     lib.st_param_grad.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64, c_void_p]
     lib.st_param_grad.restype = c_int
+    lib.st_durations.argtypes = [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.st_durations.restype = c_int
+    lib.st_generate_path.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.st_generate_path.restype = c_int
+    lib.st_align.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.st_align.restype = c_int
     if lib.st_abi_version() != 1:
         raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
     _lib = lib

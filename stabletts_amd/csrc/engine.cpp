@@ -1140,6 +1140,36 @@ int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* 
     return ST_OK;
 }
 
+// ---- duration -> alignment -> mu_y: stateless helpers (no engine handle; errors through st_last_error(NULL))
+static int align_fail(int code, const char* msg) { g_create_error = msg; return code; }
+
+int st_durations(const float* logw, const float* x_mask, float length_scale, int B, int Tx, float* w_ceil, float* cum,
+                 int64_t* y_lengths, void* stream) {
+    if (!logw || !x_mask || !w_ceil || !cum || !y_lengths) return align_fail(ST_ERR_INVALID, "null tensor pointer");
+    if (B < 1 || Tx < 1) return align_fail(ST_ERR_INVALID, "B and Tx must be >= 1");
+    if (launch_durations(logw, x_mask, length_scale, B, Tx, w_ceil, cum, (long long*)y_lengths, (hipStream_t)stream) != hipSuccess)
+        return align_fail(ST_ERR_HIP, "durations kernel launch failed");
+    return ST_OK;
+}
+
+int st_generate_path(const float* duration, const float* mask, int B, int Tx, int Ty, float* cum_scratch, float* path, void* stream) {
+    if (!duration || !mask || !cum_scratch || !path) return align_fail(ST_ERR_INVALID, "null tensor pointer");
+    if (B < 1 || Tx < 1 || Ty < 1 || B > 65535 || Tx > 65535) return align_fail(ST_ERR_INVALID, "shape out of range");
+    if (launch_cumsum_rows(duration, B, Tx, cum_scratch, (hipStream_t)stream) != hipSuccess ||
+        launch_path(cum_scratch, mask, B, Tx, Ty, path, (hipStream_t)stream) != hipSuccess)
+        return align_fail(ST_ERR_HIP, "generate_path kernel launch failed");
+    return ST_OK;
+}
+
+int st_align(const float* cum, const float* x_mask, const int64_t* y_lengths, const float* mu_x, int B, int M, int Tx, int Ty,
+             float* attn, float* mu_y, float* y_mask, void* stream) {
+    if (!cum || !x_mask || !y_lengths || !mu_x || !mu_y) return align_fail(ST_ERR_INVALID, "null tensor pointer");
+    if (B < 1 || M < 1 || Tx < 1 || Ty < 1 || B > 65535) return align_fail(ST_ERR_INVALID, "shape out of range");
+    if (launch_align(cum, x_mask, (const long long*)y_lengths, mu_x, B, M, Tx, Ty, attn, mu_y, y_mask, (hipStream_t)stream) != hipSuccess)
+        return align_fail(ST_ERR_HIP, "align kernel launch failed");
+    return ST_OK;
+}
+
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects) {
     if (!e) return ST_ERR_INVALID;
     if (nfe) *nfe = e->last_nfe;

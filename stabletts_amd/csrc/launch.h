@@ -121,6 +121,14 @@ hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_tot
                               hipStream_t s);
 hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);
 
+// ---------------------------------------------------------------- duration -> alignment -> mu_y (align_kernels.hip; models/model.py:17-27,82-96)
+hipError_t launch_durations(const float* logw, const float* x_mask, float length_scale, int B, int Tx, float* w_ceil,
+                            float* cum, long long* y_len, hipStream_t s);
+hipError_t launch_cumsum_rows(const float* dur, int B, int Tx, float* cum, hipStream_t s);
+hipError_t launch_path(const float* cum, const float* mask, int B, int Tx, int Ty, float* path, hipStream_t s);
+hipError_t launch_align(const float* cum, const float* x_mask, const long long* y_len, const float* mu_x, int B, int M, int Tx,
+                        int Ty, float* attn, float* mu_y, float* y_mask, hipStream_t s);
+
 // ---------------------------------------------------------------- adaptive dopri5 support (adaptive_ode.hip)
 hipError_t launch_set_scalar(float* dst, float v, hipStream_t s);
 // Deterministic sums of squares over n elements (two-stage reduction, fixed order), result in out[0..1]:

@@ -245,3 +245,22 @@ def test_fixed_grid_rules_have_their_classical_order():
         y = oracle.odeint_fixed(lambda t, y: y, y0, t_span, method)
         taylor = sum(h ** k / math.factorial(k) for k in range(deg + 1))
         assert abs(float(y[0]) - taylor) < 1e-14, method
+
+
+def test_alignment_oracle_matches_reference_fixture():
+    """oracle.align_oracle (numpy restatement of models/model.py:17-27,85-95) vs outputs of the REAL generate_path /
+    sequence_mask (tests/golden/align_outputs.npz, oracle/make_golden_align.py): integer results bit-exact."""
+    import os
+    import numpy as np
+    from oracle.align_oracle import length_regulate
+    from oracle.make_golden_align import CASES, align_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "align_outputs.npz"))
+    for name, (B, Tx, xl, M, ls, seed) in CASES.items():
+        logw, mu_x, x_mask, _ = align_inputs(B, Tx, xl, M, seed)
+        r = length_regulate(logw.numpy(), x_mask.numpy(), mu_x.numpy(), ls)
+        assert np.array_equal(r["w_ceil"], g[name + "_w_ceil"]), name
+        assert np.array_equal(r["y_lengths"], g[name + "_y_lengths"]), name
+        assert np.array_equal(r["y_mask"], g[name + "_y_mask"]), name
+        assert np.array_equal(r["attn"].astype(np.uint8), g[name + "_attn"]), name
+        assert np.abs(r["mu_y"] - g[name + "_mu_y"]).max() <= 1e-6, name
+        assert (r["attn"].sum(1) <= 1).all()                       # at most one text position per mel frame
