@@ -469,19 +469,29 @@ hipError_t launch_wgrad_reduce(const float* partial, int S, int cin, int cout, i
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* part_b, int rowblocks, int cout, float* db, int co_start,
-                                                          int co_cnt, const float* unscale) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= cout || co < co_start || co >= co_start + co_cnt) return;
+// block = 64 channels x 16 row-block groups; fixed summation order (group partials combined 0..15): deterministic
+__global__ __launch_bounds__(1024) void bias_reduce_kernel(const float* part_b, int rowblocks, int cout, float* db, int co_start,
+                                                           int co_cnt, const float* unscale) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int co = blockIdx.x * 64 + tx;
     float v = 0.f;
-    for (int rb = 0; rb < rowblocks; ++rb) v += part_b[(size_t)rb * cout + co];
-    if (unscale) v *= unscale[1];
-    db[co - co_start] = v;
+    if (co < cout)
+        for (int rb = ty; rb < rowblocks; rb += 16) v += part_b[(size_t)rb * cout + co];
+    red[ty][tx] = v;
+    __syncthreads();
+    if (ty == 0 && co < cout && co >= co_start && co < co_start + co_cnt) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][tx];
+        if (unscale) t *= unscale[1];
+        db[co - co_start] = t;
+    }
 }
 
 hipError_t launch_bias_reduce(const float* part_b, int rowblocks, int cout, float* db, int co_start, int co_cnt,
                               const float* unscale, hipStream_t s) {
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, part_b, rowblocks, cout, db, co_start, co_cnt, unscale);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((cout + 63) / 64), dim3(1024), 0, s, part_b, rowblocks, cout, db, co_start, co_cnt, unscale);
     return hipGetLastError();
 }
 
@@ -533,21 +543,30 @@ hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k,
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void linear_bwd_in_kernel(const float* in, const float* dout, const float* W, int n, int k, int o,
-                                                            int silu_in, float* din, int accumulate) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over n x k
-    if (idx >= (int64_t)n * k) return;
-    const int ki = (int)(idx % k), ni = (int)(idx / k);
+// block = one item x 64 inputs x 16 output groups; fixed combination order: deterministic
+__global__ __launch_bounds__(1024) void linear_bwd_in_kernel(const float* in, const float* dout, const float* W, int n, int k, int o,
+                                                             int silu_in, float* din, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ni = blockIdx.y, ki = blockIdx.x * 64 + tx;
     float acc = 0.f;
-    for (int oi = 0; oi < o; ++oi) acc += dout[(size_t)ni * o + oi] * W[(size_t)oi * k + ki];
-    if (silu_in) acc *= silu_grad(in[idx]);
-    din[idx] = accumulate ? din[idx] + acc : acc;
+    if (ki < k)
+        for (int oi = ty; oi < o; oi += 16) acc += dout[(size_t)ni * o + oi] * W[(size_t)oi * k + ki];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && ki < k) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][tx];
+        const size_t idx = (size_t)ni * k + ki;
+        if (silu_in) t *= silu_grad(in[idx]);
+        din[idx] = accumulate ? din[idx] + t : t;
+    }
 }
 
 hipError_t launch_linear_bwd_in(const float* in, const float* dout, const float* W, int n, int k, int o, int silu_in,
                                 float* din, int accumulate, hipStream_t s) {
-    const int64_t total = (int64_t)n * k;
-    hipLaunchKernelGGL(linear_bwd_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, dout, W, n, k, o, silu_in, din, accumulate);
+    hipLaunchKernelGGL(linear_bwd_in_kernel, dim3((k + 63) / 64, n), dim3(1024), 0, s, in, dout, W, n, k, o, silu_in, din, accumulate);
     return hipGetLastError();
 }
 

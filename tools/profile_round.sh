@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel stats + two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command.
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
-TAG=${1:-r01_v4}
+TAG=${1:-r02_v1}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
