@@ -223,10 +223,187 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small grids (single-utterance synthesis: n_items * H * ceil(T/256) blocks of the kernel above would occupy a few
+// CUs and walk their key tiles one after the other): one block = 32 queries of one (item, head), and its 8 waves
+// split the KEY tiles between them (wave w takes tiles w, w+8, ...), each wave streaming its own K / V^T tile into
+// its own 16 KB of LDS -- no block barrier in the main phase.  The 8 partial (m, l, O) triples are then merged
+// through LDS with the usual log-sum-exp rescale.  Same operand layouts, same MFMA formulation as above.
+constexpr int kAttnSmallLds = 8 * 2 * 64 * 128;
+template <class P>
+__global__ __launch_bounds__(512, 1) void attention_small_kernel(const AttnArgs a) {
+    constexpr int NW = 8, TILE_BYTES = 64 * 128, WAVE_LDS = 2 * TILE_BYTES, OP = 33;
+    using vec8 = typename P::vec8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int T = a.T, Tp = a.Tp, H = a.H;
+    const int qgroups = (T + 31) / 32;
+    const int total = a.n_items * H * qgroups;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int qt = lin % qgroups;
+    const int nh = lin / qgroups;
+    const int n = nh / H, h = nh % H;
+    const int mb = n % a.mask_mod;
+    const int kvend = a.kv_end[mb];
+    const int nfull = a.n_full[mb];
+    const float* kbias = a.kbias + (size_t)mb * Tp;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int query = qt * 32 + l31;
+
+    const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
+    const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
+    const unsigned char* vbase = (const unsigned char*)a.vt + ((size_t)nh * 64) * Tp * 2;
+    const unsigned char* zeros = (const unsigned char*)a.zeros;
+    unsigned char* Ks = smem + wave * WAVE_LDS;
+    unsigned char* Vs = Ks + TILE_BYTES;
+
+    vec8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (query < T) v = *(const uint4*)(qbase + (size_t)query * 128 + ks * 32 + hi * 16);
+        qf[ks] = as_vec8<P>(v);
+    }
+    int row_off[2], swz[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int row = b * 32 + l31;
+        row_off[b] = row * 128; swz[b] = (row >> 1) & 7;
+    }
+    f32x16_t o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (kvend + 63) >> 6;
+    for (int kt = wave; kt < ntiles; kt += NW) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous tile's fragment reads have returned
+#pragma unroll
+        for (int piece = 0; piece < 8; ++piece) {
+            const int row = piece * 8 + (lane >> 3);
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const int key = kt * 64 + row;
+            glds16b(key < T ? kbase + (size_t)key * 128 + seg * 16 : zeros, Ks + piece * 1024);
+            glds16b(vbase + ((size_t)row * Tp + kt * 64 + seg * 8) * 2, Vs + piece * 1024);
+        }
+        ST_DMA_WAIT(0);
+
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const unsigned char* kp = Ks + row_off[kb];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(kp + (((ks * 2 + hi) ^ swz[kb]) << 4))), qf[ks], s[kb]);
+        }
+        if ((kt + 1) * 64 > nfull) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 bz = *(const float4*)(kbias + kt * 64 + kb * 32 + 8 * g4 + 4 * hi);
+                    s[kb][4 * g4 + 0] += bz.x; s[kb][4 * g4 + 1] += bz.y;
+                    s[kb][4 * g4 + 2] += bz.z; s[kb][4 * g4 + 3] += bz.w;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = xor32_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_run = m_new;
+        }
+        vec8 pf[4];
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+                psum += p;
+                pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p);
+            }
+        l_run += psum;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const unsigned char* vp = Vs + row_off[d];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
+        }
+    }
+
+    // ---- merge the 8 partial results: each wave parks (O^T [d][query] fp32, m, l) in its own LDS region
+    const float l_tot = xor32_sum(l_run);
+    float* ow = (float*)(smem + wave * WAVE_LDS);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ow[(d * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * OP + l31] = o[d][r];
+    if (hi == 0) { ow[64 * OP + l31] = m_run; ow[64 * OP + 32 + l31] = l_tot; }
+    __syncthreads();
+    const int q = tid >> 4, d0 = (tid & 15) * 4;
+    float mw[NW], M = -1e30f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { mw[w] = ((const float*)(smem + w * WAVE_LDS))[64 * OP + q]; M = fmaxf(M, mw[w]); }
+    float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float* pw = (const float*)(smem + w * WAVE_LDS);
+        const float sc = __builtin_amdgcn_exp2f(mw[w] - M);
+        L += pw[64 * OP + 32 + q] * sc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += pw[(d0 + i) * OP + q] * sc;
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    if (qt * 32 + q < T)
+        *(uint2*)((unsigned char*)a.out + (((size_t)n * T + qt * 32 + q) * (H * 64) + h * 64 + d0) * 2) =
+            pack4<P>(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+}
+
+template <class P>
+static hipError_t launch_attention_small(const AttnArgs& a, hipStream_t s) {
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_done_dev[dev_]) {
+        hipError_t e = hipFuncSetAttribute((const void*)attention_small_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnSmallLds);
+        if (e != hipSuccess) return e;
+        attr_done_dev[dev_] = true;
+    }
+    const int total = a.n_items * a.H * ((a.T + 31) / 32);
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL((attention_small_kernel<P>), dim3(grid), dim3(512), kAttnSmallLds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (!a.zeros || !a.kbias) return hipErrorInvalidValue;
     const int qtiles = (a.T + 32 * ST_ATTN_WAVES - 1) / (32 * ST_ATTN_WAVES);
     const int total = a.n_items * a.H * qtiles;
+    if (!a.lse && a.small_max_blocks > 0 && total <= a.small_max_blocks)
+        return dtype == DT_BF16 ? launch_attention_small<OpBF16>(a, s) : launch_attention_small<OpF16>(a, s);
     const int grid = ((total + 7) / 8) * 8;
     if (a.lse) {
         if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);

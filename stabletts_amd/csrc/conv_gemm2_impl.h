@@ -401,10 +401,16 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     unsigned char* As = smem;
     unsigned char* Ws = smem + 2 * A_BYTES;
 
-    const int total = g.n_items * g.tiles_f * g.tiles_c;
+    // split-K launches (g.ksplit > 1, small grids): `ksplit` consecutive blocks share an output tile and each
+    // contracts its own range of 64-channel chunks; the raw fp32 partial sums go to plane kz of out32
+    // ([ksplit][items][T][cout]) and splitk_finish_kernel applies the epilogue to their sum.
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    const int total = g.n_items * g.tiles_f * g.tiles_c * ks;
     const int per_xcd = gridDim.x >> 3;
-    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lin >= total) return;
+    const int lin0 = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin0 >= total) return;
+    const int kz = lin0 % ks;
+    const int lin = lin0 / ks;
     const int tc = lin % g.tiles_c;
     const int rest = lin / g.tiles_c;
     const int tf = rest % g.tiles_f;
@@ -416,7 +422,8 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const int wc = wave % WC, wf = wave / WC;
     const int cbase = tc * BC, t0 = tf * BF;
     const int cin = g.c0 + g.c1 + g.c2;
-    const int nch = cin >> 6;
+    const int nch_all = cin >> 6;
+    const int cb = kz * nch_all / ks, nch = (kz + 1) * nch_all / ks;      // this block's chunks [cb, nch)
     const int T = g.T;
 
     const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
@@ -516,7 +523,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
         }
     };
 
-    issueA(0, 0); issueW(0, 0, 0);
+    issueA(cb, cb & 1); issueW(cb, 0, 0);
     ST_DMA_WAIT(0);
     __syncthreads();
 #if ST_STAGE_TIMING
@@ -525,7 +532,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const unsigned long long tStart = tS;
 #endif
     int it = 0;
-    for (int c = 0; c < nch; ++c) {
+    for (int c = cb; c < nch; ++c) {
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) {
             const bool last = (c == nch - 1) && (j == TAPS - 1);
@@ -559,7 +566,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #endif
     if constexpr (EPI == EPI_ACT16) g2_epilogue_act16<P, BC, BF, WC, WF>(acc, smem, g, n, t0, BF, cbase, wave, lane);
     else if constexpr (EPI == EPI_QKV) g2_epilogue_qkv<P, BC, BF, WC, WF>(acc, smem, g, n, t0, cbase, wave, lane);
-    else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BF, cbase, wave, lane);
+    else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, kz * g.n_items + n, t0, BF, cbase, wave, lane);
 #if ST_STAGE_TIMING
     if (g.dbg && lane == 0 && (wave == 0 || wave == NW - 1) && lin < 64) {
         unsigned long long* d = g.dbg + (size_t)(lin * 2 + (wave ? 1 : 0)) * 8;
@@ -703,6 +710,55 @@ __global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvG
     else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
 }
 
+// Second half of a split-K launch (cout == 256): one wave per frame row, lane = 4 channels.  Adds the `S` partial
+// planes in order (deterministic) and runs the same per-row epilogue the fused kernels run on their accumulators
+// (g2_rows: bias / mask / gate / residual, optional FiLM + LayerNorm + modulate of the next op).
+template <class P, int EPI>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmArgs g, const float* __restrict__ part, int S) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rows = g.n_items * g.T;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int n = row / g.T, t = row - n * g.T;
+    const int ch = lane * 4;
+    const G2Consts kc = g2_consts<EPI, true>(g, n, ch);
+    const float* src = part + (size_t)row * 256 + ch;
+    const size_t plane = (size_t)rows * 256;
+    float4 v[1]; v[0] = *(const float4*)src;
+    int s = 1;
+    for (; s + 4 <= S; s += 4) {       // four planes in flight per round, added in plane order
+        float4 p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = *(const float4*)(src + (s + i) * plane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[0].x += p[i].x; v[0].y += p[i].y; v[0].z += p[i].z; v[0].w += p[i].w; }
+    }
+    for (; s < S; ++s) {
+        const float4 p = *(const float4*)(src + s * plane);
+        v[0].x += p.x; v[0].y += p.y; v[0].z += p.z; v[0].w += p.w;
+    }
+    const float m[1] = {g.mask ? g.mask[(size_t)(n % g.mask_mod) * g.T + t] : 1.0f};
+    float4 xin[1]; xin[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI == EPI_RESGATE) xin[0] = *(const float4*)(g.out32 + (size_t)row * 256 + ch);
+    if constexpr (EPI == EPI_F32) {
+        if (g.add32) xin[0] = *(const float4*)(g.add32 + ((size_t)(n < g.add_clamp ? n : g.add_clamp) * g.T + t) * 256 + ch);
+    }
+    const int tt[1] = {t}; const bool ok[1] = {true};
+    g2_rows<P, EPI, true, 1>(g, kc, n, tt, ok, ch, v, m, xin);
+}
+
+template <class P>
+static hipError_t launch_splitk_finish_t(int epi, const ConvGemmArgs& a, const float* part, int S, hipStream_t s) {
+    if (a.cout != 256 || S < 1 || !part) return hipErrorInvalidValue;
+    const int rows = a.n_items * a.T;
+    const dim3 grid((rows + 3) / 4), blk(256);
+    if (epi == EPI_F32) hipLaunchKernelGGL((splitk_finish_kernel<P, EPI_F32>), grid, blk, 0, s, a, part, S);
+    else if (epi == EPI_RESGATE) hipLaunchKernelGGL((splitk_finish_kernel<P, EPI_RESGATE>), grid, blk, 0, s, a, part, S);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 template <class P, int EPI, int BC = 128, int BF = 128, int WC = 2, int WF = 2>
 static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
     constexpr int lds_loop = 2 * BF * 128 + 3 * BC * 128, lds_stage = (WC * WF == 8 ? BF / WF : BF) * (BC + 4) * 4;
@@ -718,7 +774,7 @@ static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 | a.c1) & 63) != 0 || a.c2 != 0) return hipErrorInvalidValue;
+    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 | a.c1) & 63) != 0 || a.c2 != 0 || a.ksplit > 1) return hipErrorInvalidValue;
     ConvGemmArgs b = a;
     b.tiles_f = (a.T + BF - 3) / (BF - 2);
     b.tiles_c = a.cout / BC;
@@ -748,7 +804,12 @@ static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
     ConvGemmArgs b = a;
     b.tiles_f = (a.T + BF - 1) / BF;
     b.tiles_c = a.cout / BC;
-    const int total = b.n_items * b.tiles_f * b.tiles_c;
+    if (a.ksplit > 1) {      // raw partial sums only: no bias / mask / residual / 16-bit outputs, every split owns >= 1 chunk
+        if (EPI != EPI_F32 || a.bias || a.add32 || a.out16 || a.ln_h16 || (a.flags & GF_MASK) || !a.out32 ||
+            a.ksplit > (a.c0 + a.c1 + a.c2) / 64 || a.w_item_stride)
+            return hipErrorInvalidValue;
+    }
+    const int total = b.n_items * b.tiles_f * b.tiles_c * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = ((total + 7) / 8) * 8;
     if (EPI == EPI_QKV && (a.cout != 3 * BC || a.n_heads * 64 != BC || !a.q || !a.k || !a.vt)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>), dim3(grid), dim3(K::NT), LDS, s, b);

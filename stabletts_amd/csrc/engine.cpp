@@ -99,11 +99,35 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
     const int T = a.T;
     const bool fills = ((T + 255) / 256) * 256 * 10 <= ((T + 127) / 128) * 128 * 11;
     const bool big_fills_chip = (int64_t)e->conc * a.n_items * ((T + 255) / 256) * (a.cout / 256) >= e->big_min_blocks;
+    // Small grids (a few frame tiles in total: single-utterance synthesis): the K loop of one block is a serial chain
+    // of DMA -> barrier -> MFMA stages, so a handful of blocks walking 24..48 stages each leaves the chip idle for
+    // tens of microseconds.  Split the contraction over `ks` blocks per output tile (raw fp32 partial planes in
+    // e->kpart) and apply the epilogue -- including a fused LayerNorm -- in a row-wise finish kernel.
+    if (e->kpart && e->conc == 1 && a.cout == 256 && (epi == EPI_F32 || epi == EPI_RESGATE) && !a.w_item_stride) {
+        const int nch = (a.c0 + a.c1 + a.c2) / 64;
+        const int64_t blocks = (int64_t)a.n_items * ((T + 127) / 128) * 2;
+        const int64_t plane = (int64_t)a.n_items * T * 256 * 4;
+        int ks = (int)std::min<int64_t>(std::min(nch, e->splitk_max), e->splitk_target / blocks);
+        ks = (int)std::min<int64_t>(ks, (int64_t)e->kpart_bytes / plane);
+        if (ks >= 2 && nch * taps >= e->splitk_min_stages) {
+            ConvGemmArgs pa = a;
+            pa.bias = nullptr; pa.flags = 0; pa.mask = nullptr; pa.add32 = nullptr; pa.out16 = nullptr; pa.out16_lo = nullptr;
+            pa.ln_h16 = nullptr; pa.gate = nullptr; pa.out32 = e->kpart; pa.ksplit = ks;
+            const int pcfg = e->small_tiles ? G2_T64 : G2_T128;
+            hipError_t he = bf ? launch_conv_gemm2_bf16(pcfg, taps, EPI_F32, pa, s) : launch_conv_gemm2_f16(pcfg, taps, EPI_F32, pa, s);
+            if (he != hipSuccess) return he;
+            return bf ? launch_splitk_finish_bf16(epi, a, e->kpart, ks, s) : launch_splitk_finish_f16(epi, a, e->kpart, ks, s);
+        }
+    }
     int cfg;
     if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = G2_BIG;
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
     else if (taps == 3 && a.c0 + a.c1 >= 512 && a.c2 == 0) cfg = G2_K3PIPE;
     else cfg = G2_T128;
+    // latency-bound small grids: 64-frame tiles double the block count and halve every block's serial work
+    const bool tiny = e->small_tiles && e->conc == 1 && (int64_t)a.n_items * ((T + 127) / 128) * (a.cout / 128) <= e->small_tiles;
+    if (tiny && cfg == G2_T128 && (epi == EPI_ACT16 ? taps == 3 : epi == EPI_F32)) cfg = G2_T64;
+    if (tiny && cfg == G2_RC && epi == EPI_QKV) cfg = G2_RC64;
     return bf ? launch_conv_gemm2_bf16(cfg, taps, epi, a, s) : launch_conv_gemm2_f16(cfg, taps, epi, a, s);
 }
 
@@ -399,6 +423,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.kbias = p.kbias; a.mask_mod = p.B; a.zeros = e->zeros;
             a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
+            a.small_max_blocks = e->conc == 1 ? e->attn_small_blocks : 0;
             ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
@@ -484,6 +509,7 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
             AttnArgs a; memset(&a, 0, sizeof(a));
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.kbias = p.kbias; a.mask_mod = p.B; a.zeros = e->zeros;
             a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
+            a.small_max_blocks = e->conc == 1 ? e->attn_small_blocks : 0;
             ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
@@ -739,9 +765,16 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     e->K = cfg->kernel_size; e->G = cfg->gin_channels;
     e->kind = kind; e->n_vocab = n_vocab;
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
+    if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
+        if (atoi(v) == 0) {                               // key-split attention): results independent of the batch composition
+            e->splitk_target = 0; e->small_tiles = 0; e->attn_small_blocks = 0;
+        }
+    }
     build_param_table(e);
+    if (hipMalloc((void**)&e->kpart, kSplitKBytes) == hipSuccess) e->kpart_bytes = kSplitKBytes; else e->kpart = nullptr;
     if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
         g_create_error = "hipMalloc failed";
+        if (e->kpart) hipFree(e->kpart);
         delete e;
         return ST_ERR_HIP;
     }
@@ -774,6 +807,7 @@ void st_destroy(st_engine* e) {
     if (e->rope_cos) hipFree(e->rope_cos);
     if (e->rope_sin) hipFree(e->rope_sin);
     if (e->zeros) hipFree(e->zeros);
+    if (e->kpart) hipFree(e->kpart);
     delete e;
 }
 

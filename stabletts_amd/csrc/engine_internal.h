@@ -39,6 +39,9 @@ struct TrainState;     // engine_train.cpp
 
 }  // namespace sthost
 
+constexpr int kSplitKMax = 16;
+constexpr size_t kSplitKBytes = 32u << 20;
+
 struct st_engine {
     st_config cfg{};
     int device = 0;
@@ -85,6 +88,12 @@ struct st_engine {
     // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     int big_min_blocks = 192;
+    int splitk_max = kSplitKMax, splitk_min_stages = 4;
+    int small_tiles = 256;              // conv launches of <= this many 128x128 tiles use the 64-frame tile variants (0: never)
+    int splitk_target = 256;            // split-K: blocks a small conv launch is brought up to (gemm())
+    int attn_small_blocks = 32;         // attention launches of <= this many 256-query blocks use the key-split kernel
+    float* kpart = nullptr;             // split-K partial planes [ks][items][T][256] fp32
+    size_t kpart_bytes = 0;
     int conc = 1;                       // solve parts in flight on separate streams (their launches share the chip)
     hipStream_t s2 = nullptr;           // stream of the second solve part
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -43,15 +43,20 @@ struct ConvGemmArgs {
     const float* ln_film; int ln_film_stride; int ln_film_mod;     // gamma = film[(n%mod)*stride + ch], beta = +256
     const float* ln_ada; int ln_ada_stride; int ln_shift_off; int ln_scale_off;
     int ln_mask_out;
+    int ksplit;                       // > 1: split-K launch (EPI_F32 only): out32 = partial planes [ksplit][items][T][cout], raw sums
     unsigned long long* dbg;          // diagnostics (ST_STAGE_TIMING builds of tools/gemm2_bench only), else nullptr
 };
 
 // tile configurations (conv_gemm2_impl.h): T128 = 128x128 tile, RC = row-complete 256x128 tile (cout % 256 == 0,
 // may carry the fused FiLM + LayerNorm + modulate of the next op through the ln_* fields; also the QKV epilogue)
 enum { G2_T128 = 0, G2_RC = 1, G2_K3PIPE = 2,   // K3PIPE: k=3 only, three weight buffers, counted vmcnt
-       G2_BIG = 3 };                             // 256 x 256 tile, 8 waves of 128 x 64 (cout % 256 == 0)
+       G2_BIG = 3,                               // 256 x 256 tile, 8 waves of 128 x 64 (cout % 256 == 0)
+       G2_T64 = 4, G2_RC64 = 5 };                // 64-frame versions of T128 / RC (QKV only) for small, latency-bound grids
 hipError_t launch_conv_gemm2_bf16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 hipError_t launch_conv_gemm2_f16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
+// epilogue `epi` (EPI_F32 / EPI_RESGATE, cout == 256) of the sum of the S partial planes a split-K launch left in `part`
+hipError_t launch_splitk_finish_bf16(int epi, const ConvGemmArgs& a, const float* part, int S, hipStream_t s);
+hipError_t launch_splitk_finish_f16(int epi, const ConvGemmArgs& a, const float* part, int S, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 
@@ -69,6 +74,7 @@ struct AttnArgs {
     const void* zeros;                     // >= 16 zero bytes in global memory (out-of-range K rows)
     float* lse;                            // training: [item][H][T] log2-sum-exp of the scores (nullptr: inference kernel)
     DropCfg drop;                          // training: dropout on the attention probabilities (diffusion_transformer.py:77)
+    int small_max_blocks;                  // inference: launches of <= this many 256-query blocks use the key-split small-grid kernel (0: never)
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 

@@ -33,10 +33,17 @@ def _solve(d, inp, n, solver, kw):
 
 
 @pytest.mark.parametrize("solver,n,cfg", [("euler", 4, 3.0), ("rk4", 2, None), ("midpoint", 3, 2.0)])
-def test_two_part_solve_is_bitwise_identical(dec, cfg_params, monkeypatch, solver, n, cfg):
+def test_two_part_solve_is_bitwise_identical(sd, cfg_params, monkeypatch, solver, n, cfg):
     """ST_SPLIT=2: the batch is solved as two parts on two streams (MFMA-bound kernels of one part overlap the
     HBM-bound epilogues of the other).  Utterances never share a tile, so every output must equal the one-part
-    solve bit for bit -- odd batch sizes, ragged lengths, with and without CFG, eager and graph replay."""
+    solve bit for bit -- odd batch sizes, ragged lengths, with and without CFG, eager and graph replay.
+    (Engine created with ST_SMALL_GRID=0: the split-K path of small grids picks its split count -- hence its
+    summation order -- from the launch's block count, which differs between a batch and its parts.)"""
+    from stabletts_amd.flow_matching import CFMDecoder
+    monkeypatch.setenv("ST_SMALL_GRID", "0")
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="bf16")
+    dec.estimator.load_state_dict(sd)
+    dec = dec.to("cuda:0")
     kw = _kw(cfg_params, cfg) if cfg is not None else None
     for B, T, lengths in ((5, 200, [200, 133, 64, 200, 7]), (2, 70, [70, 51])):
         inp = make_inputs(B, T, seed=80 + B, lengths=lengths)
