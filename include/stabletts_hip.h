@@ -149,6 +149,29 @@ int st_generate_path(const float* duration, const float* mask, int B, int Tx, in
 int st_align(const float* cum, const float* x_mask, const int64_t* y_lengths, const float* mu_x, int B, int M, int Tx, int Ty,
              float* attn, float* mu_y, float* y_mask, void* stream);
 
+/* ---- Vocos vocoder: mel -> waveform, the step after the decoder (api.py:76) ------------------------ */
+
+/* Replaces Vocos.__init__(VocosConfig(), MelConfig()) (vocoders/vocos/models/model.py:11-15, config.py:4-19,46-50). */
+typedef struct st_vocos_config {
+    int32_t input_channels;    /* n_mels, config.py:47 (multiple of 64) */
+    int32_t dim;               /* config.py:48; native kernels: 512 */
+    int32_t intermediate_dim;  /* config.py:49 (multiple of 256) */
+    int32_t num_layers;        /* config.py:50 (1..32) */
+    int32_t n_fft;             /* MelConfig.n_fft, config.py:6; native kernels: 2048 */
+    int32_t hop_length;        /* MelConfig.hop_length, config.py:8; native kernels: 512 */
+    int32_t operand_dtype;     /* ST_OPERAND_* of the GEMM operands (accumulation, LayerNorms, residual stream, ISTFT: fp32) */
+} st_vocos_config;
+
+/* The handle takes the parameters of Vocos.state_dict() under their reference names ("backbone.embed.weight", ...,
+ * "backbone.convnext.<i>.gamma", ..., "head.out.bias", "head.istft.window") through st_load_param / st_finalize and
+ * is destroyed with st_destroy.  The decoder / text-encoder entry points reject it and vice versa. */
+int st_create_vocoder(const st_vocos_config* cfg, int device, st_engine** out);
+
+/* Replaces Vocos.forward(x) (model.py:17-20) = ISTFTHead(VocosBackbone(x)) (backbone.py:50-56, head.py:93-117 with
+ * padding="same"):  mel (B, input_channels, T) fp32 -> audio (B, T * hop_length) fp32, device pointers.  Like the
+ * reference there is no mask: every utterance is vocoded at the padded length T. */
+int st_vocos_forward(st_engine* e, const float* mel, float* audio, int B, int T, void* stream);
+
 /* ---- training: autograd counterpart of Decoder.forward ------------------------------------------- */
 
 /* Replaces Decoder.forward(t, x, mask, mu, c) UNDER AUTOGRAD as CFMDecoder.compute_loss calls it (models/flow_matching.py:99,

@@ -14,14 +14,17 @@ import sys
 __all__ = ["install", "CFMDecoder", "TextEncoder"]
 
 
-def install(text_encoder=False):
-    """Make ``models.flow_matching`` (and optionally ``models.text_encoder``) resolve to the native drop-ins
-    (call before importing models.model)."""
+def install(text_encoder=False, vocoder=False):
+    """Make ``models.flow_matching`` (and optionally ``models.text_encoder`` / ``vocoders.vocos.models.model``)
+    resolve to the native drop-ins (call before importing models.model / api.get_vocoder)."""
     from . import flow_matching
     sys.modules["models.flow_matching"] = flow_matching
     if text_encoder:
         from . import text_encoder as te
         sys.modules["models.text_encoder"] = te
+    if vocoder:
+        from . import vocos
+        sys.modules["vocoders.vocos.models.model"] = vocos      # api.py:26-28: from vocoders.vocos.models.model import Vocos
     return flow_matching
 
 
@@ -29,6 +32,9 @@ def __getattr__(name):
     if name == "CFMDecoder":
         from .flow_matching import CFMDecoder
         return CFMDecoder
+    if name == "Vocos":
+        from .vocos import Vocos
+        return Vocos
     if name == "TextEncoder":
         from .text_encoder import TextEncoder
         return TextEncoder

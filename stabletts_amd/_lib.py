@@ -27,7 +27,7 @@ EXPORTS = [
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad",
-    "st_durations", "st_generate_path", "st_align",
+    "st_durations", "st_generate_path", "st_align", "st_create_vocoder", "st_vocos_forward",
 ]
 
 
@@ -35,6 +35,11 @@ class StConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "noise_channels", "hidden_channels", "filter_channels", "n_heads", "n_layers",
         "kernel_size", "gin_channels", "operand_dtype")]
+
+
+class StVocosConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "input_channels", "dim", "intermediate_dim", "num_layers", "n_fft", "hop_length", "operand_dtype")]
 
 
 class NativeError(RuntimeError):
@@ -122,6 +127,10 @@ def load():
     lib.st_generate_path.restype = c_int
     lib.st_align.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.st_align.restype = c_int
+    lib.st_create_vocoder.argtypes = [ctypes.POINTER(StVocosConfig), c_int, ctypes.POINTER(c_void_p)]
+    lib.st_create_vocoder.restype = c_int
+    lib.st_vocos_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.st_vocos_forward.restype = c_int
     if lib.st_abi_version() != 1:
         raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
     _lib = lib
@@ -132,9 +141,11 @@ class Engine:
     """Thin owner of one ``st_engine`` handle."""
 
     def __init__(self, noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
-                 gin_channels, operand_dtype="bf16", device=0, text_encoder_vocab=None):
+                 gin_channels, operand_dtype="bf16", device=0, text_encoder_vocab=None, vocoder=None):
         """text_encoder_vocab: None -> CFM decoder estimator (st_create); n_vocab -> TextEncoder handle
-        (st_create_text_encoder; noise_channels is then the encoder's out_channels)."""
+        (st_create_text_encoder; noise_channels is then the encoder's out_channels).
+        vocoder: dict(input_channels, dim, intermediate_dim, num_layers, n_fft, hop_length) -> Vocos handle
+        (st_create_vocoder; the decoder arguments are ignored)."""
         self.lib = load()
         if operand_dtype not in OPERAND_DTYPES:
             raise ValueError(f"operand_dtype must be one of {sorted(OPERAND_DTYPES)}")
@@ -142,7 +153,11 @@ class Engine:
         cfg = StConfig(noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
                        gin_channels, OPERAND_DTYPES[operand_dtype])
         h = ctypes.c_void_p()
-        if text_encoder_vocab is None:
+        if vocoder is not None:
+            vc = StVocosConfig(vocoder["input_channels"], vocoder["dim"], vocoder["intermediate_dim"], vocoder["num_layers"],
+                               vocoder["n_fft"], vocoder["hop_length"], OPERAND_DTYPES[operand_dtype])
+            rc = self.lib.st_create_vocoder(ctypes.byref(vc), int(device), ctypes.byref(h))
+        elif text_encoder_vocab is None:
             rc = self.lib.st_create(ctypes.byref(cfg), int(device), ctypes.byref(h))
         else:
             rc = self.lib.st_create_text_encoder(ctypes.byref(cfg), int(text_encoder_vocab), int(device), ctypes.byref(h))
@@ -208,6 +223,10 @@ class Engine:
         self._check(self.lib.st_text_encoder_forward(self.handle, tokens.data_ptr(), lengths.data_ptr(), c.data_ptr(),
                                                      x_out.data_ptr(), mu_out.data_ptr(), mask_out.data_ptr(), B, T,
                                                      ctypes.c_void_p(stream)))
+
+    def vocos_forward(self, mel, audio, stream):
+        B, _, T = mel.shape
+        self._check(self.lib.st_vocos_forward(self.handle, mel.data_ptr(), audio.data_ptr(), B, T, ctypes.c_void_p(stream)))
 
     # ---- training: forward that keeps activations + backward (include/stabletts_hip.h, "training")
     def train_forward(self, t, x, mu, mask, c, out, p_dropout, seed, stream):

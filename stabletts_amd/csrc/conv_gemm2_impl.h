@@ -236,7 +236,7 @@ __device__ __forceinline__ void g2_init_acc(f32x16_t (&acc)[FC][FF], const ConvG
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_ACT16 || EPI == EPI_QKV) { if (g.bias) bv = *(const float4*)(g.bias + chw + a * 32 + 8 * q4 + 4 * hi); }
+            if constexpr (EPI == EPI_ACT16 || EPI == EPI_GELU16 || EPI == EPI_QKV) { if (g.bias) bv = *(const float4*)(g.bias + chw + a * 32 + 8 * q4 + 4 * hi); }
 #pragma unroll
             for (int b = 0; b < FF; ++b) {
                 acc[a][b][4 * q4 + 0] = bv.x; acc[a][b][4 * q4 + 1] = bv.y;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void g2_init_acc(f32x16_t (&acc)[FC][FF], const ConvG
 // column; every wave works at once, no barrier, no per-row control flow), the results are packed to 16 bit and
 // parked in LDS as [frame][channel] (row pitch BC*2+16 B), and after ONE barrier the block writes the tile as
 // whole rows: 16 B per lane, 64 lanes = 1 KiB of consecutive HBM bytes per store instruction.
-template <class P, int BC, int BF, int WC, int WF>
+template <class P, int BC, int BF, int WC, int WF, bool GELU = false>
 __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], unsigned char* stage,
                                                   const ConvGemmArgs& g, int n, int t0, int fvalid, int cbase, int wave, int lane) {
     constexpr int NW = WC * WF, TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32, PB = BC * 2 + 16;
@@ -268,7 +268,10 @@ __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][
 #pragma unroll
         for (int a = 0; a < FC; ++a) {          // one 32x32 fragment at a time: its registers die at the ds_write
             f32x16_t v = acc[a][b];
-            if (do_silu) {
+            if constexpr (GELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+            } else if (do_silu) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = silu_fast(v[r]);
             }
@@ -564,7 +567,8 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #if ST_STAGE_TIMING
     const unsigned long long tLoop = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (EPI == EPI_ACT16) g2_epilogue_act16<P, BC, BF, WC, WF>(acc, smem, g, n, t0, BF, cbase, wave, lane);
+    if constexpr (EPI == EPI_ACT16 || EPI == EPI_GELU16)
+        g2_epilogue_act16<P, BC, BF, WC, WF, EPI == EPI_GELU16>(acc, smem, g, n, t0, BF, cbase, wave, lane);
     else if constexpr (EPI == EPI_QKV) g2_epilogue_qkv<P, BC, BF, WC, WF>(acc, smem, g, n, t0, cbase, wave, lane);
     else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, kz * g.n_items + n, t0, BF, cbase, wave, lane);
 #if ST_STAGE_TIMING

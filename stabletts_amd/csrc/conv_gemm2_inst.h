@@ -14,6 +14,7 @@ static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemm
         if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 128, 128, 2, 2>(a, s);
         if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 128, 128, 2, 2>(a, s);
         if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 128, 128, 2, 2>(a, s);
+        if (taps == 1 && epi == EPI_GELU16) return launch_g2<P, 1, EPI_GELU16, 128, 128, 2, 2>(a, s);
     } else if (cfg == 1) {
         if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 256, 128, 4, 2>(a, s);
         if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 256, 128, 4, 2>(a, s);
@@ -27,6 +28,7 @@ static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemm
         if (taps == 3 && epi == EPI_RESGATE) return launch_g2<P, 3, EPI_RESGATE, 256, 256, 2, 4>(a, s);
         if (taps == 1 && epi == EPI_RESGATE) return launch_g2<P, 1, EPI_RESGATE, 256, 256, 2, 4>(a, s);
         if (taps == 1 && epi == EPI_QKV) return launch_g2<P, 1, EPI_QKV, 256, 256, 2, 4>(a, s);
+        if (taps == 1 && epi == EPI_GELU16) return launch_g2<P, 1, EPI_GELU16, 256, 256, 2, 4>(a, s);
     } else if (cfg == 4) {   // T64: 128 ch x 64 frames, 4 waves of 64x32 -- twice the blocks of T128 for latency-bound small grids
         if (taps == 3 && epi == EPI_ACT16) return launch_g2<P, 3, EPI_ACT16, 128, 64, 2, 2>(a, s);
         if (taps == 1 && epi == EPI_F32) return launch_g2<P, 1, EPI_F32, 128, 64, 2, 2>(a, s);

@@ -794,6 +794,7 @@ void st_destroy(st_engine* e) {
     hipDeviceSynchronize();
     e->drop_graphs();
     train_destroy(e);
+    vocos_destroy(e);
     if (e->gstream) hipStreamDestroy(e->gstream);
     if (e->s2) hipStreamDestroy(e->s2);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -850,6 +851,7 @@ int st_finalize(st_engine* e) {
     e->drop_graphs();          // instantiated graphs hold the old packed-weight pointers
     for (void* p : e->owned) hipFree(p);
     e->owned.clear(); e->weight_bytes = 0;
+    if (e->kind == 2) return vocos_finalize(e);
     const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
     hipStream_t s = nullptr;
     // generic packer: (cout, cin_total, taps) source slice -> Conv with padded dims.  split: the packed K dimension
@@ -914,7 +916,7 @@ int st_finalize(st_engine* e) {
 int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x, const float* mu,
                          const float* mask, const float* c, float* out, int B, int T, void* stream) {
     int rc = check_ready(e, B, T); if (rc) return rc;
-    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
+    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is not a CFM decoder (st_create)");
     if (!t || !x || !mu || !mask || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (t_len != 1 && t_len != B) return e->fail(ST_ERR_INVALID, "t must have 1 or B elements");
     HIPCHK(e, hipSetDevice(e->device));
@@ -946,7 +948,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                  const float* fake_speaker, const float* fake_content,
                  float* out, int B, int T, void* stream) {
     int rc = check_ready(e, B, T); if (rc) return rc;
-    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
+    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is not a CFM decoder (st_create)");
     if (!mu || !mask || !z || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (n_steps < 1 || n_steps > 4096) return e->fail(ST_ERR_INVALID, "n_steps out of range");
     if (solver < ST_SOLVER_EULER || solver > ST_SOLVER_ADAPTIVE_HEUN)

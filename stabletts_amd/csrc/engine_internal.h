@@ -36,6 +36,7 @@ struct ProfEvent { int cls; hipEvent_t a, b; double flops; };
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct TrainState;     // engine_train.cpp
+struct VocosState;     // engine_vocos.cpp
 
 }  // namespace sthost
 
@@ -47,7 +48,7 @@ struct st_engine {
     int device = 0;
     int dt = st::DT_BF16;
     int M = 0, Mp = 0, C = 0, F = 0, H = 0, L = 0, K = 0, G = 0;
-    int kind = 0;                       // 0: CFM decoder estimator, 1: TextEncoder (same DiT block kernels)
+    int kind = 0;                       // 0: CFM decoder estimator, 1: TextEncoder (same DiT block kernels), 2: Vocos vocoder
     int n_vocab = 0;
     // parameter-name prefix of DiT block i: estimator.py:13,79 "blocks.i.block." / text_encoder.py:25 "encoder.i."
     std::string blk(int i) const {
@@ -111,6 +112,7 @@ struct st_engine {
 
     // training (engine_train.cpp): transposed dgrad weights, saved activations, gradient buffers
     sthost::TrainState* train = nullptr;
+    sthost::VocosState* voc = nullptr;  // kind == 2 (engine_vocos.cpp)
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
 };
@@ -133,6 +135,9 @@ void capture(st_engine* e, const std::string& name, const void* dev, int64_t n, 
 int ensure_ws(st_engine* e, size_t bytes);
 int ensure_rope(st_engine* e, int T, hipStream_t s);
 int check_ready(st_engine* e, int B, int T);
+extern std::string g_create_error;
+int vocos_finalize(st_engine* e);
+void vocos_destroy(st_engine* e);
 
 // HIP-event bracket around the launches of one kernel class (st_profile_*)
 struct ProfScope {

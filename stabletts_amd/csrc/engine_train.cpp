@@ -216,7 +216,7 @@ extern "C" {
 int st_train_forward(st_engine* e, const float* t, const float* x, const float* mu, const float* mask, const float* c,
                      float* out, int B, int T, float p_dropout, uint64_t seed, void* stream) {
     int rc = check_ready(e, B, T); if (rc) return rc;
-    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is a text encoder (st_create_text_encoder)");
+    if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is not a CFM decoder (st_create)");
     if (!t || !x || !mu || !mask || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (e->G != e->C) return e->fail(ST_ERR_UNSUPPORTED, "training path is built for gin_channels == hidden_channels");
     if (!(p_dropout >= 0.f && p_dropout < 1.f)) return e->fail(ST_ERR_INVALID, "p_dropout must be in [0, 1)");

@@ -11,7 +11,8 @@ enum { DT_BF16 = 0, DT_F16 = 1 };
 // out[ch][frame] = bias[ch] + sum_{tap j, ci} W[ch][j][ci] * act[frame + j - TAPS/2][ci]
 // Activations are TIME-MAJOR 16-bit tensors [item][T][C]; the K dimension may span two source
 // tensors (channel concat without materialising torch.cat: estimator.py:120,131).
-enum { EPI_ACT16 = 0, EPI_F32 = 1, EPI_RESGATE = 2, EPI_QKV = 3 };
+enum { EPI_ACT16 = 0, EPI_F32 = 1, EPI_RESGATE = 2, EPI_QKV = 3,
+       EPI_GELU16 = 4 };   // EPI_ACT16 with exact-erf GELU in place of SiLU (Vocos pwconv1, module.py:38-39)
 enum { GF_SILU = 1, GF_MASK = 2 };
 
 struct ConvGemmArgs {

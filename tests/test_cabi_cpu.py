@@ -121,3 +121,51 @@ def test_text_encoder_shim_mirrors_reference_interface():
             sys.modules.pop(k, None)
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_vocos_shim_mirrors_reference_interface():
+    """vocoders/vocos/models/model.py:11-20: constructor Vocos(vocos_config, mel_config), forward(x), the state_dict
+    layout of the REAL module (names + shapes recorded by oracle/make_golden_vocos.py), the reference's init
+    (backbone.py:44-48, module.py:27-31), and no CPU fallback."""
+    import inspect
+    import os
+    import sys
+    import types
+    import numpy as np
+    import stabletts_amd
+    from stabletts_amd.vocos import Vocos
+    v = Vocos(types.SimpleNamespace(input_channels=128, dim=512, intermediate_dim=1536, num_layers=8),
+              types.SimpleNamespace(n_fft=2048, hop_length=512))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocos_outputs.npz"))
+    ref = dict(zip(g["state_dict.names"].tolist(), g["state_dict.shapes"].tolist()))
+    sd = v.state_dict()
+    assert list(sd) == list(ref)                                                   # same keys, same order
+    assert all(",".join(map(str, sd[k].shape)) == ref[k] for k in ref)
+    assert list(inspect.signature(v.forward).parameters) == ["x"]
+    assert float(sd["backbone.convnext.3.gamma"][0]) == pytest.approx(1 / 8)       # layer_scale_init_value = 1 / num_layers
+    assert float(sd["backbone.embed.bias"].abs().max()) == 0.0 and abs(float(sd["backbone.embed.weight"].std()) - 0.02) < 2e-3
+    assert torch.equal(sd["head.istft.window"], torch.hann_window(2048))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        v(torch.zeros(1, 128, 4))
+    saved = sys.modules.pop("vocoders.vocos.models.model", None)
+    try:
+        stabletts_amd.install(vocoder=True)
+        assert sys.modules["vocoders.vocos.models.model"].Vocos is Vocos
+    finally:
+        sys.modules.pop("vocoders.vocos.models.model", None)
+        if saved is not None:
+            sys.modules["vocoders.vocos.models.model"] = saved
+
+
+def test_vocoder_config_limits(lib):
+    """st_create_vocoder rejects what the native kernels are not built for (and never touches a GPU to do so)."""
+    import ctypes
+    from stabletts_amd._lib import StVocosConfig, ST_ERR_INVALID, ST_ERR_UNSUPPORTED
+    h = ctypes.c_void_p()
+    ok = dict(input_channels=128, dim=512, intermediate_dim=1536, num_layers=8, n_fft=2048, hop_length=512, operand_dtype=0)
+    for bad, code in ((dict(dim=256), ST_ERR_UNSUPPORTED), (dict(n_fft=1024), ST_ERR_UNSUPPORTED),
+                      (dict(hop_length=256), ST_ERR_UNSUPPORTED), (dict(num_layers=0), ST_ERR_INVALID),
+                      (dict(operand_dtype=7), ST_ERR_INVALID), (dict(input_channels=100), ST_ERR_UNSUPPORTED)):
+        cfg = StVocosConfig(**{**ok, **bad})
+        assert lib.st_create_vocoder(ctypes.byref(cfg), 0, ctypes.byref(h)) == code, bad
+        assert lib.st_last_error(None)

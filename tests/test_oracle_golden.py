@@ -264,3 +264,40 @@ def test_alignment_oracle_matches_reference_fixture():
         assert np.array_equal(r["attn"].astype(np.uint8), g[name + "_attn"]), name
         assert np.abs(r["mu_y"] - g[name + "_mu_y"]).max() <= 1e-6, name
         assert (r["attn"].sum(1) <= 1).all()                       # at most one text position per mel frame
+
+
+def test_vocos_oracle_matches_reference_fixture():
+    """oracle.vocos_oracle (numpy restatement of vocoders/vocos/models/{backbone,module,head}.py) vs outputs of the REAL
+    Vocos module in fp32 (tests/golden/vocos_outputs.npz, oracle/make_golden_vocos.py): backbone output and waveform."""
+    import os
+    import numpy as np
+    from oracle import vocos_oracle as vo
+    from oracle.make_golden_vocos import CASES, SD_SEED
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocos_outputs.npz"))
+    sd = vo.make_vocos_state_dict(SD_SEED)
+    for name, (B, T, seed) in CASES.items():
+        mel = vo.make_mel(B, T, seed)
+        hid = vo.backbone_forward(sd, mel)
+        audio = vo.head_forward(sd, hid)
+        assert audio.shape == (B, T * 512)
+        assert np.abs(hid - g[name + ".hidden"]).max() <= 2e-6 * np.abs(g[name + ".hidden"]).max(), name
+        assert np.abs(audio - g[name + ".audio"]).max() <= 5e-6 * np.abs(g[name + ".audio"]).max(), name
+
+
+def test_vocos_oracle_istft_is_inverse_of_stft():
+    """Size-independent property of the ISTFT restatement (head.py:39-72): with "same" padding it inverts an STFT with the
+    same window / hop on the interior of the signal (window-sum normalisation), and it is linear in the spectrum."""
+    import numpy as np
+    from oracle import vocos_oracle as vo
+    rng = np.random.default_rng(0)
+    n_fft, hop, T = 2048, 512, 12
+    win = vo.make_vocos_state_dict(1)["head.istft.window"].astype(np.float64)
+    x = rng.standard_normal(T * hop)
+    pad = (n_fft - hop) // 2
+    xp = np.pad(x, (pad, pad))
+    S = np.stack([np.fft.rfft(xp[t * hop:t * hop + n_fft] * win) for t in range(T)], axis=1)[None]
+    y = vo.istft_same(S, win, n_fft, hop)[0]
+    assert np.abs(y - x)[pad:-pad].max() < 1e-9                                     # interior: all 4 frames present
+    S2 = rng.standard_normal(S.shape) + 1j * rng.standard_normal(S.shape)
+    lhs = vo.istft_same(2.0 * S + 3.0 * S2, win, n_fft, hop)
+    assert np.abs(lhs - (2.0 * y[None] + 3.0 * vo.istft_same(S2, win, n_fft, hop))).max() < 1e-9
