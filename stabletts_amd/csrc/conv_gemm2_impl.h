@@ -21,6 +21,7 @@
 #pragma once
 #include "common.h"
 #include "launch.h"
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef ST_STAGE_TIMING

@@ -2,6 +2,7 @@
 // conv_gemm2_<dtype>.hip translation units).
 #pragma once
 #include "conv_gemm2_impl.h"
+#include "conv_gemm_phased.h"
 
 namespace st {
 
@@ -35,6 +36,10 @@ static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemm
         if (taps == 3 && epi == EPI_F32) return launch_g2<P, 3, EPI_F32, 128, 64, 2, 2>(a, s);
     } else if (cfg == 5) {   // RC64: 256 ch x 64 frames, 8 waves of 64x32 (QKV planes of small grids)
         if (taps == 1 && epi == EPI_QKV) return launch_g2<P, 1, EPI_QKV, 256, 64, 4, 2>(a, s);
+    } else if (cfg == 6) {   // 256 x 254 tile, k = 3, phased K loop with three weight buffers (conv_gemm_phased.h)
+        if (taps == 3 && epi == EPI_ACT16) return launch_phased3<P, EPI_ACT16>(a, s);
+        if (taps == 3 && epi == EPI_F32) return launch_phased3<P, EPI_F32>(a, s);
+        if (taps == 3 && epi == EPI_RESGATE) return launch_phased3<P, EPI_RESGATE>(a, s);
     } else if (cfg == 2) {   // 3-buffer k=3 kernel (counted vmcnt), 128 ch x 126 frames
         if (taps == 3 && epi == EPI_ACT16) return launch_g3<P, EPI_ACT16>(a, s);
         if (taps == 3 && epi == EPI_F32) return launch_g3<P, EPI_F32>(a, s);

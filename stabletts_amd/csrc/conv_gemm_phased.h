@@ -1,0 +1,226 @@
+// Phased K loop for the k = 3 convolutions on 256-channel x 254-frame tiles (8 waves of 128 ch x 64 frames): the same
+// implicit GEMM as conv_gemm2_kernel (conv_gemm2_impl.h), same operand layouts, same accumulation order -- results are
+// bit-identical -- with a K loop built for overlap instead of one `vmcnt(0)` + __syncthreads per stage:
+//
+//  * A stage (one tap of one 64-channel chunk) is cut into FOUR phases, one per 16-wide K slice over the whole wave
+//    tile: 4 + 2 fragment reads (nothing is read twice), 8 MFMAs on 8 independent accumulators, 24 fragment registers.
+//  * The two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) run half a phase apart with ONE raw
+//    s_barrier per phase: group 0 takes it between its reads and its MFMAs, group 1 before its reads, so between two
+//    barriers group 0 runs [M(p-1) R(p)] while group 1 runs [R(p-1) M(p-1)] -- on every SIMD one wave is in its MFMAs
+//    (s_setprio 1) while the other reads fragments and issues LDS-DMA.
+//  * THREE weight buffers and counted waits: the weight tile of stage s+2 is issued during stage s and retired by a
+//    `s_waitcnt vmcnt(N)` in stage s+1 that leaves the younger pieces in flight, so every LDS-DMA piece has more than
+//    a whole stage to land.  (With two buffers and a drain per stage the stage time is set by the DMA round trip:
+//    removing the MFMAs from that loop changed its time by 4 %.)
+//
+// LDS: 2 activation + 3 weight buffers of exactly 32 KiB = the CU's 160 KiB, which is why the activation tile is
+// 256 rows = frames t0-1 .. t0+254 (254 output frames per tile + its own halo, like conv_gemm3_kernel): accumulator
+// columns 254, 255 read two rows past the tile (inside the block's own LDS) and are dropped by the epilogue.
+//
+// Per stage (c, j), stage index s = 3c + j, weight buffer = j (3 | stages per chunk); pieces = 1 KiB, 4 + 4 per wave:
+//   phase 1: (j = 1: A(c+1) piece 2)        phase 2: W(s+2) pieces 0, 1
+//   phase 3: WAIT, W(s+2) piece 2 (j = 0: A(c+1) piece 0)        phase 4: W(s+2) piece 3 (j = 0: A piece 1; j = 1: A piece 3)
+// The wait must retire W(s+1) (and at j = 2 the whole of A(c+1)).  Younger than W(s+1)'s last piece at that point:
+//   j = 0: W(s+2) p0,p1 -> vmcnt(2)     j = 1: A1, A2, W p0,p1 -> vmcnt(4)     j = 2: A3, W p0,p1, A3 needed -> vmcnt(2)
+// Every piece is issued unconditionally (rows outside [0, T) read the zero page), so the counts hold for every wave;
+// the last chunk, which issues less, drains with vmcnt(0).
+// Hazards, counted in barriers ("ticks"; group 1 runs a phase one tick after group 0):
+//   RAW  the wait sits in phase 3 (group 1: tick 4s+3), the first read of the retired buffer in phase 1 of the next
+//        stage (group 0: tick 4s+4): a barrier every wave has passed lies between them.
+//   WAR  W(s+3) overwrites W(s): last read in phase 4 of stage s (group 1: tick 4s+4, retired by lgkmcnt(0) inside the
+//        tick), first issued in phase 2 of stage s+1 (group 0: tick 4s+5).  A(c+1) overwrites A(c-1), last read in
+//        phase 4 of stage (c-1, 2); its first piece is issued in phase 3 of stage (c, 0).
+// Measured (MI355X, FFN conv_2 of the headline solve, 48 stages): K loop 58 us = 74 % MFMA utilisation inside the loop
+// (conv_gemm2_kernel: ~66 us); the kernel's remaining 37 us are its HBM-bound epilogue.
+#pragma once
+#include "conv_gemm2_impl.h"
+
+namespace st {
+
+#define ST_RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <class P, int EPI, bool TWO_SRC>
+__global__ __launch_bounds__(512, 1)
+void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
+    constexpr int BC = 256, BF = 256, BFV = BF - 2, WC = 2, WF = 4, TAPS = 3;
+    using vec8 = typename P::vec8;
+    constexpr int FC = 4, FF = 2, TC = BC / WC, TF = BF / WF;
+    constexpr int A_BYTES = BF * 128, W_BYTES = BC * 128;
+    constexpr int WPW = 4, APW = 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                    // 2 buffers
+    unsigned char* Ws = smem + 2 * A_BYTES;      // 3 buffers
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int grp = wave >> 2;
+    const int cin = g.c0 + g.c1 + g.c2;
+    const int nch = cin >> 6;
+    const int T = g.T;
+    const unsigned char* zeros = (const unsigned char*)g.zeros;
+    const int prow = lane >> 3;
+    const int wrow = wc * TC + l31, arow0 = wf * TF + l31;
+
+    const int total = g.n_items * g.tiles_f * g.tiles_c;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int tc = lin % g.tiles_c;
+    const int rest = lin / g.tiles_c;
+    const int tf = rest % g.tiles_f;
+    const int n = rest / g.tiles_f;
+    const int cbase = tc * BC, t0 = tf * BFV;
+
+    const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
+    const unsigned char* a1 = TWO_SRC ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;
+    const unsigned char* wsrc = (const unsigned char*)g.w + (size_t)n * g.w_item_stride;
+
+    unsigned voffW[WPW], voffA0[APW], voffA1[TWO_SRC ? APW : 1];
+    bool validA[APW];
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) {
+        const int row = (wave * WPW + k) * 8 + prow;
+        voffW[k] = (unsigned)((cbase + row) * TAPS * cin * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int k = 0; k < APW; ++k) {
+        const int row = (wave * APW + k) * 8 + prow;
+        const int t = t0 + row - 1;
+        const unsigned segb = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        validA[k] = (t >= 0 && t < T);
+        voffA0[k] = (unsigned)(t * g.c0 * 2) + segb;
+        if constexpr (TWO_SRC) voffA1[k] = (unsigned)(t * g.c1 * 2) + segb;
+    }
+    auto issueW = [&](int c, int j, int buf, int k0, int k1) {
+        // (the stage base is wave-uniform; said explicitly, hipcc otherwise keeps it in VGPRs in this kernel and the
+        // SGPR operand of the asm statement does not assemble)
+        const uintptr_t sbv = (uintptr_t)(wsrc + (size_t)(j * cin + (c << 6)) * 2);
+        const unsigned char* sb = (const unsigned char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(sbv >> 32)) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbv));
+#pragma unroll
+        for (int k = 0; k < WPW; ++k)
+            if (k >= k0 && k < k1) glds16s(sb, voffW[k], Ws + buf * W_BYTES + (wave * WPW + k) * 1024);
+    };
+    auto issueA = [&](int c, int buf, int k0, int k1) {
+        int ch0 = c << 6;
+        if (ch0 >= g.c0 + g.c1) ch0 -= g.c0 + g.c1;
+        if (!TWO_SRC || ch0 < g.c0) {
+            const unsigned char* sb = a0 + (size_t)ch0 * 2;
+#pragma unroll
+            for (int k = 0; k < APW; ++k)
+                if (k >= k0 && k < k1) glds16b(validA[k] ? sb + voffA0[k] : zeros, As + buf * A_BYTES + (wave * APW + k) * 1024);
+        } else if constexpr (TWO_SRC) {
+            const unsigned char* sb = a1 + (size_t)(ch0 - g.c0) * 2;
+#pragma unroll
+            for (int k = 0; k < APW; ++k)
+                if (k >= k0 && k < k1) glds16b(validA[k] ? sb + voffA1[k] : zeros, As + buf * A_BYTES + (wave * APW + k) * 1024);
+        }
+    };
+
+    f32x16_t acc[FC][FF];
+    g2_init_acc<EPI, FC, FF>(acc, g, cbase + wc * TC, hi);
+
+    // Fragment addresses: rows 32 apart share the swizzle term ((row >> 1) & 7), so the four channel fragments (and the
+    // two frame fragments) of a wave are ONE per-lane address per k-slice plus a 4096-byte immediate.
+    vec8 wfr[FC], afr[FF];
+    auto load_frags = [&](const unsigned char* Wb, const unsigned char* Ab, int j, int ks) {
+        // (the row indices pass through an empty asm statement: hipcc otherwise hoists all 24 per-(tap, k-slice)
+        // addresses out of the chunk loop and holds them in VGPRs next to the 128 accumulators -- the kernel spills)
+        int wr = wrow, ar0 = arow0;
+        asm volatile("" : "+v"(wr), "+v"(ar0));
+        const unsigned wad = (unsigned)(wr * 128 + (((ks * 2 + hi) ^ ((wr >> 1) & 7)) << 4));
+        const int arow = ar0 + j;          // rows 256, 257 (last two frame columns at j = 2) fall into the next buffer
+        const unsigned aad = (unsigned)(arow * 128 + (((ks * 2 + hi) ^ ((arow >> 1) & 7)) << 4));
+#pragma unroll
+        for (int a = 0; a < FC; ++a) wfr[a] = as_vec8<P>(*(const uint4*)(Wb + wad + a * 4096));
+#pragma unroll
+        for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(*(const uint4*)(Ab + aad + b * 4096));
+    };
+    auto mma = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // One phase = fragment reads (+ this phase's LDS-DMA issues), reads retired, 8 MFMAs, with ONE barrier: group 0 takes
+    // it between its reads and its MFMAs, group 1 before its reads -- so between two barriers group 0 runs [M(p-1) R(p)]
+    // while group 1 runs [R(p-1) M(p-1)]: on every SIMD one wave is in its MFMAs while the other reads / issues.
+#define ST_PHASE(ks, ISSUE)                                      \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    if (grp) ST_RAW_BARRIER();                                   \
+    load_frags(Wb, Ab, j, ks);                                   \
+    ISSUE;                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    if (!grp) ST_RAW_BARRIER();                                  \
+    mma();                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // prologue: A(0), W(0) resident; W(1) in flight (retired by stage 0's wait)
+    issueA(0, 0, 0, APW); issueW(0, 0, 0, 0, WPW);
+    issueW(0, 1, 1, 0, WPW);
+    ST_DMA_WAIT(4);
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        const bool lastc = (c == nch - 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // stage s + 2 = (c, j + 2) or (c + 1, j - 1); its buffer is (j + 2) % 3
+            const int c2 = (j == 0) ? c : c + 1, j2 = (j + 2) % 3;
+            const bool w2 = (j == 0) || !lastc;
+            const unsigned char* Ab = As + (c & 1) * A_BYTES;
+            const unsigned char* Wb = Ws + j * W_BYTES;
+            ST_PHASE(0, if (j == 1 && !lastc) issueA(c + 1, (c + 1) & 1, 2, 3))
+            ST_PHASE(1, if (w2) issueW(c2, j2, j2, 0, 2))
+            ST_PHASE(2, {
+                if (lastc && j >= 1) ST_DMA_WAIT(0);
+                else if (j == 1) ST_DMA_WAIT(4);
+                else ST_DMA_WAIT(2);
+                if (w2) issueW(c2, j2, j2, 2, 3);
+                if (j == 0 && !lastc) issueA(c + 1, (c + 1) & 1, 0, 1);
+            })
+            ST_PHASE(3, {
+                if (w2) issueW(c2, j2, j2, 3, 4);
+                if (j == 0 && !lastc) issueA(c + 1, (c + 1) & 1, 1, 2);
+                if (j == 1 && !lastc) issueA(c + 1, (c + 1) & 1, 3, 4);
+            })
+        }
+    }
+#undef ST_PHASE
+    __syncthreads();
+
+    if constexpr (EPI == EPI_ACT16 || EPI == EPI_GELU16)
+        g2_epilogue_act16<P, BC, BF, WC, WF, EPI == EPI_GELU16>(acc, smem, g, n, t0, BFV, cbase, wave, lane);
+    else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
+}
+
+template <class P, int EPI>
+static hipError_t launch_phased3(const ConvGemmArgs& a, hipStream_t s) {
+    constexpr int BC = 256, BF = 256, LDS = 5 * 32768;
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_done_dev[dev_]) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_phased3_kernel<P, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_gemm_phased3_kernel<P, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_done_dev[dev_] = true;
+    }
+    if (!a.zeros || (a.cout % BC) != 0 || ((a.c0 | a.c1 | a.c2) & 63) != 0 || (a.c2 && a.c2 > a.c0) || a.ksplit > 1) return hipErrorInvalidValue;
+    ConvGemmArgs b = a;
+    b.tiles_f = (a.T + BF - 3) / (BF - 2);
+    b.tiles_c = a.cout / BC;
+    const int total = b.n_items * b.tiles_f * b.tiles_c;
+    const int grid = ((total + 7) / 8) * 8;
+    if (a.c1) hipLaunchKernelGGL((conv_gemm_phased3_kernel<P, EPI, true>), dim3(grid), dim3(512), LDS, s, b);
+    else      hipLaunchKernelGGL((conv_gemm_phased3_kernel<P, EPI, false>), dim3(grid), dim3(512), LDS, s, b);
+    return hipGetLastError();
+}
+
+}  // namespace st

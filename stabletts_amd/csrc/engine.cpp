@@ -21,7 +21,7 @@ namespace sthost {
 std::string g_create_error;
 
 // Default of the two-part solve (see st_cfm_solve): -1 = automatic (large fixed-grid batches), 1 = never.
-constexpr int kDefaultSplit = 1;
+constexpr int kDefaultSplit = -1;
 
 const char* kProfNames[PC_COUNT] = {
     "prep", "prenet_conv", "in_proj", "film_ln1", "qkv_rope", "attention", "out_proj", "ln2",
@@ -120,7 +120,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         }
     }
     int cfg;
-    if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = G2_BIG;
+    if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = (e->phased && taps == 3) ? G2_PHASED : G2_BIG;
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
     else if (taps == 3 && a.c0 + a.c1 >= 512 && a.c2 == 0) cfg = G2_K3PIPE;
     else cfg = G2_T128;
@@ -765,6 +765,7 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     e->K = cfg->kernel_size; e->G = cfg->gin_channels;
     e->kind = kind; e->n_vocab = n_vocab;
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
+    if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
     if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
         if (atoi(v) == 0) {                               // key-split attention): results independent of the batch composition
             e->splitk_target = 0; e->small_tiles = 0; e->attn_small_blocks = 0;

@@ -89,6 +89,7 @@ struct st_engine {
     // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     int big_min_blocks = 192;
+    int phased = 1;                     // k = 3 convs on 256-wide tiles use the phased K loop (conv_gemm_phased.h); ST_PHASED=0: A/B runs
     int splitk_max = kSplitKMax, splitk_min_stages = 4;
     int small_tiles = 256;              // conv launches of <= this many 128x128 tiles use the 64-frame tile variants (0: never)
     int splitk_target = 256;            // split-K: blocks a small conv launch is brought up to (gemm())
