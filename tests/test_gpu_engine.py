@@ -58,6 +58,54 @@ def test_two_part_solve_is_bitwise_identical(sd, cfg_params, monkeypatch, solver
         monkeypatch.delenv("ST_HIP_GRAPH")
 
 
+def _fresh(sd, monkeypatch, dtype="bf16", **env):
+    """A decoder whose engine is created under the given environment (the tile-policy knobs are read at st_create)."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dtype)
+    d.estimator.load_state_dict(sd)
+    d = d.to("cuda:0")
+    d.estimator.engine()
+    for k in env:
+        monkeypatch.delenv(k)
+    return d
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_phased_k_loop_is_bit_identical_to_the_two_buffer_kernel(sd, cfg_params, monkeypatch, dtype):
+    """conv_gemm_phased3_kernel (K-slice phases, staggered wave groups, three weight buffers, counted LDS-DMA waits,
+    254-frame tiles) accumulates every output in the same order as conv_gemm2_kernel's 256 x 256 tile: whole solves
+    must agree bit for bit -- at tile-edge lengths (254 | 255 | 509 frames: one tile, one frame into the second, two
+    tiles minus 1+...), ragged masks and with the long-skip (two-source) convolutions.  ST_BIG_MIN_BLOCKS=1 forces the
+    256-wide tiles at these small batch sizes; a race in the hand-counted vmcnt / barrier protocol would show up as
+    run-to-run differences, so every solve is repeated."""
+    kw = _kw(cfg_params, 3.0)
+    old = _fresh(sd, monkeypatch, dtype, ST_BIG_MIN_BLOCKS="1", ST_PHASED="0", ST_SMALL_GRID="0")
+    new = _fresh(sd, monkeypatch, dtype, ST_BIG_MIN_BLOCKS="1", ST_PHASED="1", ST_SMALL_GRID="0")
+    for B, T, lengths in ((2, 254, [254, 100]), (1, 255, [255]), (3, 509, [509, 508, 3]), (2, 700, [700, 255])):
+        inp = make_inputs(B, T, seed=90 + T, lengths=lengths)
+        ref = _solve(old, inp, 2, "euler", kw)
+        for _ in range(3):
+            assert torch.equal(_solve(new, inp, 2, "euler", kw), ref), (B, T)
+
+
+def test_small_grid_variants_match_the_plain_kernels(sd, cfg_params, monkeypatch):
+    """Split-K convolutions (+ row-wise finish kernel), 64-frame tiles and the key-split attention kernel change only
+    the fp32 summation order: a small solve with them (default) and without (ST_SMALL_GRID=0) must agree to fp32
+    rounding amplified through the 16-bit operands -- far inside the parity gate -- and repeat bit for bit."""
+    kw = _kw(cfg_params, 3.0)
+    plain = _fresh(sd, monkeypatch, "f16", ST_SMALL_GRID="0")
+    small = _fresh(sd, monkeypatch, "f16")
+    for B, T, lengths in ((1, 500, [500]), (2, 130, [130, 77]), (1, 31, [31])):
+        inp = make_inputs(B, T, seed=70 + T, lengths=lengths)
+        a, b = _solve(plain, inp, 4, "euler", kw), _solve(small, inp, 4, "euler", kw)
+        assert torch.equal(_solve(small, inp, 4, "euler", kw), b)
+        rel = float((a - b).abs().max() / a.abs().max())
+        print(f"B={B} T={T}: small-grid vs plain {rel:.2e}")
+        assert rel < 2e-4
+
+
 def test_graph_replay_survives_rope_table_growth(dec, cfg_params, monkeypatch):
     """the RoPE tables are reallocated when T grows; instantiated graphs that baked the old pointers
     into the QKV kernel arguments must be dropped.  Sequence: capture a graph at T=200, then a longer-T solve with a
