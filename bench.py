@@ -37,10 +37,6 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/f16, MI355X_MICROARCH.md chip-level table
 HBM_PEAK_GBPS = 8000.0         # HBM3E, same table
 B_PER_GPU, T_FRAMES, N_STEPS, CFG = 32, 1000, 10, 3.0
-# kernel behind each profile class at the headline batch size (rocprofv3 names, profiles/README.md)
-DOM_KERNEL = {"ffn_conv1": "conv_gemm_phased3_kernel<EPI_ACT16>", "ffn_conv2": "conv_gemm_phased3_kernel<EPI_RESGATE>",
-              "lsc_conv": "conv_gemm_phased3_kernel<EPI_F32>", "attention": "attention_kernel",
-              "qkv_rope": "conv_gemm2_kernel<EPI_QKV, 256x256>", "out_proj": "conv_gemm2_kernel<EPI_RESGATE, 256x256>"}
 PROFILE_STRIDE = 4             # timed region: HIP events around every 4th launch of the dominant kernel class
 
 
@@ -98,9 +94,9 @@ def cpu_baseline(sd, cfg_params, budget_s=20.0):
 
 # kernel that implements each profiled class on the default path (for the PMC traffic lookup)
 CLASS_KERNEL = {
-    "ffn_conv1": "conv_gemm2_kernel<st::Op{DT}, 3, 0, 256, 256, 2, 4>",
-    "ffn_conv2": "conv_gemm2_kernel<st::Op{DT}, 3, 2, 256, 256, 2, 4>",
-    "lsc_conv": "conv_gemm2_kernel<st::Op{DT}, 3, 1, 256, 256, 2, 4>",
+    "ffn_conv1": "conv_gemm_phased3_kernel<st::Op{DT}, 0, false>",
+    "ffn_conv2": "conv_gemm_phased3_kernel<st::Op{DT}, 2, false>",
+    "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
     "attention": "attention_kernel<st::Op{DT}, false>",
     "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 256, 2, 4>",
     "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4>",
@@ -109,7 +105,7 @@ CLASS_KERNEL = {
 
 def _pmc_table():
     """Committed rocprofv3 PMC passes of this same command (newest round first)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", name))), name
         except Exception:
@@ -327,7 +323,7 @@ def main():
                          "valid_frames": valid_frames_total, "padded_T_this_rank": T_batch},
             "parity": "f16 operands meet north_star's 1e-3 (displacement metric, tests/test_gpu_parity.py); bf16 operands "
                       "(BASELINE's named dtype) measure ~4e-3",
-            "roofline": {"bound": "mfma", "kernel": f"{DOM_KERNEL.get(dom, 'conv_gemm2_kernel')} [{dom}]", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": (CLASS_KERNEL.get(dom, "conv_gemm2_kernel").replace("{DT}", "BF16" if args.dtype == "bf16" else "F16") + f" [{dom}]"), "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic(dom, args.dtype), "traffic_unit": "HBM bytes per launch (PMC)",
                          "launches_sampled": p["launches"], "sample_stride": PROFILE_STRIDE, "avg_launch_us": avg_s * 1e6,
