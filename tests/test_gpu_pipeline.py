@@ -53,6 +53,22 @@ def test_synthesise_chain_native_vs_oracle(sd, cfg_params):
     assert torch.isfinite(out).all()
     assert float((out - oref).abs().max() / (oref - z).abs().max()) <= 3e-3           # encoder + decoder errors chained
     assert _rel(out, oref) <= 1e-3
+    # ---- ... and the vocoder on the decoder's mel (api.py:76): native Vocos vs the numpy oracle on the ORACLE's mel
+    # (random decoder weights leave the mel ~ noise z: values of a few units, fine as a vocoder input)
+    import types
+    from oracle import vocos_oracle as vo
+    from stabletts_amd.vocos import Vocos
+    vc = vo.VocosConfig
+    voc = Vocos(types.SimpleNamespace(input_channels=vc.input_channels, dim=vc.dim, intermediate_dim=vc.intermediate_dim,
+                                      num_layers=vc.num_layers), types.SimpleNamespace(n_fft=vc.n_fft, hop_length=vc.hop_length))
+    vsd = vo.make_vocos_state_dict(77)
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in vsd.items()})
+    audio = voc.cuda()(out.cuda()).cpu().numpy()
+    aref = vo.vocos_forward(vsd, oref.numpy())
+    assert audio.shape == (B, out.shape[2] * 512)
+    aerr = float(np.abs(audio - aref).max() / np.abs(aref).max())
+    print(f"chain: mel {tuple(out.shape)} -> audio {audio.shape}, waveform vs oracle chain {aerr:.2e}")
+    assert aerr <= 2.5e-3                                                              # decoder error + f16 vocoder operands (measured 8.6e-4)
 
 
 def test_decoder_fuzz_random_shapes_solvers_cfg(sd, cfg_params):
