@@ -797,9 +797,11 @@ void st_destroy(st_engine* e) {
     train_destroy(e);
     vocos_destroy(e);
     if (e->gstream) hipStreamDestroy(e->gstream);
-    if (e->s2) hipStreamDestroy(e->s2);
+    for (int k = 1; k < kMaxParts; ++k) {
+        if (e->sx[k]) hipStreamDestroy(e->sx[k]);
+        if (e->ev_joinx[k]) hipEventDestroy(e->ev_joinx[k]);
+    }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    if (e->ev_join) hipEventDestroy(e->ev_join);
     for (auto& kv : e->params) if (kv.second.dev) hipFree(kv.second.dev);
     for (void* p : e->owned) hipFree(p);
     for (auto& kv : e->caps) if (kv.second.dev) hipFree(kv.second.dev);
@@ -976,7 +978,8 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         const char* sv = getenv("ST_SPLIT");
         const int want = sv ? atoi(sv) : kDefaultSplit;
         const int64_t frames = (int64_t)(use_cfg ? 2 : 1) * B * T;
-        if (!adaptive && !e->capture && B >= 2 && (want == 2 || (want != 0 && want != 1 && frames >= 24000 && B >= 8))) nparts = 2;
+        if (!adaptive && !e->capture && B >= 2 && (want >= 2 || (want != 0 && want != 1 && frames >= 24000 && B >= 8))) nparts = 2;
+        if (want > 2 && B >= want) nparts = std::min(want, kMaxParts);
         if (want == 1 || want == 0) nparts = 1;
     }
     struct Part { Plan p; int b0, nb; hipStream_t s; const float* mask; };
@@ -992,11 +995,12 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         for (auto& pt : parts) bind_plan(e, &pt.p);
     }
     if ((rc = ensure_rope(e, T, s))) return rc;
-    if (nparts > 1 && !e->s2) {
-        HIPCHK(e, hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
-        HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    }
+    if (nparts > 1 && !e->ev_fork) HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int k = 1; k < nparts; ++k)
+        if (!e->sx[k]) {
+            HIPCHK(e, hipStreamCreateWithFlags(&e->sx[k], hipStreamNonBlocking));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_joinx[k], hipEventDisableTiming));
+        }
 
     // evaluation times, fp32 arithmetic as torchdiffeq does on the fp32 t_span (flow_matching.py:46)
     const std::vector<float> grid = linspace01(n_steps);
@@ -1083,9 +1087,9 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         e->conc = nparts;
         if (nparts > 1) {
             HIPCHK(e, hipEventRecord(e->ev_fork, cs));
-            HIPCHK(e, hipStreamWaitEvent(e->s2, e->ev_fork, 0));
+            for (int k = 1; k < nparts; ++k) HIPCHK(e, hipStreamWaitEvent(e->sx[k], e->ev_fork, 0));
         }
-        for (int k = 0; k < nparts; ++k) parts[k].s = k == 0 ? cs : e->s2;
+        for (int k = 0; k < nparts; ++k) parts[k].s = k == 0 ? cs : e->sx[k];
         for (auto& pt : parts) {
             if ((rc = run_prenet(e, pt.p, pt.s))) return rc;
             if ((rc = run_adaln(e, pt.p, pt.s))) return rc;
@@ -1098,9 +1102,9 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                 for (auto& pt : parts)
                     if ((rc = step_fixed(pt, i, pt.s))) return rc;
         }
-        if (nparts > 1) {
-            HIPCHK(e, hipEventRecord(e->ev_join, e->s2));
-            HIPCHK(e, hipStreamWaitEvent(cs, e->ev_join, 0));
+        for (int k = 1; k < nparts; ++k) {
+            HIPCHK(e, hipEventRecord(e->ev_joinx[k], e->sx[k]));
+            HIPCHK(e, hipStreamWaitEvent(cs, e->ev_joinx[k], 0));
         }
         return ST_OK;
     };

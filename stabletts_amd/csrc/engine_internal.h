@@ -40,6 +40,7 @@ struct VocosState;     // engine_vocos.cpp
 
 }  // namespace sthost
 
+constexpr int kMaxParts = 4;
 constexpr int kSplitKMax = 16;
 constexpr size_t kSplitKBytes = 32u << 20;
 
@@ -97,8 +98,8 @@ struct st_engine {
     float* kpart = nullptr;             // split-K partial planes [ks][items][T][256] fp32
     size_t kpart_bytes = 0;
     int conc = 1;                       // solve parts in flight on separate streams (their launches share the chip)
-    hipStream_t s2 = nullptr;           // stream of the second solve part
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t sx[kMaxParts] = {};     // streams of solve parts 1.. (part 0 runs on the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_joinx[kMaxParts] = {};
 
     // HIP-graph replay of the fixed-grid solve body (ST_HIP_GRAPH=1): one instantiated graph per solve signature
     struct SolveGraph {

@@ -52,6 +52,9 @@ def test_two_part_solve_is_bitwise_identical(sd, cfg_params, monkeypatch, solver
         monkeypatch.setenv("ST_SPLIT", "2")
         two = _solve(dec, inp, n, solver, kw)
         assert torch.equal(one, two)
+        monkeypatch.setenv("ST_SPLIT", "4")             # up to four parts (B >= 4; B = 2 stays at two)
+        assert torch.equal(_solve(dec, inp, n, solver, kw), one)
+        monkeypatch.setenv("ST_SPLIT", "2")
         monkeypatch.setenv("ST_HIP_GRAPH", "1")
         for _ in range(3):                      # eager, capture, replay
             assert torch.equal(_solve(dec, inp, n, solver, kw), one)
