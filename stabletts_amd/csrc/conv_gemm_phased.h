@@ -30,8 +30,8 @@
 //   WAR  W(s+3) overwrites W(s): last read in phase 4 of stage s (group 1: tick 4s+4, retired by lgkmcnt(0) inside the
 //        tick), first issued in phase 2 of stage s+1 (group 0: tick 4s+5).  A(c+1) overwrites A(c-1), last read in
 //        phase 4 of stage (c-1, 2); its first piece is issued in phase 3 of stage (c, 0).
-// Measured (MI355X, FFN conv_2 of the headline solve, 48 stages): K loop 58 us = 74 % MFMA utilisation inside the loop
-// (conv_gemm2_kernel: ~66 us); the kernel's remaining 37 us are its HBM-bound epilogue.
+// Measured (MI355X, FFN conv_2 of the headline solve, 48 stages): K loop 64 us = 67 % MFMA utilisation inside the loop
+// (conv_gemm2_kernel: ~74 us); the kernel's remaining 36 us are its HBM-bound epilogue.
 #pragma once
 #include "conv_gemm2_impl.h"
 
