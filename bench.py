@@ -299,6 +299,31 @@ def main():
         sec1 = time_variant(dec, one, 10, None, 10)
         extras["config1_latency"] = {"workload": "B=1 x T=500, n_timesteps=10 euler, CFG off", "ms_per_solve": sec1 * 1e3,
                                      "mel_frames_per_sec": 500 / sec1, "dtype": args.dtype}
+        # (c) the step after the path: the batch's mel through the native Vocos vocoder (seeded weights of the
+        #     oracle's generator; 44.1 kHz, hop 512) -> seconds of audio per second for decoder + vocoder
+        import types
+        from oracle import vocos_oracle as vo
+        from stabletts_amd.vocos import Vocos
+        vc = vo.VocosConfig
+        voc = Vocos(types.SimpleNamespace(input_channels=vc.input_channels, dim=vc.dim, intermediate_dim=vc.intermediate_dim,
+                                          num_layers=vc.num_layers), types.SimpleNamespace(n_fft=vc.n_fft, hop_length=vc.hop_length))
+        voc.load_state_dict({k: torch.from_numpy(v) for k, v in vo.make_vocos_state_dict(77).items()})
+        voc = voc.to(dev)
+        for _ in range(2):
+            voc(out)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(10):
+            audio = voc(out)
+        torch.cuda.synchronize(dev)
+        voc_s = (time.perf_counter() - t2) / 10
+        assert torch.isfinite(audio).all()
+        audio_seconds = valid_frames_total * 512 / 44100.0
+        extras["vocoder"] = {"workload": f"Vocos (8 ConvNeXt blocks dim 512 + ISTFT head), the batch's {B_PER_GPU} x {T_batch} mel frames, f16 operands",
+                             "ms_per_batch": voc_s * 1e3, "mel_frames_per_sec": B_PER_GPU * T_batch / voc_s,
+                             "decoder_plus_vocoder_audio_seconds_per_second": audio_seconds / (elapsed / args.steps + voc_s),
+                             "real_time_factor": (elapsed / args.steps + voc_s) / audio_seconds}
+        del voc
 
     if rank == 0:
         p = prof[dom]
