@@ -240,3 +240,26 @@ def test_ddp_two_ranks_match_single_process(tmp_path):
     assert a["losses"][-1] < a["losses"][0]                       # it trains
     for k in a["params"]:
         assert _rel(a["params"][k].numpy(), b["params"][k].numpy()) <= 2e-3, k
+
+
+def test_ddp_over_rccl_one_rank(tmp_path):
+    """The nccl (= RCCL on ROCm) backend around the shim's parameters: a 1-GPU box cannot host two RCCL ranks, but a
+    world_size-1 process group still runs RCCL's communicator set-up, DDP's parameter broadcast / bucket construction over
+    the 116 native parameters and the bucketed gradient all-reduce on the GPU (train.py:25-31,51).  Losses and parameters
+    after 4 AdamW steps must equal the plain single-process run."""
+    outd, out1 = tmp_path / "rccl.pt", tmp_path / "one.pt"
+    port = 29300 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "train_ddp.py"), "--out", str(outd), "--backend", "nccl",
+           "--force-dist"]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_ddp.py"), "--out", str(out1)],
+                        env=dict(os.environ), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    a, b = torch.load(outd), torch.load(out1)
+    assert a["world"] == 1 and len(a["losses"]) == 4
+    for la, lb in zip(a["losses"], b["losses"]):
+        assert abs(la - lb) <= 1e-5 * abs(lb), (a["losses"], b["losses"])
+    for k in a["params"]:
+        assert _rel(a["params"][k].numpy(), b["params"][k].numpy()) <= 1e-4, k

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--items", type=int, default=4)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and wrap in DDP even for one rank "
+                    "(a 1-GPU box can exercise the nccl = RCCL backend that way)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -31,7 +33,8 @@ def main():
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local % ndev if os.environ.get("BENCH_SHARE_GPU") == "1" else local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -47,7 +50,7 @@ def main():
     dec.estimator.load_state_dict(sd)
     dec = dec.to(dev).eval()            # eval: dropout off, so that the two runs are comparable step by step
     model = dec
-    if world > 1:
+    if use_dist:
         model = torch.nn.parallel.DistributedDataParallel(dec, device_ids=[dev.index])
     opt = torch.optim.AdamW(dec.parameters(), lr=2e-4)
     B, T = args.items, args.frames
@@ -60,7 +63,7 @@ def main():
     for step in range(args.steps):
         t_rand = torch.rand(B, 1, 1, generator=gen); z = torch.randn(B, 128, T, generator=gen)
         opt.zero_grad()
-        if world > 1:       # DDP hooks fire on the module's forward: route compute_loss through it
+        if use_dist:       # DDP hooks fire on the module's forward: route compute_loss through it
             loss, _ = _DDPLoss(model)(x1[sl].to(dev), inp["mask"][sl].to(dev), inp["mu"][sl].to(dev), inp["c"][sl].to(dev),
                                       t_rand[sl].to(dev), z[sl].to(dev))
         else:
@@ -69,7 +72,7 @@ def main():
         loss.backward()
         opt.step()
         lv = loss.detach().clone()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(lv); lv /= world
         losses.append(float(lv))
     if rank == 0:
@@ -77,7 +80,7 @@ def main():
                 "blocks.5.block.adaLN_modulation.2.weight", "time_mlp.layer.0.weight"]
         params = {k: v.detach().cpu() for k, v in dec.estimator.named_parameters() if k in keep}
         torch.save(dict(world=world, losses=losses, params=params), args.out)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
