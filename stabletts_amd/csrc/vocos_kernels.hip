@@ -77,40 +77,61 @@ hipError_t launch_voc_ln(int dtype, const float* x, const float* w, const float*
 }
 
 // ---------------------------------------------------------------- ConvNeXt block prologue: depthwise k = 7 conv + LayerNorm (module.py:35-37)
-// One wave per frame, lane = 8 channels: 7 neighbouring rows of the fp32 residual stream (L2-resident) x 56 taps.
-template <class P>
+// One wave per R consecutive frames of one utterance (R = 4; 1 for small batches), lane = 8 channels: the R + 6 fp32 residual
+// rows of the window are requested up front and the 56 taps of the lane's channels loaded once per wave.
+template <class P, int R>
 __global__ __launch_bounds__(256) void voc_dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ dw,
                                                             const float* __restrict__ dbias, const float* __restrict__ w,
-                                                            const float* __restrict__ b, int T, long long rows, void* h16) {
+                                                            const float* __restrict__ b, int T, int groups_per_item, long long n_groups,
+                                                            void* h16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long row = (long long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    const int t = (int)(row % T);
+    const long long grp = (long long)blockIdx.x * 4 + wave;
+    if (grp >= n_groups) return;
+    const int item = (int)(grp / groups_per_item);
+    const int t0 = (int)(grp - (long long)item * groups_per_item) * R;
     const int ch = lane * 8;
+    const float* xi = x + (size_t)item * T * 512 + ch;
+    const Row8 zero = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    Row8 win[R + 6];          // every row of the window is requested before anything is computed: one exposed latency per wave
+#pragma unroll
+    for (int j = 0; j < R + 6; ++j) {
+        const int t = t0 - 3 + j;
+        win[j] = (t >= 0 && t < T) ? ld8(xi + (size_t)t * 512) : zero;      // zero padding of nn.Conv1d(padding=3)
+    }
     float wt[8][7];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 7; ++j) wt[i][j] = dw[(size_t)(ch + i) * 7 + j];
-    Row8 acc = ld8(dbias + ch);
+    const Row8 bias = ld8(dbias + ch), lw = ld8(w + ch), lb = ld8(b + ch);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int tt = t + j - 3;
-        if (tt < 0 || tt >= T) continue;            // wave-uniform: zero padding of nn.Conv1d(padding=3)
-        const Row8 v = ld8(x + (size_t)(row + j - 3) * 512 + ch);
-        acc.a.x += wt[0][j] * v.a.x; acc.a.y += wt[1][j] * v.a.y; acc.a.z += wt[2][j] * v.a.z; acc.a.w += wt[3][j] * v.a.w;
-        acc.b.x += wt[4][j] * v.b.x; acc.b.y += wt[5][j] * v.b.y; acc.b.z += wt[6][j] * v.b.z; acc.b.w += wt[7][j] * v.b.w;
+    for (int r = 0; r < R; ++r) {
+        const int t = t0 + r;
+        if (t >= T) break;                          // wave-uniform
+        Row8 acc = bias;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const Row8& v = win[r + j];
+            acc.a.x += wt[0][j] * v.a.x; acc.a.y += wt[1][j] * v.a.y; acc.a.z += wt[2][j] * v.a.z; acc.a.w += wt[3][j] * v.a.w;
+            acc.b.x += wt[4][j] * v.b.x; acc.b.y += wt[5][j] * v.b.y; acc.b.z += wt[6][j] * v.b.z; acc.b.w += wt[7][j] * v.b.w;
+        }
+        voc_ln8(acc, lw, lb);
+        st16x8<P>((unsigned char*)h16 + (((size_t)item * T + t) * 512 + ch) * 2, acc);
     }
-    voc_ln8(acc, ld8(w + ch), ld8(b + ch));
-    st16x8<P>((unsigned char*)h16 + ((size_t)row * 512 + ch) * 2, acc);
+}
+
+template <class P, int R>
+static void launch_dw(const float* x, const float* dw, const float* dbias, const float* w, const float* b, int B, int T, void* h16, hipStream_t s) {
+    const int gpi = (T + R - 1) / R;
+    const long long n_groups = (long long)B * gpi;
+    hipLaunchKernelGGL((voc_dwconv_ln_kernel<P, R>), dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, s, x, dw, dbias, w, b, T, gpi, n_groups, h16);
 }
 
 hipError_t launch_voc_dwconv_ln(int dtype, const float* x, const float* dw, const float* dbias, const float* w, const float* b,
                                 int B, int T, void* h16, hipStream_t s) {
-    const long long rows = (long long)B * T;
-    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((voc_dwconv_ln_kernel<OpBF16>), grid, blk, 0, s, x, dw, dbias, w, b, T, rows, h16);
-    else                  hipLaunchKernelGGL((voc_dwconv_ln_kernel<OpF16>), grid, blk, 0, s, x, dw, dbias, w, b, T, rows, h16);
+    const bool big = (long long)B * T >= 8192;      // small batches: one frame per wave (more waves than a few CUs' worth)
+    if (dtype == DT_BF16) { if (big) launch_dw<OpBF16, 4>(x, dw, dbias, w, b, B, T, h16, s); else launch_dw<OpBF16, 1>(x, dw, dbias, w, b, B, T, h16, s); }
+    else                  { if (big) launch_dw<OpF16, 4>(x, dw, dbias, w, b, B, T, h16, s); else launch_dw<OpF16, 1>(x, dw, dbias, w, b, B, T, h16, s); }
     return hipGetLastError();
 }
 
