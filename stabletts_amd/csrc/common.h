@@ -57,6 +57,18 @@ __device__ __forceinline__ float silu_fast(float x) {
 
 // Cross-lane reductions on the VALU (DPP row rotations + gfx950 v_permlane{16,32}_swap): __shfl_xor lowers to
 // ds_bpermute_b32, an LDS-crossbar round trip of ~60+ cycles per step on the dependent chain.
+// nn.GELU() (exact erf form) with erf from Abramowitz & Stegun 7.1.26: branch-free, |error| <= 1.5e-7 on erf, 4.7e-7 absolute on
+// GELU over [-8, 8] (fp32 evaluation) -- far below the 16-bit rounding of the activation it produces; libm's erff is a
+// piecewise evaluation whose branches both run under a divergent wave.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = x * 0.70710678118654752f, az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float er = copysignf(fmaf(-poly, e, 1.0f), z);
+    return 0.5f * x * (1.0f + er);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));

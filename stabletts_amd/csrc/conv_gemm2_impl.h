@@ -271,7 +271,7 @@ __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][
             f32x16_t v = acc[a][b];
             if constexpr (GELU) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+                for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
             } else if (do_silu) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = silu_fast(v[r]);
