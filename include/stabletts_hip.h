@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ST_ABI_VERSION 1
+#define ST_ABI_VERSION 2
 
 enum {
     ST_OK = 0,
@@ -85,8 +85,17 @@ int st_num_params(const st_engine* e);
 int st_param_info(const st_engine* e, int index, const char** name, int64_t* shape);
 
 /* Packs the uploaded fp32 parameters into the engine's 16-bit MFMA operand layouts.  Must be
- * called after loading (and again after any parameter update). */
+ * called after loading (and again after any parameter update).  Synchronises the device. */
 int st_finalize(st_engine* e);
+
+/* The training-loop form of the two calls above (nn.Parameter semantics: train.py:78-82 updates the weights in place
+ * every iteration).  st_bind_param makes the engine READ the fp32 tensor at the caller's device pointer instead of
+ * keeping a copy: `data` (device memory, reference shape) stays owned by the caller and must outlive the binding
+ * (re-bind after the storage moves).  After an in-place update of bound tensors (optimizer.step()), st_repack
+ * re-packs the 16-bit operand copies INTO THE EXISTING BUFFERS as kernels on `stream` -- no allocation, no host
+ * copy, no device synchronisation; it needs one earlier st_finalize (which allocates them). */
+int st_bind_param(st_engine* e, const char* name, const float* data, const int64_t* shape, int ndim);
+int st_repack(st_engine* e, void* stream);
 
 /* Replaces Decoder.forward(t, x, mask, mu, c) (models/estimator.py:103-138): ONE vector-field
  * evaluation.  t: device fp32, t_len = 1 (inference, 0-dim t) or B (training, flow_matching.py:99).
@@ -182,11 +191,18 @@ int st_vocos_forward(st_engine* e, const float* mel, float* audio, int B, int T,
 int st_train_forward(st_engine* e, const float* t, const float* x, const float* mu, const float* mask, const float* c,
                      float* out, int B, int T, float p_dropout, uint64_t seed, void* stream);
 
+/* Serial number of the st_train_forward whose activations the engine holds now (monotonically increasing from 1;
+ * 0 = none: never run, or invalidated by a parameter update).  The engine keeps the activations of ONE forward. */
+int64_t st_train_serial(const st_engine* e);
+
 /* Replaces torch.autograd's backward of that call.  grad_out: d loss / d out (B, n_feats, T).  Writes d loss / d x,
  * d loss / d mu (B, n_feats, T) and d loss / d c (B, gin) where the pointer is not NULL, and the gradient of every
- * parameter into engine-owned fp32 buffers in the reference shapes (fetch with st_param_grad).  Must follow an
- * st_train_forward on the same engine (one forward may be followed by one backward). */
-int st_train_backward(st_engine* e, const float* grad_out, float* grad_x, float* grad_mu, float* grad_c, void* stream);
+ * parameter into engine-owned fp32 buffers in the reference shapes (fetch with st_param_grad).
+ * `serial`, B, T identify the forward this is the backward OF (st_train_serial right after that st_train_forward):
+ * if another forward has replaced its activations, or the parameters were re-packed, or the shape differs, the
+ * call fails with ST_ERR_STATE before touching any caller memory. */
+int st_train_backward(st_engine* e, int64_t serial, int B, int T, const float* grad_out, float* grad_x, float* grad_mu,
+                      float* grad_c, void* stream);
 
 /* Copies the gradient of one parameter (reference state_dict name, `numel` fp32 values) to the device pointer dst. */
 int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, void* stream);

@@ -23,7 +23,7 @@ SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_S
 # every symbol include/stabletts_hip.h declares
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
-    "st_finalize", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
+    "st_finalize", "st_bind_param", "st_repack", "st_train_serial", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad",
@@ -83,6 +83,12 @@ def load():
     lib.st_num_params.restype = c_int
     lib.st_finalize.argtypes = [c_void_p]
     lib.st_finalize.restype = c_int
+    lib.st_bind_param.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(ctypes.c_int64), c_int]
+    lib.st_bind_param.restype = c_int
+    lib.st_repack.argtypes = [c_void_p, c_void_p]
+    lib.st_repack.restype = c_int
+    lib.st_train_serial.argtypes = [c_void_p]
+    lib.st_train_serial.restype = ctypes.c_int64
     lib.st_estimator_forward.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int, c_int, c_void_p]
     lib.st_estimator_forward.restype = c_int
@@ -117,7 +123,7 @@ def load():
     lib.st_device_bytes.restype = ctypes.c_int64
     lib.st_train_forward.argtypes = [c_void_p] + [c_void_p] * 6 + [c_int, c_int, c_float, ctypes.c_uint64, c_void_p]
     lib.st_train_forward.restype = c_int
-    lib.st_train_backward.argtypes = [c_void_p] + [c_void_p] * 4 + [c_void_p]
+    lib.st_train_backward.argtypes = [c_void_p, ctypes.c_int64, c_int, c_int] + [c_void_p] * 4 + [c_void_p]
     lib.st_train_backward.restype = c_int
     lib.st_param_grad.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64, c_void_p]
     lib.st_param_grad.restype = c_int
@@ -131,7 +137,7 @@ def load():
     lib.st_create_vocoder.restype = c_int
     lib.st_vocos_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.st_vocos_forward.restype = c_int
-    if lib.st_abi_version() != 1:
+    if lib.st_abi_version() != 2:
         raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -141,7 +147,7 @@ class Engine:
     """Thin owner of one ``st_engine`` handle."""
 
     def __init__(self, noise_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
-                 gin_channels, operand_dtype="bf16", device=0, text_encoder_vocab=None, vocoder=None):
+                 gin_channels, operand_dtype="f16", device=0, text_encoder_vocab=None, vocoder=None):
         """text_encoder_vocab: None -> CFM decoder estimator (st_create); n_vocab -> TextEncoder handle
         (st_create_text_encoder; noise_channels is then the encoder's out_channels).
         vocoder: dict(input_channels, dim, intermediate_dim, num_layers, n_fft, hop_length) -> Vocos handle
@@ -204,6 +210,19 @@ class Engine:
             self._check(self.lib.st_load_param(self.handle, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()))
         self._check(self.lib.st_finalize(self.handle))
 
+    def bind_parameters(self, named_params):
+        """named_params: iterable of (reference name, fp32 contiguous tensor ON THE ENGINE'S DEVICE).  The engine reads
+        the tensors in place from now on (st_bind_param: no copy; the caller keeps them alive) and packs its 16-bit
+        operand copies (st_finalize)."""
+        for name, t in named_params:
+            shape = (ctypes.c_int64 * t.dim())(*t.shape)
+            self._check(self.lib.st_bind_param(self.handle, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()))
+        self._check(self.lib.st_finalize(self.handle))
+
+    def repack(self, stream):
+        """After an in-place update of the bound tensors: re-pack the 16-bit copies as kernels on ``stream`` (no sync)."""
+        self._check(self.lib.st_repack(self.handle, ctypes.c_void_p(stream)))
+
     def estimator_forward(self, t, x, mu, mask, c, out, stream):
         B, _, T = x.shape
         self._check(self.lib.st_estimator_forward(self.handle, t.data_ptr(), int(t.numel()), x.data_ptr(), mu.data_ptr(),
@@ -235,10 +254,15 @@ class Engine:
                                               c.data_ptr(), out.data_ptr(), B, T, float(p_dropout), int(seed),
                                               ctypes.c_void_p(stream)))
 
-    def train_backward(self, grad_out, grad_x, grad_mu, grad_c, stream):
+    def train_serial(self):
+        """Serial of the grad-enabled forward whose activations the engine holds (0: none)."""
+        return int(self.lib.st_train_serial(self.handle))
+
+    def train_backward(self, serial, grad_out, grad_x, grad_mu, grad_c, stream):
         ptr = lambda v: v.data_ptr() if v is not None else None      # noqa: E731
-        self._check(self.lib.st_train_backward(self.handle, grad_out.data_ptr(), ptr(grad_x), ptr(grad_mu), ptr(grad_c),
-                                               ctypes.c_void_p(stream)))
+        B, _, T = grad_out.shape
+        self._check(self.lib.st_train_backward(self.handle, int(serial), B, T, grad_out.data_ptr(), ptr(grad_x), ptr(grad_mu),
+                                               ptr(grad_c), ctypes.c_void_p(stream)))
 
     def param_grad(self, name, dst, stream):
         self._check(self.lib.st_param_grad(self.handle, name.encode(), dst.data_ptr(), dst.numel(), ctypes.c_void_p(stream)))

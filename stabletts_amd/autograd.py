@@ -32,25 +32,31 @@ class _EstimatorFn(torch.autograd.Function):
             eng.train_forward(t32, x32, mu32, m32, c32, out, p_drop, seed, torch.cuda.current_stream(dev).cuda_stream)
         ctx.decoder, ctx.names = decoder, names
         ctx.shapes = (x32.shape, c32.shape)
-        ctx.engine_key = decoder._engine_key
+        ctx.engine, ctx.serial = eng, eng.train_serial()     # the engine keeps the activations of ONE forward: its serial
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         decoder = ctx.decoder
-        eng = decoder._engine
-        if eng is None or decoder._engine_key != ctx.engine_key:
-            raise RuntimeError("the estimator's parameters changed between forward and backward (the activations live in "
-                               "the engine: one backward per forward, before the next optimizer step)")
+        eng = ctx.engine
+        if eng is not decoder._engine or eng.handle is None or eng.train_serial() != ctx.serial:
+            raise RuntimeError(
+                "stabletts_amd: this backward's activations are gone -- the engine keeps the activations of ONE "
+                "grad-enabled estimator forward, and another grad-enabled forward, an optimizer step / parameter update "
+                "or a device move happened since.  Call backward() before the next grad-enabled forward (for "
+                "loss_a + loss_b or gradient accumulation: backward each loss separately, gradients accumulate in .grad).")
         dev = decoder.device()
         g = grad_out.detach().to(dtype=torch.float32).contiguous()
+        if tuple(g.shape) != tuple(ctx.shapes[0]):
+            raise RuntimeError(f"grad_out has shape {tuple(g.shape)}, the forward produced {tuple(ctx.shapes[0])}")
         need = ctx.needs_input_grad          # (decoder, names, t, x, mask, mu, c, *params)
-        gx = torch.empty(ctx.shapes[0], device=dev) if need[3] else None
-        gmu = torch.empty(ctx.shapes[0], device=dev) if need[5] else None
-        gc = torch.empty(ctx.shapes[1], device=dev) if need[6] else None
+        f32 = dict(device=dev, dtype=torch.float32)      # the kernels write fp32 whatever torch's default dtype is
+        gx = torch.empty(ctx.shapes[0], **f32) if need[3] else None
+        gmu = torch.empty(ctx.shapes[0], **f32) if need[5] else None
+        gc = torch.empty(ctx.shapes[1], **f32) if need[6] else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            eng.train_backward(g, gx, gmu, gc, stream)
+            eng.train_backward(ctx.serial, g, gx, gmu, gc, stream)     # the C ABI re-checks serial, B, T (ST_ERR_STATE)
             pgrads = []
             for name, p, nd in zip(ctx.names, decoder.parameters(), need[7:]):
                 if not nd:

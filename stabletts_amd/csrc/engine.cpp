@@ -802,7 +802,7 @@ void st_destroy(st_engine* e) {
         if (e->ev_joinx[k]) hipEventDestroy(e->ev_joinx[k]);
     }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    for (auto& kv : e->params) if (kv.second.dev) hipFree(kv.second.dev);
+    for (auto& kv : e->params) if (kv.second.dev && !kv.second.borrowed) hipFree(kv.second.dev);
     for (void* p : e->owned) hipFree(p);
     for (auto& kv : e->caps) if (kv.second.dev) hipFree(kv.second.dev);
     prof_collect(e);
@@ -838,10 +838,46 @@ int st_load_param(st_engine* e, const char* name, const float* data, const int64
     for (int i = 0; ok && i < ndim; ++i) ok = p.shape[i] == shape[i];
     if (!ok) return e->fail(ST_ERR_INVALID, std::string("shape mismatch for ") + name);
     HIPCHK(e, hipSetDevice(e->device));
+    if (p.borrowed) { p.dev = nullptr; p.borrowed = false; }
     if (!p.dev) HIPCHK(e, hipMalloc((void**)&p.dev, (size_t)p.numel() * 4));
     HIPCHK(e, hipMemcpy(p.dev, data, (size_t)p.numel() * 4, hipMemcpyDefault));
     p.loaded = true;
     e->finalized = false;
+    return ST_OK;
+}
+
+int st_bind_param(st_engine* e, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!e) return ST_ERR_INVALID;
+    if (!name || !data || !shape) return e->fail(ST_ERR_INVALID, "null argument");
+    auto it = e->params.find(name);
+    if (it == e->params.end()) return e->fail(ST_ERR_INVALID, std::string("unexpected parameter name: ") + name);
+    Param& p = it->second;
+    bool ok = (int)p.shape.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = p.shape[i] == shape[i];
+    if (!ok) return e->fail(ST_ERR_INVALID, std::string("shape mismatch for ") + name);
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, data) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != e->device) {
+        (void)hipGetLastError();
+        return e->fail(ST_ERR_INVALID, std::string("st_bind_param needs a pointer to memory of the engine's device: ") + name);
+    }
+    if (p.dev && !p.borrowed) { HIPCHK(e, hipSetDevice(e->device)); HIPCHK(e, hipDeviceSynchronize()); hipFree(p.dev); }
+    p.dev = const_cast<float*>(data);
+    p.borrowed = true;
+    p.loaded = true;
+    e->finalized = false;
+    return ST_OK;
+}
+
+int st_repack(st_engine* e, void* stream) {
+    if (!e) return ST_ERR_INVALID;
+    if (e->kind == 2) return e->fail(ST_ERR_UNSUPPORTED, "st_repack: vocoder handles re-pack through st_finalize");
+    if (!e->packed_once) return e->fail(ST_ERR_STATE, "st_repack needs one earlier st_finalize (it allocates the packed buffers)");
+    for (auto& kv : e->params)
+        if (!kv.second.loaded) return e->fail(ST_ERR_STATE, "parameter not loaded: " + kv.first);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = pack_all(e, (hipStream_t)stream); if (rc) return rc;
+    train_invalidate(e);
+    e->finalized = true;
     return ST_OK;
 }
 
@@ -851,24 +887,41 @@ int st_finalize(st_engine* e) {
     for (auto& kv : e->params)
         if (!kv.second.loaded) return e->fail(ST_ERR_STATE, "parameter not loaded: " + kv.first);
     HIPCHK(e, hipDeviceSynchronize());
-    e->drop_graphs();          // instantiated graphs hold the old packed-weight pointers
-    for (void* p : e->owned) hipFree(p);
-    e->owned.clear(); e->weight_bytes = 0;
-    if (e->kind == 2) return vocos_finalize(e);
+    if (e->kind == 2) {
+        e->drop_graphs();
+        for (void* p : e->owned) hipFree(p);
+        e->owned.clear(); e->weight_bytes = 0;
+        return vocos_finalize(e);
+    }
+    e->drop_graphs();          // instantiated graphs hold fp32 parameter pointers that a re-bind may have changed
+    int rc = pack_all(e, nullptr); if (rc) return rc;
+    HIPCHK(e, hipDeviceSynchronize());
+    train_invalidate(e);
+    e->finalized = true;
+    return ST_OK;
+}
+
+}  // extern "C"
+
+namespace sthost {
+// Packs every convolution's weights into the 16-bit MFMA operand layouts on stream `s`.  The packed buffers are
+// allocated by the first call and re-used by every later one (shapes are fixed by the configuration), so instantiated
+// HIP graphs and in-flight launch sequences keep valid pointers and a re-pack is pure stream work.
+int pack_all(st_engine* e, hipStream_t s) {
     const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
-    hipStream_t s = nullptr;
     // generic packer: (cout, cin_total, taps) source slice -> Conv with padded dims.  split: the packed K dimension
     // is [W_hi | W_hi | W_lo] (W_lo = W - float(W_hi)), the weight side of a split-precision operand
     auto pack = [&](Conv& cv, const std::string& wname, const float* bias_src, int cout, int cout_p, int cin_total,
                     int taps, int ci_off, int ci_cnt, int cin_p, bool split) -> int {
         cv.cout = cout_p; cv.cin = split ? 3 * cin_p : cin_p; cv.taps = taps; cv.split = split;
         const size_t wbytes = (size_t)cout_p * taps * cv.cin * 2;
-        int rc = dev_alloc(e, &cv.w, wbytes); if (rc) return rc;
+        int rc;
+        if (!cv.w && (rc = dev_alloc(e, &cv.w, wbytes))) return rc;
         HIPCHK(e, hipMemsetAsync(cv.w, 0, wbytes, s));
         for (int part = 0; part < (split ? 3 : 1); ++part)
             HIPCHK(e, launch_pack_weight(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cv.cin,
                                          part * cin_p, cin_p, part == 2, s));
-        rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4); if (rc) return rc;
+        if (!cv.bias && (rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4))) return rc;
         HIPCHK(e, hipMemsetAsync(cv.bias, 0, (size_t)cout_p * 4, s));
         if (bias_src) HIPCHK(e, hipMemcpyAsync(cv.bias, bias_src, (size_t)cout * 4, hipMemcpyDeviceToDevice, s));
         return ST_OK;
@@ -877,7 +930,7 @@ int st_finalize(st_engine* e) {
     if (e->kind == 1) {
         if ((rc = pack(e->fin, "proj.weight", P(e, "proj.bias"), M, Mp, C, 1, 0, C, C, false))) return rc;
     } else {
-    e->pre.assign(3, Conv());
+    if (e->pre.size() != 3) e->pre.assign(3, Conv());
     if ((rc = pack(e->pre[0], "cond_proj.0.weight", P(e, "cond_proj.0.bias"), F, F, M, K, 0, M, Mp, false))) return rc;
     if ((rc = pack(e->pre[1], "cond_proj.2.weight", P(e, "cond_proj.2.bias"), F, F, F, K, 0, F, F, false))) return rc;
     if ((rc = pack(e->pre[2], "cond_proj.4.weight", P(e, "cond_proj.4.bias"), C, C, F, K, 0, F, F, false))) return rc;
@@ -886,19 +939,19 @@ int st_finalize(st_engine* e) {
     if ((rc = pack(e->inx, "in_proj.weight", nullptr, C, C, C + M, 1, 0, M, Mp, true))) return rc;
     if ((rc = pack(e->inc, "in_proj.weight", P(e, "in_proj.bias"), C, C, C + M, 1, M, C, C, true))) return rc;
     if ((rc = pack(e->fin, "final_proj.weight", P(e, "final_proj.bias"), M, Mp, C, 1, 0, C, C, true))) return rc;
-    e->lsc.assign(L / 2, Conv());
+    if ((int)e->lsc.size() != L / 2) e->lsc.assign(L / 2, Conv());
     for (int i = 0; i < L / 2; ++i) {
         const std::string n = "lsc_layers." + std::to_string(i);
         if ((rc = pack(e->lsc[i], n + ".weight", P(e, n + ".bias"), C, C, 2 * C, K, 0, 2 * C, 2 * C, false))) return rc;
     }
     }
-    e->qkv.assign(L, Conv()); e->oproj.assign(L, Conv()); e->ffn1.assign(L, Conv()); e->ffn2.assign(L, Conv());
+    if ((int)e->qkv.size() != L) { e->qkv.assign(L, Conv()); e->oproj.assign(L, Conv()); e->ffn1.assign(L, Conv()); e->ffn2.assign(L, Conv()); }
     for (int i = 0; i < L; ++i) {
         const std::string b = e->blk(i);
         Conv& q = e->qkv[i];
         q.cout = 3 * C; q.cin = C; q.taps = 1;
-        if ((rc = dev_alloc(e, &q.w, (size_t)3 * C * C * 2))) return rc;
-        if ((rc = dev_alloc(e, (void**)&q.bias, (size_t)3 * C * 4))) return rc;
+        if (!q.w && (rc = dev_alloc(e, &q.w, (size_t)3 * C * C * 2))) return rc;
+        if (!q.bias && (rc = dev_alloc(e, (void**)&q.bias, (size_t)3 * C * 4))) return rc;
         int r = 0;
         for (const char* nm : {"q", "k", "v"}) {
             const std::string n = b + "attn.conv_" + nm;
@@ -910,11 +963,12 @@ int st_finalize(st_engine* e) {
         if ((rc = pack(e->ffn1[i], b + "mlp.conv_1.weight", P(e, b + "mlp.conv_1.bias"), F, F, C, K, 0, C, C, false))) return rc;
         if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F, false))) return rc;
     }
-    HIPCHK(e, hipDeviceSynchronize());
-    train_invalidate(e);
-    e->finalized = true;
+    e->packed_once = true;
     return ST_OK;
 }
+}  // namespace sthost
+
+extern "C" {
 
 int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x, const float* mu,
                          const float* mask, const float* c, float* out, int B, int T, void* stream) {
@@ -1291,7 +1345,7 @@ int st_profile_read(st_engine* e, int cls, int64_t* launches, double* total_ms, 
 int64_t st_device_bytes(const st_engine* e) {
     if (!e) return ST_ERR_INVALID;
     int64_t n = e->weight_bytes + (int64_t)e->ws_cap;
-    for (auto& kv : e->params) if (kv.second.dev) n += kv.second.numel() * 4;
+    for (auto& kv : e->params) if (kv.second.dev && !kv.second.borrowed) n += kv.second.numel() * 4;
     return n;
 }
 

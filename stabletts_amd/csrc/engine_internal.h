@@ -19,6 +19,7 @@ struct Param {
     std::vector<int64_t> shape;
     float* dev = nullptr;
     bool loaded = false;
+    bool borrowed = false;     // st_bind_param: dev is the caller's tensor, never freed here
     int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
 };
 
@@ -57,6 +58,7 @@ struct st_engine {
     }
     std::map<std::string, sthost::Param> params;
     bool finalized = false;
+    bool packed_once = false;          // pack_all has allocated the packed-weight buffers (st_repack re-uses them)
     std::string err;
     int64_t weight_bytes = 0;
 
@@ -139,6 +141,7 @@ int ensure_rope(st_engine* e, int T, hipStream_t s);
 int check_ready(st_engine* e, int B, int T);
 extern std::string g_create_error;
 int vocos_finalize(st_engine* e);
+int pack_all(st_engine* e, hipStream_t s);            // (re)packs every 16-bit weight; allocates on the first call only
 void vocos_destroy(st_engine* e);
 
 // HIP-event bracket around the launches of one kernel class (st_profile_*)

@@ -43,6 +43,7 @@ struct TrainState {
     int B = 0, T = 0, Tp = 0;
     float p_drop = 0.f; unsigned long long seed = 0;
     bool have_fwd = false;
+    int64_t serial = 0;                        // of the forward whose activations are held (have_fwd); counts st_train_forward calls
     bool packed = false;                       // dgrad weights match the current parameters
     // saved tensors
     void *mu16, *x16, *x16lo, *a1, *p1, *a2, *p2, *cond16, *cond16lo, *h0_16, *x3lo;
@@ -337,7 +338,7 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         for (int i = 0; i < L; ++i) {
             const std::string bn = "t" + std::to_string(i) + ".";
             capture(e, bn + "x1", ts->L[i].x1, R * C, false, s); capture(e, bn + "x2", ts->L[i].x2, R * C, false, s);
-            capture(e, bn + "x3", ts->L[i].x3, R * C, false, s);
+            capture(e, bn + "x3", ts->L[i].x3, R * C, false, s); capture(e, bn + "h1", ts->L[i].h1, R * C, true, s);
             capture(e, bn + "q", ts->L[i].q, R * C, true, s); capture(e, bn + "k", ts->L[i].k, R * C, true, s);
             capture(e, bn + "vt", ts->L[i].vt, (int64_t)N * C * Tp, true, s); capture(e, bn + "attn", ts->L[i].attn16, R * C, true, s);
             capture(e, bn + "lse", ts->L[i].lse, (int64_t)N * H * T, false, s);
@@ -345,7 +346,13 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         }
     }
     ts->have_fwd = true;
+    ts->serial += 1;
     return ST_OK;
+}
+
+int64_t st_train_serial(const st_engine* e) {
+    if (!e || !e->train || !e->train->have_fwd) return 0;
+    return e->train->serial;
 }
 
 }  // extern "C"
@@ -394,9 +401,15 @@ float* G(TrainState* ts, const std::string& name) { return ts->grads.at(name); }
 
 extern "C" {
 
-int st_train_backward(st_engine* e, const float* grad_out, float* grad_x, float* grad_mu, float* grad_c, void* stream) {
+int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float* grad_out, float* grad_x, float* grad_mu,
+                      float* grad_c, void* stream) {
     if (!e) return ST_ERR_INVALID;
-    if (e->kind != 0 || !e->train || !e->train->have_fwd) return e->fail(ST_ERR_STATE, "st_train_backward needs a preceding st_train_forward");
+    if (e->kind != 0 || !e->train || !e->train->have_fwd)
+        return e->fail(ST_ERR_STATE, "st_train_backward needs a preceding st_train_forward (none held: never run, or invalidated by a parameter update)");
+    if (serial != e->train->serial || B_ != e->train->B || T_ != e->train->T)
+        return e->fail(ST_ERR_STATE, "st_train_backward: the engine holds the activations of forward #" + std::to_string(e->train->serial) +
+                       " (B=" + std::to_string(e->train->B) + ", T=" + std::to_string(e->train->T) + "), not of #" + std::to_string(serial) +
+                       " (B=" + std::to_string(B_) + ", T=" + std::to_string(T_) + "): one backward per forward, before the next grad-enabled forward");
     if (!grad_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;

@@ -14,17 +14,19 @@ from . import _lib
 
 
 def _param_key(module):
-    """(storage address, version counter) of every parameter: changes whenever autograd-visible code rewrites a
-    weight.  Inference tensors (a module built or moved under torch.inference_mode) carry no version counter; they
-    key on the address alone and need sync_weights() after an in-place update."""
-    key = []
+    """(storage identity, version counters) of the parameters.  The first changes when a tensor moves (``.to()``,
+    ``.half()``, re-assignment), the second whenever autograd-visible code rewrites a weight in place (optimizer step,
+    ``load_state_dict``).  Inference tensors (a module built or moved under torch.inference_mode) carry no version
+    counter; they key on the address alone and need sync_weights() after an in-place update."""
+    ptrs, vers = [], []
     for p in module.parameters():
         try:
             ver = p._version
         except RuntimeError:
             ver = -1
-        key.append((p.data_ptr(), ver))
-    return tuple(key)
+        ptrs.append((p.data_ptr(), p.dtype, p.is_contiguous()))
+        vers.append(ver)
+    return tuple(ptrs), tuple(vers)
 
 
 class _ParamsOnly(nn.Module):
@@ -99,7 +101,7 @@ class Decoder(nn.Module):
 
     def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels,
                  dropout=0.1, n_layers=1, n_heads=4, kernel_size=3, gin_channels=0, use_lsc=True,
-                 operand_dtype="bf16"):
+                 operand_dtype="f16"):
         super().__init__()
         assert hidden_channels % 2 == 0, "SinusoidalPosEmb requires dim to be even"
         if not use_lsc:
@@ -128,7 +130,9 @@ class Decoder(nn.Module):
                                                    padding=kernel_size // 2) for _ in range(self.n_lsc_layers)])
         self.initialize_weights()
         self._engine = None
-        self._engine_key = None
+        self._engine_key = None        # storage identity of the parameters the engine is bound to
+        self._engine_vers = None       # their version counters at the last (re)pack
+        self._staging = None           # fp32 copies the engine reads when the parameters themselves are not fp32
 
     def initialize_weights(self):
         """adaLN-Zero (models/estimator.py:98-101)."""
@@ -139,7 +143,7 @@ class Decoder(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()      # the ctypes engine handle is per-process, never copied/pickled
         st["_engine"] = None
-        st["_engine_key"] = None
+        st["_engine_key"] = st["_engine_vers"] = st["_staging"] = None
         return st
 
     # ------------------------------------------------------------------ native engine plumbing
@@ -147,11 +151,11 @@ class Decoder(nn.Module):
         return _param_key(self)
 
     def sync_weights(self):
-        """Force the engine to re-read the parameters at the next call.  Needed only after writes that bypass
+        """Force the engine to re-pack its 16-bit weight copies at the next call.  Needed only after writes that bypass
         autograd's version counter (``p.data.copy_(ema)``, ``m.weight.data.normal_()``, as some EMA / weight-swap
         utilities do); in-place ops on the parameters themselves, optimizer steps, ``load_state_dict`` and
         ``.to()`` are detected automatically."""
-        self._engine_key = None
+        self._engine_vers = None
 
     def _apply(self, fn, *a, **k):            # .to() / .cuda() / .half(): storage changes
         self._engine_key = None
@@ -162,7 +166,12 @@ class Decoder(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     def engine(self):
-        """The st_engine bound to the device of the parameters, with weights in sync."""
+        """The st_engine bound to the device of the parameters, with weights in sync.
+
+        The engine READS the fp32 parameters where torch keeps them (st_bind_param: no copy); what it owns are the
+        packed 16-bit MFMA operand copies.  After an in-place update (every optimizer step of a training loop) those
+        are re-packed by kernels on the current stream (st_repack): no allocation, no host copy, no synchronisation.
+        Only a change of storage (first use, ``.to()``, dtype change) takes the slow path (bind + st_finalize)."""
         p0 = next(self.parameters())
         if p0.device.type != "cuda":
             raise RuntimeError("stabletts_amd: the estimator runs only on a HIP device (move the module with "
@@ -174,12 +183,25 @@ class Decoder(nn.Module):
             self._engine = _lib.Engine(self.noise_channels, self.hidden_channels, self.filter_channels, self.n_heads,
                                        self.n_layers, self.kernel_size, self.gin_channels, self.operand_dtype, dev)
             self._engine_key = None
-        key = self._param_key()
+        key, vers = self._param_key()
         if key != self._engine_key:
             with torch.no_grad():
-                torch.cuda.synchronize(dev)
-                self._engine.load_state_dict(self.state_dict())
-            self._engine_key = key
+                named = list(self.named_parameters())
+                if all(p.dtype == torch.float32 and p.is_contiguous() for _, p in named):
+                    self._staging = None
+                    bound = [(n, p.detach()) for n, p in named]
+                else:       # e.g. a .half() module: the engine reads fp32 staging copies
+                    self._staging = [p.detach().to(dtype=torch.float32).contiguous() for _, p in named]
+                    bound = [(n, s) for (n, _), s in zip(named, self._staging)]
+                self._engine.bind_parameters(bound)        # st_finalize synchronises the device: pending writes have landed
+            self._engine_key, self._engine_vers = key, vers
+        elif vers != self._engine_vers:
+            with torch.no_grad(), torch.cuda.device(dev):
+                if self._staging is not None:
+                    for s, p in zip(self._staging, self.parameters()):
+                        s.copy_(p)
+                self._engine.repack(torch.cuda.current_stream(dev).cuda_stream)
+            self._engine_vers = vers
         return self._engine
 
     def device(self):

@@ -16,7 +16,7 @@ from .estimator import DiTConVBlock, _param_key
 
 class TextEncoder(nn.Module):
     def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size,
-                 p_dropout, gin_channels, operand_dtype="bf16"):
+                 p_dropout, gin_channels, operand_dtype="f16"):
         super().__init__()
         self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
         self.filter_channels, self.n_heads, self.n_layers = filter_channels, n_heads, n_layers

@@ -76,6 +76,10 @@ class Vocos(nn.Module):
         c = self.cfg
         self.backbone = VocosBackbone(c["input_channels"], c["dim"], c["intermediate_dim"], c["num_layers"])
         self.head = ISTFTHead(c["dim"], c["n_fft"], c["hop_length"])
+        # inference-only module (the reference only ever calls it under inference_mode, api.py:64,76):
+        # its parameters do not ask for gradients, so a plain ``voc(mel)`` is legal in any grad mode; asking for them
+        # (requires_grad_(True) or a mel that requires grad) raises in forward instead of silently training nothing
+        self.requires_grad_(False)
         self._engine = None
         self._engine_key = None
 
@@ -118,8 +122,9 @@ class Vocos(nn.Module):
 
     def forward(self, x):
         """mel (B, input_channels, T) -> audio (B, T * hop_length)  (model.py:17-20)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            raise NotImplementedError("the native vocoder is inference-only (SURVEY 8f-4); run it under torch.no_grad()")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("the native vocoder is inference-only (SURVEY 8f-4): it has no backward, so a mel or "
+                                      "parameters that require grad would silently train nothing; run it under torch.no_grad()")
         dev = next(self.parameters()).device
         if x.device != dev:
             raise ValueError(f"mel is on {x.device}, the vocoder's parameters are on {dev}")

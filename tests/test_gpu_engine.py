@@ -179,3 +179,20 @@ def test_two_ranks_sharing_one_gpu_equal_single_process(tmp_path):
     for i in range(12):
         assert torch.equal(got["mel"][i], want["mel"][i]), i
     assert got["imbalance"][0] < 1.5
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's plain command form): bench.py
+    re-executes itself under torch.distributed.run, one rank per GPU (BENCH_SHARE_GPU=1: both ranks on the one visible
+    GPU), and rank 0 prints exactly one JSON line for the whole job."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["dtype"] == "f16"
+    assert j["config"]["global_batch"] == 64 and j["value"] > 0 and j["roofline"]["frac"] > 0

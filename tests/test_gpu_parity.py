@@ -6,8 +6,9 @@ Gates (fixed noise, max over the whole tensor):
   * full ODE solve: the DISPLACEMENT metric max|out - ref| / max|ref - z| -- what the decoder actually computes.
     (max|out - ref| / max|ref| is also asserted, but at random weights the mel is ~95 % the input noise z, so that
     number alone would tolerate a 2 % error of the decoder's own contribution.)
-  north_star's bar is 1e-3.  **f16 operands meet it** on both metrics (gates 1e-3, measured 4-6e-4) and are the
-  parity-gated configuration.  **bf16 operands do not**: 8 mantissa bits give ~4e-3 per evaluation / displacement
+  north_star's bar is 1e-3.  **f16 operands -- the DEFAULT of every module and the dtype bench.py headlines -- meet
+  it** on both metrics: gates 7e-4 (measured 2-4.4e-4), 1e-3 with O(1) adaLN gates (measured 6.1e-4).  **bf16 operands
+  (opt-in) do not**: 8 mantissa bits give ~4e-3 per evaluation / displacement
   (2^-9 per operand rounding through ~40 GEMMs; the split-precision operands of in_proj / final_proj remove only
   the un-gated part); their gates below are regression guards, not a claim of meeting 1e-3.
 """
@@ -22,9 +23,9 @@ from oracle.inputs import make_inputs
 
 pytestmark = pytest.mark.gpu
 
-NFE_TOL = {"bf16": 1e-2, "f16": 1e-3}
+NFE_TOL = {"bf16": 1e-2, "f16": 7e-4}
 MEL_TOL = 1e-3
-DISP_TOL = {"bf16": 1e-2, "f16": 1e-3}
+DISP_TOL = {"bf16": 1e-2, "f16": 7e-4}
 
 
 def _rel(a, b):
@@ -161,7 +162,7 @@ def test_config3_at_size_long_ode(decoders, sd, cfg_params, solver, n):
 def c2(decoders, cfg_params):
     inp = make_inputs(32, 1000, seed=0, ragged=True)
     kw = _cfg(cfg_params, 3.0, True)
-    out = _solve(decoders["bf16"], inp, 10, "euler", kw, inp["z"])
+    out = _solve(decoders["f16"], inp, 10, "euler", kw, inp["z"])      # f16 = the shipping default
     return inp, out
 
 
@@ -177,11 +178,11 @@ def test_c2_padding_is_exactly_zero_and_finite(c2):
 def test_c2_deterministic_and_batch_permutation_equivariant(decoders, cfg_params, c2):
     inp, out = c2
     kw = _cfg(cfg_params, 3.0, True)
-    again = _solve(decoders["bf16"], inp, 10, "euler", kw, inp["z"])
+    again = _solve(decoders["f16"], inp, 10, "euler", kw, inp["z"])
     assert torch.equal(again, out)                                    # bitwise repeatable
     perm = torch.randperm(32, generator=torch.Generator().manual_seed(0))
     pin = {k: v[perm] for k, v in inp.items()}
-    pout = _solve(decoders["bf16"], pin, 10, "euler", kw, pin["z"])
+    pout = _solve(decoders["f16"], pin, 10, "euler", kw, pin["z"])
     assert torch.equal(pout, out[perm])                               # utterances are independent units
 
 
@@ -196,7 +197,7 @@ def test_c2_batch_rows_match_oracle(sd, cfg_params, c2):
     ref = oracle.cfm_forward(sd, sub["mu"], sub["mask"], 10, sub["z"], sub["c"], "euler", _cfg(cfg_params, 3.0, False))
     got = out[rows]
     assert _rel(got, ref) <= MEL_TOL
-    assert _disp(got, ref, sub["z"]) <= DISP_TOL["bf16"]
+    assert _disp(got, ref, sub["z"]) <= DISP_TOL["f16"]
 
 
 def test_c2_all_ones_mask_rows_match_oracle(decoders, sd, cfg_params):
@@ -269,7 +270,7 @@ def test_strong_gates_ada_std_015(dt):
     out = dec.estimator(t.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
     r = _rel(out, ref)
     print(f"ada_std=0.15 one-NFE rel err [{dt}]: {r:.3e}")
-    assert r <= NFE_TOL[dt]
+    assert r <= {"bf16": 1e-2, "f16": 1e-3}[dt]
 
 
 def test_c2_items_match_oracle_at_full_length(decoders, sd, cfg_params):

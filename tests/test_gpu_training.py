@@ -24,7 +24,8 @@ from oracle.inputs import make_inputs
 pytestmark = [pytest.mark.gpu, pytest.mark.grad]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = {"f16": 3e-3, "bf16": 2e-2}          # measured 5.3e-4 / 4.2e-3
-TOL_QK = {"f16": 6e-2, "bf16": 4e-1}       # measured 2.3e-2 / 1.9e-1 (conditioning of dq, dk at random init, see above)
+TOL_QK = {"f16": 6e-2, "bf16": 4e-1}       # end-to-end only, measured 2.3e-2 / 1.9e-1 (conditioning of dq, dk at random init, see above);
+                                           # the gate for q / k is the matched-input chain of test_gradients_at_config5_size
 
 
 def _rel(a, b):
@@ -119,6 +120,206 @@ def test_attention_backward_at_matched_inputs(sd, dt):
                 assert r <= {"f16": 1e-3, "bf16": 8e-3}[dt], (i, nm, r)       # measured <= 4e-4 / 3.8e-3
     finally:
         eng.debug_capture(False)
+
+
+# ---------------------------------------------------------------- BASELINE config 5 shapes (train.py:78-81 at T = 1000)
+SIZE_B, SIZE_T, SIZE_LENS = 4, 1000, [1000, 873, 655, 512]
+
+
+@pytest.fixture(scope="module")
+def size_case(sd):
+    """One compute_loss step at config-5 frame counts (B=4 x T=1000, ragged) through the ORACLE's autograd (fp32 CPU,
+    ~3 s): loss, all 116 parameter gradients, d loss/d mu, d loss/d c."""
+    inp = make_inputs(SIZE_B, SIZE_T, seed=81, lengths=SIZE_LENS)
+    x1 = make_inputs(SIZE_B, SIZE_T, seed=82)["z"]
+    g0 = torch.Generator().manual_seed(19)
+    t_rand = torch.rand(SIZE_B, 1, 1, generator=g0)
+    z = torch.randn(SIZE_B, 128, SIZE_T, generator=g0)
+    with torch.enable_grad():
+        pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        mu = inp["mu"].clone().requires_grad_(True)
+        c = inp["c"].clone().requires_grad_(True)
+        loss, _ = oracle.compute_loss(pr, x1, inp["mask"], mu, c, t_rand, z)
+        loss.backward()
+    return dict(inp=inp, x1=x1, t_rand=t_rand, z=z, loss=float(loss.detach()), gmu=mu.grad.numpy(), gc=c.grad.numpy(),
+                grads={k: v.grad.numpy() for k, v in pr.items()})
+
+
+def _cos(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
+def _rope_T(d, T):
+    """Transpose of the partial rotary embedding (pairs (j, j+16), j < 16, theta_j = 10000^(-2j/32)) applied to a
+    gradient d[..., T, 64] (models/diffusion_transformer.py:180-198): dx1 = dy1 c + dy2 s, dx2 = dy2 c - dy1 s."""
+    j = np.arange(16)
+    ang = np.arange(T)[:, None].astype(np.float32) * (1.0 / np.power(np.float32(10000.0), (2 * j) / np.float32(32.0))).astype(np.float32)
+    c, s = np.cos(ang.astype(np.float32)).astype(np.float64), np.sin(ang.astype(np.float32)).astype(np.float64)
+    out = d.copy()
+    out[..., 0:16] = d[..., 0:16] * c + d[..., 16:32] * s
+    out[..., 16:32] = d[..., 16:32] * c - d[..., 0:16] * s
+    return out
+
+
+@pytest.mark.parametrize("dt,tiles", [("f16", "policy"), ("f16", "big"), ("bf16", "big")])
+def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
+    """The production backward configurations against the oracle's autograd on the same inputs: T = 1000 ragged rows
+    (16 key tiles in the attention backward, weight gradients split over up to 64 row chunks, dgrad through the
+    k = 3 kernels), once with the tile policy as shipped for this batch size and once with ST_BIG_MIN_BLOCKS=1, which
+    makes every conv -- forward, dgrad AND wgrad -- take the 256 x 256 / phased tiles a B = 64 batch runs on.
+    Gates: every tensor 3e-3 (f16) / 2e-2 (bf16) of max |ref|, as at the small size -- except conv_q / conv_k, whose
+    end-to-end error is dominated by the conditioning of dq, dk at random init (module docstring): for those the
+    MATCHED-INPUT checks below are the gate (attention backward vs fp64 on the native q, k, v, d attn; RoPE^T + pack +
+    weight-gradient GEMM vs fp64 on the native dq, dk, h1) and the end-to-end number is gated loosely and printed."""
+    sc = size_case
+    if tiles == "big":
+        monkeypatch.setenv("ST_BIG_MIN_BLOCKS", "1")
+    dec = _decoder(sd, dt)
+    eng = dec.estimator.engine()
+    monkeypatch.delenv("ST_BIG_MIN_BLOCKS", raising=False)
+    inp = sc["inp"]
+    mu = inp["mu"].cuda().requires_grad_(True)
+    c = inp["c"].cuda().requires_grad_(True)
+    eng.debug_capture(True)
+    try:
+        loss, _ = dec.compute_loss(sc["x1"].cuda(), inp["mask"].cuda(), mu, c, t_rand=sc["t_rand"].cuda(), z=sc["z"].cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.detach()) - sc["loss"]) <= {"f16": 5e-4, "bf16": 3e-3}[dt] * sc["loss"]
+        params = dict(dec.estimator.named_parameters())
+        worst, cosq = {}, {}
+        for name, ref in sc["grads"].items():
+            g = params[name].grad
+            assert g is not None and torch.isfinite(g).all(), name
+            worst[name] = _rel(g.cpu().numpy(), ref)
+            if _is_qk(name):
+                cosq[name] = _cos(g.cpu().numpy(), ref)
+        wq = max(v for k, v in worst.items() if _is_qk(k))
+        wo = max(v for k, v in worst.items() if not _is_qk(k))
+        print(f"[{dt}/{tiles}] B={SIZE_B} T={SIZE_T}: worst non-q/k {wo:.2e}; q/k end-to-end {wq:.2e}, min cosine {min(cosq.values()):.6f}; "
+              f"d mu {_rel(mu.grad.cpu().numpy(), sc['gmu']):.2e}, d c {_rel(c.grad.cpu().numpy(), sc['gc']):.2e}")
+        bad = {k: v for k, v in worst.items() if v > (TOL_QK if _is_qk(k) else TOL)[dt]}
+        assert not bad, bad
+        assert min(cosq.values()) >= {"f16": 0.999, "bf16": 0.98}[dt], cosq
+        assert _rel(mu.grad.cpu().numpy(), sc["gmu"]) <= TOL[dt]
+        assert _rel(c.grad.cpu().numpy(), sc["gc"]) <= TOL[dt]
+        # ---- matched inputs at size: attention backward kernels, then RoPE^T + pack + wgrad of conv_q / conv_k / conv_v
+        B, T, H = SIZE_B, SIZE_T, 4
+        Tp = (T + 63) // 64 * 64
+        tt = np.arange(Tp)
+        pos = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)
+        scale = float(eng.debug_fetch("g.scale")[0])
+        m = inp["mask"][:, 0].double().numpy()
+        bias = (1 - m)[:, None, None, :] * (-1e30)
+        for i in (5, 0):
+            q = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64).astype(np.float64)
+            k = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64).astype(np.float64)
+            v = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)
+            dO = (eng.debug_fetch(f"g.dattn_{i}").reshape(B, T, H, 64).transpose(0, 2, 1, 3) / scale).astype(np.float64)
+            S2 = q @ k.transpose(0, 1, 3, 2) + bias
+            S2 -= S2.max(-1, keepdims=True)
+            P = np.exp2(S2); P /= P.sum(-1, keepdims=True)
+            dP = dO @ v.transpose(0, 1, 3, 2)
+            D = (P * dP).sum(-1, keepdims=True)
+            dS = P * (dP - D)
+            want = {"dq": dS @ k, "dk": dS.transpose(0, 1, 3, 2) @ q, "dv": P.transpose(0, 1, 3, 2) @ dO}
+            got = {}
+            for nm, ref in want.items():
+                got[nm] = eng.debug_fetch(f"g.{nm}_{i}").reshape(B, H, T, 64).astype(np.float64) / scale
+                r = _rel(got[nm], ref)
+                print(f"[{dt}/{tiles}] block {i} {nm} at matched inputs: {r:.2e}")
+                assert r <= {"f16": 1e-3, "bf16": 8e-3}[dt], (i, nm, r)
+            # d q_proj = R^T(dq / 8), d k_proj = R^T(dk ln 2), d v_proj = dv; dW = sum_{n,t} d proj[n,t,co] h1[n,t,ci]
+            h1 = eng.debug_fetch(f"t{i}.h1").reshape(B * T, 256).astype(np.float64)
+            for nm, dproj in (("q", _rope_T(got["dq"] / 8.0, T)), ("k", _rope_T(got["dk"] * math.log(2.0), T)), ("v", got["dv"])):
+                dp = dproj.transpose(0, 2, 1, 3).reshape(B * T, 256)
+                name = f"blocks.{i}.block.attn.conv_{nm}"
+                r = _rel(params[name + ".weight"].grad[:, :, 0].cpu().numpy(), dp.T @ h1)
+                rb = _rel(params[name + ".bias"].grad.cpu().numpy(), dp.sum(0))
+                print(f"[{dt}/{tiles}] block {i} conv_{nm} weight / bias gradient from the native d{nm}, h1 (fp64): {r:.2e} / {rb:.2e}")
+                assert max(r, rb) <= {"f16": 2e-3, "bf16": 1.2e-2}[dt], (name, r, rb)
+    finally:
+        eng.debug_capture(False)
+
+
+def test_backward_of_replaced_activations_fails_loudly(sd):
+    """The engine keeps the activations of ONE grad-enabled forward: a backward whose activations were
+    replaced by a later forward must raise (autograd Function) / return ST_ERR_STATE (C ABI) before any memory is
+    touched -- not silently use the other forward's activations, whose (B, T) may differ."""
+    from stabletts_amd._lib import NativeError, ST_ERR_STATE
+    dec = _decoder(sd, "f16")
+    a = make_inputs(2, 40, seed=61, lengths=[40, 31])
+    b = make_inputs(1, 72, seed=62)
+    la, _ = dec.compute_loss(make_inputs(2, 40, seed=63)["z"].cuda(), a["mask"].cuda(), a["mu"].cuda(), a["c"].cuda())
+    lb, _ = dec.compute_loss(make_inputs(1, 72, seed=64)["z"].cuda(), b["mask"].cuda(), b["mu"].cuda(), b["c"].cuda())
+    with pytest.raises(RuntimeError, match="activations of ONE"):
+        la.backward()                                # la's activations were replaced by lb's forward
+    assert all(p.grad is None for p in dec.estimator.parameters())
+    lb2, _ = dec.compute_loss(make_inputs(1, 72, seed=64)["z"].cuda(), b["mask"].cuda(), b["mu"].cuda(), b["c"].cuda())
+    lb2.backward()                                   # the newest forward's backward is fine
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.estimator.parameters())
+    # C ABI: wrong serial / wrong shape / after a parameter update
+    eng = dec.estimator.engine()
+    g = torch.zeros(1, 128, 72, device="cuda")
+    serial = eng.train_serial()
+    assert serial > 0
+    for ser, gg in ((serial + 1, g), (serial - 1, g), (serial, torch.zeros(1, 128, 71, device="cuda")), (serial, torch.zeros(2, 128, 72, device="cuda"))):
+        with pytest.raises(NativeError) as ei:
+            eng.train_backward(ser, gg, None, None, None, torch.cuda.current_stream().cuda_stream)
+        assert ei.value.code == ST_ERR_STATE
+    eng.train_backward(serial, g, None, None, None, torch.cuda.current_stream().cuda_stream)     # the matching one is accepted
+    with torch.no_grad():
+        dec.estimator.final_proj.bias.add_(0.5)      # version bump -> re-pack -> the held activations are invalidated
+    lc, _ = dec.compute_loss(make_inputs(2, 40, seed=63)["z"].cuda(), a["mask"].cuda(), a["mu"].cuda(), a["c"].cuda())
+    with torch.no_grad():
+        dec.estimator.final_proj.bias.add_(0.5)
+    dec.estimator.engine()                           # ... picked up by any later use of the engine
+    with pytest.raises(RuntimeError, match="activations of ONE"):
+        lc.backward()
+
+
+def test_optimizer_steps_repack_in_place_without_reallocation(sd):
+    """Every optimizer step bumps the parameters' version counters (train.py:82).  The engine reads the fp32 tensors
+    where torch keeps them (st_bind_param) and re-packs its 16-bit copies on the stream (st_repack): device bytes and
+    the time-step count stay put, and the result equals a fresh decoder loaded with the updated weights bit for bit."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    dec = _decoder(sd, "f16", train=True)
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-3)
+    inp = make_inputs(2, 64, seed=71, lengths=[64, 50])
+    x1 = make_inputs(2, 64, seed=72)["z"].cuda()
+    args = (inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+    eng = dec.estimator.engine()
+    handle, nbytes = eng.handle.value, None
+    for step in range(3):
+        torch.manual_seed(step)
+        loss, _ = dec.compute_loss(x1, *args)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        assert dec.estimator.engine().handle.value == handle
+        if nbytes is None:
+            nbytes = eng.device_bytes()
+        assert eng.device_bytes() == nbytes          # nothing is freed / re-allocated by a parameter update
+    assert dec.estimator._staging is None            # fp32 parameters are read in place: no copies
+    dec.eval()
+    t = torch.tensor(0.35).cuda()
+    with torch.no_grad():
+        got = dec.estimator(t, inp["z"].cuda(), *args)
+        fresh = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+        fresh.estimator.load_state_dict({k: v.detach().cpu() for k, v in dec.estimator.state_dict().items()})
+        want = fresh.cuda().eval().estimator(t, inp["z"].cuda(), *args)
+    assert torch.equal(got, want)
+    # a module whose parameters are not fp32 (.half()) is served from fp32 staging copies
+    with torch.no_grad():
+        h = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+        h.estimator.load_state_dict(sd)
+        h = h.cuda().half().eval()
+        outh = h.estimator(t, inp["z"].cuda(), *args)
+        assert h.estimator._staging is not None and outh.dtype == torch.float32
+        r = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+        r.estimator.load_state_dict({k: v.half().float() for k, v in sd.items()})
+        assert torch.equal(outh, r.cuda().eval().estimator(t, inp["z"].cuda(), *args))
 
 
 # ---- python port of the counter-based dropout hash (stabletts_amd/csrc/common.h: drop_hash, train_kernels.hip: make_drop)

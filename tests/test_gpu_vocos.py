@@ -92,3 +92,26 @@ def test_vocos_rejects_wrong_inputs(voc):
         voc(torch.zeros(1, 128, 8))                       # CPU tensor
     with pytest.raises(ValueError):
         voc(torch.zeros(1, 80, 8, device="cuda"))         # wrong n_mels
+
+
+def test_vocoder_is_inference_only_and_says_so():
+    """the native vocoder has no backward.  Its parameters do not require grad (plain ``voc(mel)`` works in
+    any grad mode and returns a graph-less tensor); asking for gradients -- a mel that requires grad, or parameters
+    switched to requires_grad -- raises instead of silently training nothing."""
+    import types
+    from stabletts_amd.vocos import Vocos
+    c = vo.VocosConfig
+    voc = Vocos(types.SimpleNamespace(input_channels=c.input_channels, dim=c.dim, intermediate_dim=c.intermediate_dim, num_layers=c.num_layers),
+                types.SimpleNamespace(n_fft=c.n_fft, hop_length=c.hop_length))
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in vo.make_vocos_state_dict(77).items()})
+    voc = voc.cuda()
+    assert not any(p.requires_grad for p in voc.parameters())
+    mel = torch.randn(1, c.input_channels, 20, device="cuda")
+    with torch.enable_grad():
+        out = voc(mel)
+        assert not out.requires_grad and torch.isfinite(out).all()
+        with pytest.raises(NotImplementedError, match="inference-only"):
+            voc(mel.clone().requires_grad_(True))
+        voc.backbone.embed.weight.requires_grad_(True)
+        with pytest.raises(NotImplementedError, match="inference-only"):
+            voc(mel)
