@@ -44,7 +44,7 @@ static float* dev_fill(size_t n, uint32_t seed, float scale) {
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 2, T = argc > 2 ? atoi(argv[2]) : 96, n_steps = argc > 3 ? atoi(argv[3]) : 4;
     const int M = 128, G = 256;
-    st_config cfg = {M, 256, 1024, 4, 6, 3, G, ST_OPERAND_BF16};
+    st_config cfg = {M, 256, 1024, 4, 6, 3, G, ST_OPERAND_F16};   /* the shipping default: the parity-gated operand type */
     st_engine* eng = NULL;
     if (st_abi_version() != ST_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
     if (st_create(&cfg, 0, &eng) != ST_OK) { fprintf(stderr, "st_create: %s\n", st_last_error(NULL)); return 1; }

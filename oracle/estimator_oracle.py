@@ -58,7 +58,7 @@ def rope(x, d=32, base=10000):
     return torch.cat((x_rope, x_pass), dim=-1)
 
 
-def attention(q, k, v, mask, n_heads=4, drop=None):
+def attention(q, k, v, mask, n_heads=4, drop=None, subst=None):
     """models/diffusion_transformer.py:67-79 + mask construction :107-108.
 
     q,k,v: (B, C, T) conv outputs; mask (B,1,T) float 0/1. Returns (B, C, T) and the
@@ -73,6 +73,14 @@ def attention(q, k, v, mask, n_heads=4, drop=None):
     vh = v.view(B, n_heads, dh, T).transpose(2, 3)
     qh = rope(qh, int(dh * 0.5))
     kh = rope(kh, int(dh * 0.5))
+    if subst is not None:
+        # test hook (tests/test_gpu_training.py): evaluate the attention AT the given post-RoPE values (the native
+        # forward's own 16-bit q, k, v) while gradients keep flowing through this graph -- a straight-through
+        # substitution.  d q, d k are ill-conditioned in v at random init; matching the forward operands removes
+        # that amplification from an end-to-end gradient comparison.
+        qh = qh + (subst["q"] - qh).detach()
+        kh = kh + (subst["k"] - kh).detach()
+        vh = vh + (subst["v"] - vh).detach()
     am = mask.unsqueeze(1) * mask.unsqueeze(-1)                    # (B,1,T,T)
     am = torch.zeros_like(am).masked_fill(am == 0, -torch.finfo(q.dtype).max)
     s = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + am
@@ -84,12 +92,12 @@ def attention(q, k, v, mask, n_heads=4, drop=None):
     return out, (qh, kh, vh)
 
 
-def mha(sd, prefix, x, mask, n_heads=4, taps=None, drop=None):
+def mha(sd, prefix, x, mask, n_heads=4, taps=None, drop=None, subst=None):
     """models/diffusion_transformer.py:58-65 (MultiHeadAttention.forward)."""
     q = F.conv1d(x, sd[prefix + "conv_q.weight"], sd[prefix + "conv_q.bias"])
     k = F.conv1d(x, sd[prefix + "conv_k.weight"], sd[prefix + "conv_k.bias"])
     v = F.conv1d(x, sd[prefix + "conv_v.weight"], sd[prefix + "conv_v.bias"])
-    a, (qh, kh, vh) = attention(q, k, v, mask, n_heads, drop)
+    a, (qh, kh, vh) = attention(q, k, v, mask, n_heads, drop, subst)
     if taps is not None:
         taps["q"], taps["k"], taps["v"], taps["attn"] = qh, kh, vh, a
     return F.conv1d(a, sd[prefix + "conv_o.weight"], sd[prefix + "conv_o.bias"])
@@ -115,7 +123,7 @@ def layer_norm_c(x):
     return F.layer_norm(x.transpose(1, 2), (x.shape[1],), eps=1e-5).transpose(1, 2)
 
 
-def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None, drop=None):
+def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None, drop=None, qkv_subst=None):
     """DitWrapper.forward (models/estimator.py:15-18) + DiTConVBlock.forward
     (models/diffusion_transformer.py:98-117); arithmetic order of SURVEY.md 3.3."""
     p = f"blocks.{i}."
@@ -133,7 +141,8 @@ def dit_block(sd, i, x, c, tau, mask, n_heads=4, k=3, taps=None, drop=None):
     h = layer_norm_c(x) * (1 + sc_a) + sh_a
     if taps is not None:
         taps["h1"] = h
-    x = x + g_a * mha(sd, p + "block.attn.", h, mask, n_heads, taps, None if drop is None else drop["attn"][i]) * mask
+    x = x + g_a * mha(sd, p + "block.attn.", h, mask, n_heads, taps, None if drop is None else drop["attn"][i],
+                      None if qkv_subst is None else qkv_subst[i]) * mask
     if taps is not None:
         taps["x2"] = x
     h = layer_norm_c(x) * (1 + sc_m) + sh_m
@@ -190,7 +199,7 @@ def text_encoder_forward(sd, tokens, c, lengths, n_heads=4, k=3, taps=None):
 
 
 # ----------------------------------------------------------------------------- estimator
-def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None, drop=None):
+def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None, drop=None, qkv_subst=None):
     """models/estimator.py:103-138 (Decoder.forward): one vector-field evaluation.
 
     t: () or (B,), x/mu: (B,M,T), mask: (B,1,T), c: (B,gin).  taps: optional dict that
@@ -217,7 +226,7 @@ def decoder_forward(sd, t, x, mask, mu, c, n_heads=4, k=3, taps=None, drop=None)
             if taps is not None:
                 taps[f"lsc{i - n_lsc}"] = x
         bt = {} if taps is not None else None
-        x = dit_block(sd, i, x, c, tau, mask, n_heads, k, bt, drop)
+        x = dit_block(sd, i, x, c, tau, mask, n_heads, k, bt, drop, qkv_subst)
         if taps is not None:
             for kk, vv in bt.items():
                 taps[f"b{i}.{kk}"] = vv

@@ -20,7 +20,10 @@
 // a dot product -- so P never leaves registers and never crosses lanes.  The matching key order of the
 // V^T operand (bits 2<->3 of the key index swapped) is baked into the global vT layout by the QKV
 // epilogue.  Softmax max/sum are lane-local plus one shuffle with lane^32 (the other half of the same
-// query's keys); the running-max rescale of O is skipped whenever no lane's max moved.
+// query's keys).  The softmax reference value of a query enters the scores THROUGH THE MFMA (a fifth k-step:
+// K augmented by a column of ones, Q by -m_ref), so p = exp2 of the accumulator with no per-element subtraction, and
+// the reference is raised lazily (O, l rescaled) only when a tile's maximum exceeds it by 2^8: per key tile a wave
+// issues 9 + 8 MFMAs next to 32 v_exp, 32 v_add (row sum), 16 v_max3 and 16 v_cvt_pk.
 // Tiles below the valid prefix skip the bias add entirely, tiles past the last valid key are never
 // visited.  Padded QUERY rows produce finite garbage that the out-projection epilogue multiplies by
 // 0, exactly as the reference's uniform-softmax rows are zeroed by "* x_mask" (:111).
@@ -36,8 +39,8 @@ namespace st {
 // TRAIN: also writes the log2-sum-exp of every query row (for the backward's recomputation of P) and applies
 // dropout to the probabilities that enter P.V (not to the normaliser), as SDPA's dropout_p does.
 template <class P, bool TRAIN>
-__global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) void attention_kernel(const AttnArgs a) {
-    constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW;      // waves and queries per block
+__global__ __launch_bounds__(64 * ST_ATTN_WAVES, (ST_ATTN_WAVES >= 16 || TRAIN) ? 2 : 4) void attention_kernel(const AttnArgs a) {
+    constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW, QTILE = QB;      // waves and queries per block
     using vec8 = typename P::vec8;
     constexpr int TILE_BYTES = 64 * 128;
     constexpr int SMEM = 4 * TILE_BYTES > NW * 32 * 144 ? 4 * TILE_BYTES : NW * 32 * 144;
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
     const int nh = lin / qtiles;
     const int n = nh / H, h = nh % H;
     const int mb = n % a.mask_mod;
+    if (a.t_lim && qt * QTILE >= a.t_lim[mb]) return;        // ragged batch: every query of this tile is past the item's last needed frame
     const int kvend = a.kv_end[mb];
     const int nfull = a.n_full[mb];
     const float* kbias = a.kbias + (size_t)mb * Tp;
@@ -67,7 +71,6 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
     const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
     const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
     const unsigned char* vbase = (const unsigned char*)a.vt + ((size_t)nh * 64) * Tp * 2;
-    const unsigned char* zeros = (const unsigned char*)a.zeros;
 
     // Q fragments (B operand): lane (query, hi) holds head dims ks*16 + hi*8 .. +8
     vec8 qf[4];
@@ -80,20 +83,25 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
 
     const int ntiles = (kvend + 63) >> 6;
     // LDS-DMA: the 8 + 8 pieces (8 rows x 128 B each) of the K tile and of the V^T tile are split over the waves
+    // (SGPR base + 32-bit per-lane offset: the per-lane parts are loop invariant single registers; out-of-range K rows of
+    //  the last tile are clamped to key T-1 -- a valid row whose score the key bias sends to -1e30 anyway)
+    auto sgpr_ptr = [](const unsigned char* p) {
+        const uintptr_t v = (uintptr_t)p;
+        return (const unsigned char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+    };
     auto issueKV = [&](int kt, int buf) {
         auto k_piece = [&](int piece) {
             const int row = piece * 8 + (lane >> 3);
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
-            const int key = kt * 64 + row;
-            const unsigned char* ksrc = key < T ? kbase + (size_t)key * 128 + seg * 16 : zeros;
-            glds16b(ksrc, Ks + buf * TILE_BYTES + piece * 1024);
+            const int key = min(kt * 64 + row, T - 1);
+            glds16s(sgpr_ptr(kbase), (unsigned)(key * 128 + seg * 16), Ks + buf * TILE_BYTES + piece * 1024);
         };
         auto v_piece = [&](int piece) {
             // V^T row = head dim `row`; 8 consecutive (permuted) keys kt*64 + seg*8 .. +8, always inside Tp
             const int row = piece * 8 + (lane >> 3);
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
-            const unsigned char* vsrc = vbase + ((size_t)row * Tp + kt * 64 + seg * 8) * 2;
-            glds16b(vsrc, Vs + buf * TILE_BYTES + piece * 1024);
+            glds16s(sgpr_ptr(vbase + (size_t)kt * 128), (unsigned)((row * Tp + seg * 8) * 2), Vs + buf * TILE_BYTES + piece * 1024);
         };
         if constexpr (NW <= 8) {
 #pragma unroll
@@ -116,7 +124,20 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    // Online softmax against a per-query REFERENCE m_ref (a 16-bit representable value, raised lazily) that enters the
+    // scores through the MFMA instead of the VALU: the K tile is augmented by one k-step whose slot 0 is 1 for every key
+    // and whose slot 1 is 1 for masked keys, Q by (-m_ref, -BIG) -- so the QK^T accumulator comes out as
+    // s' = s - m_ref + key bias and p = exp2(s') needs no subtraction and no bias add (a per-row constant cancels
+    // exactly between P and l, so the 16-bit rounding of m_ref is harmless; the product 1 x (-m_ref) is exact).
+    // m_ref is raised (O, l rescaled, s' corrected) only when a tile's maximum exceeds it by more than kLazy: p <= 2^kLazy
+    // stays inside f16's range, and since m_ref >= the first tile's exact maximum, smaller terms only underflow when
+    // they are negligible.  The first tile always takes the correction path (m_ref starts at 0).
+    constexpr float kLazy = 8.0f, kFloor = -20000.0f;
+    float m_ref = 0.f, l_run = 0.f;
+    vec8 qaug, kaug;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qaug[i] = to16<P>(0.f); kaug[i] = to16<P>(0.f); }
+    if (hi == 0) kaug[0] = to16<P>(1.0f);
 
     if (ntiles > 0) issueKV(0, 0);
     ST_DMA_WAIT(0);
@@ -127,66 +148,76 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
         const int buf = kt & 1;
         if (kt + 1 < ntiles_run) issueKV(kt + 1, buf ^ 1);
 
-        // ---- S^T = K . Q^T  (log2 units)
         f32x16_t s[2];
+        const bool partial = (kt + 1) * 64 > nfull;       // tiles inside the valid prefix have no masked key
+        // ---- S'^T = [K | 1] . [Q | -m_ref]^T (+ key bias)  (log2 units)
+        auto scores = [&]() {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-        }
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+                s[kb] = P::mfma(kaug, qaug, s[kb]);
+                const unsigned char* kp = Ks + buf * TILE_BYTES + row_off[kb];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const unsigned char* kp = Ks + buf * TILE_BYTES + row_off[kb];
+                for (int ks = 0; ks < 4; ++ks)
+                    s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(kp + (((ks * 2 + hi) ^ swz[kb]) << 4))), qf[ks], s[kb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (partial) {        // key bias (-1e30 on masked / out-of-range keys): only tiles that reach past the valid prefix
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(kp + (((ks * 2 + hi) ^ swz[kb]) << 4))), qf[ks], s[kb]);
-        }
-        // ---- key bias (only tiles that are not entirely inside the valid prefix)
-        if ((kt + 1) * 64 > nfull) {
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 bz = *(const float4*)(kbias + kt * 64 + kb * 32 + 8 * g4 + 4 * hi);
-                    s[kb][4 * g4 + 0] += bz.x; s[kb][4 * g4 + 1] += bz.y;
-                    s[kb][4 * g4 + 2] += bz.z; s[kb][4 * g4 + 3] += bz.w;
-                }
-        }
-        // ---- online softmax, one query per lane (pair lane^32 shares the query)
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 bz = *(const float4*)(kbias + kt * 64 + kb * 32 + 8 * g4 + 4 * hi);
+                        s[kb][4 * g4 + 0] += bz.x; s[kb][4 * g4 + 1] += bz.y;
+                        s[kb][4 * g4 + 2] += bz.z; s[kb][4 * g4 + 3] += bz.w;
+                    }
+            }
+        };
+        scores();
+        // ---- tile maximum relative to the reference, one query per lane (pair lane^32 shares the query)
         float mx = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = xor32_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        if (__any(m_new != m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        if (kt == 0 || __any(mx > kLazy)) {
+            // Rare (and the first tile): raise the reference of the rows that need it, rescale their O and l, and
+            // RECOMPUTE the tile's scores with the new reference (subtracting the step from s' instead would keep the
+            // fp32 rounding of s - m_ref_old).  A fully masked tile (mx = -1e30) leaves the reference at kFloor: its
+            // probabilities are exactly 0 and the first tile with a valid key corrects from there.
+            const bool need = kt == 0 || mx > kLazy;
+            const float m_new = need ? (float)to16<P>(fmaxf(m_ref + mx, kFloor)) : m_ref;
+            const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
             l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            m_run = m_new;
+            m_ref = m_new;
+            if (hi == 0) qaug[0] = to16<P>(-m_ref);
+            scores();
         }
 
         vec8 pf[4];
-        float psum = 0.f;
+        float psum[2] = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
-                psum += p;
+                float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                psum[r & 1] = add_f32_scalar(psum[r & 1], p);
                 if constexpr (TRAIN) {
                     const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     p *= drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key);
                 }
                 pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p);
             }
-        l_run += psum;
+        l_run += psum[0] + psum[1];
 
         // ---- O^T += V^T . P^T
+        __builtin_amdgcn_sched_barrier(0);       // (keeps the V^T fragment reads below the softmax: 32 registers)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             const unsigned char* vp = Vs + buf * TILE_BYTES + row_off[d];
@@ -197,6 +228,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
         ST_DMA_WAIT(0);       // tile kt+1 (asm-issued LDS-DMA, flying under this tile's MFMAs and exps) has landed
         __syncthreads();      // fence the buffer swap
     }
+    const float m_run = m_ref;
 
     const float l_tot = xor32_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -232,7 +264,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 1 : 2) vo
 constexpr int kAttnSmallLds = 8 * 2 * 64 * 128;
 template <class P>
 __global__ __launch_bounds__(512, 1) void attention_small_kernel(const AttnArgs a) {
-    constexpr int NW = 8, TILE_BYTES = 64 * 128, WAVE_LDS = 2 * TILE_BYTES, OP = 33;
+    constexpr int NW = 8, TILE_BYTES = 64 * 128, WAVE_LDS = 2 * TILE_BYTES, OP = 33, QTILE = 32;
     using vec8 = typename P::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -246,6 +278,7 @@ __global__ __launch_bounds__(512, 1) void attention_small_kernel(const AttnArgs 
     const int nh = lin / qgroups;
     const int n = nh / H, h = nh % H;
     const int mb = n % a.mask_mod;
+    if (a.t_lim && qt * QTILE >= a.t_lim[mb]) return;        // ragged batch: every query of this tile is past the item's last needed frame
     const int kvend = a.kv_end[mb];
     const int nfull = a.n_full[mb];
     const float* kbias = a.kbias + (size_t)mb * Tp;

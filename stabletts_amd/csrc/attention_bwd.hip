@@ -555,7 +555,7 @@ hipError_t launch_attn_from_T(int dtype, const void* inT, int n_items, int H, in
 template <class P>
 __global__ __launch_bounds__(256) void qkv_grad_pack_kernel(const float* dq, const float* dk, const float* dv,
                                                             const float* rope_cos, const float* rope_sin, int H, int T,
-                                                            int64_t total, typename P::elem* out) {
+                                                            int64_t total, const float* qs, typename P::elem* out, typename P::elem* outw) {
     // one thread per (item, t, h, j < 16): handles dims j, j+16 (rotated pair) and j+32, j+48 (pass-through)
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -566,28 +566,36 @@ __global__ __launch_bounds__(256) void qkv_grad_pack_kernel(const float* dq, con
     const float c = rope_cos[(size_t)t * 16 + j], sn = rope_sin[(size_t)t * 16 + j];
     const size_t src = (((size_t)n * H + h) * T + t) * 64;
     const int C = H * 64;
+    const float fc = qs[0], fq = qs[8], fk = qs[9], fv = qs[10];      // powers of two: the products below are exact
     typename P::elem* o = out + (size_t)row * 3 * C + h * 64;
+    typename P::elem* w = outw + (size_t)row * 3 * C + h * 64;
     {   // y1 = x1 c - x2 s, y2 = x2 c + x1 s  =>  dx1 = dy1 c + dy2 s, dx2 = dy2 c - dy1 s
         const float a1 = dq[src + j] * 0.125f, a2 = dq[src + j + 16] * 0.125f;
-        o[j] = to16<P>(a1 * c + a2 * sn); o[j + 16] = to16<P>(a2 * c - a1 * sn);
-        o[j + 32] = to16<P>(dq[src + j + 32] * 0.125f); o[j + 48] = to16<P>(dq[src + j + 48] * 0.125f);
+        const float r0 = a1 * c + a2 * sn, r1 = a2 * c - a1 * sn, r2 = dq[src + j + 32] * 0.125f, r3 = dq[src + j + 48] * 0.125f;
+        o[j] = to16<P>(r0 * fc); o[j + 16] = to16<P>(r1 * fc); o[j + 32] = to16<P>(r2 * fc); o[j + 48] = to16<P>(r3 * fc);
+        w[j] = to16<P>(r0 * fq); w[j + 16] = to16<P>(r1 * fq); w[j + 32] = to16<P>(r2 * fq); w[j + 48] = to16<P>(r3 * fq);
     }
     {
         const float ln2 = 0.6931471805599453f;
         const float a1 = dk[src + j] * ln2, a2 = dk[src + j + 16] * ln2;
-        o[C + j] = to16<P>(a1 * c + a2 * sn); o[C + j + 16] = to16<P>(a2 * c - a1 * sn);
-        o[C + j + 32] = to16<P>(dk[src + j + 32] * ln2); o[C + j + 48] = to16<P>(dk[src + j + 48] * ln2);
+        const float r0 = a1 * c + a2 * sn, r1 = a2 * c - a1 * sn, r2 = dk[src + j + 32] * ln2, r3 = dk[src + j + 48] * ln2;
+        o[C + j] = to16<P>(r0 * fc); o[C + j + 16] = to16<P>(r1 * fc); o[C + j + 32] = to16<P>(r2 * fc); o[C + j + 48] = to16<P>(r3 * fc);
+        w[C + j] = to16<P>(r0 * fk); w[C + j + 16] = to16<P>(r1 * fk); w[C + j + 32] = to16<P>(r2 * fk); w[C + j + 48] = to16<P>(r3 * fk);
     }
-    o[2 * C + j] = to16<P>(dv[src + j]); o[2 * C + j + 16] = to16<P>(dv[src + j + 16]);
-    o[2 * C + j + 32] = to16<P>(dv[src + j + 32]); o[2 * C + j + 48] = to16<P>(dv[src + j + 48]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float v = dv[src + j + 16 * q];
+        o[2 * C + j + 16 * q] = to16<P>(v * fc); w[2 * C + j + 16 * q] = to16<P>(v * fv);
+    }
 }
 
 hipError_t launch_qkv_grad_pack(int dtype, const float* dq, const float* dk, const float* dv, const float* rope_cos,
-                                const float* rope_sin, int n_items, int H, int T, void* dqkv16, hipStream_t s) {
+                                const float* rope_sin, int n_items, int H, int T, const float* qs, void* d16, void* w16,
+                                hipStream_t s) {
     const int64_t total = (int64_t)n_items * T * H * 16;
     const int grid = (int)((total + 255) / 256);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((qkv_grad_pack_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, dq, dk, dv, rope_cos, rope_sin, H, T, total, (__bf16*)dqkv16);
-    else                  hipLaunchKernelGGL((qkv_grad_pack_kernel<OpF16>), dim3(grid), dim3(256), 0, s, dq, dk, dv, rope_cos, rope_sin, H, T, total, (_Float16*)dqkv16);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((qkv_grad_pack_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, dq, dk, dv, rope_cos, rope_sin, H, T, total, qs, (__bf16*)d16, (__bf16*)w16);
+    else                  hipLaunchKernelGGL((qkv_grad_pack_kernel<OpF16>), dim3(grid), dim3(256), 0, s, dq, dk, dv, rope_cos, rope_sin, H, T, total, qs, (_Float16*)d16, (_Float16*)w16);
     return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 struct OpBF16 {
     using elem = __bf16;
     using vec8 = bf16x8_t;
+    static constexpr float kMaskedScore = -1e30f;     // 16-bit representable "minus infinity" of a masked attention score
     static __device__ __forceinline__ f32x16_t mfma(vec8 a, vec8 b, f32x16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -24,6 +25,7 @@ struct OpBF16 {
 struct OpF16 {
     using elem = _Float16;
     using vec8 = f16x8_t;
+    static constexpr float kMaskedScore = -60000.0f;  // f16 saturates at 65504; exp2(-60000 + anything sane) == 0
     static __device__ __forceinline__ f32x16_t mfma(vec8 a, vec8 b, f32x16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -67,6 +69,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
     const float er = copysignf(fmaf(-poly, e, 1.0f), z);
     return 0.5f * x * (1.0f + er);
+}
+
+// fp32 add that hipcc's SLP vectoriser cannot fuse into v_pk_add_f32: beside MFMAs a packed fp32 op costs more than the
+// two scalar ones it replaces (MI355X_MICROARCH.md, per-instruction constants; measured here: attention +28 %)
+__device__ __forceinline__ float add_f32_scalar(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 template <int CTRL>

@@ -425,6 +425,7 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
     const int cbase = tc * BC, t0 = tf * BF;
+    if (g.t_lim && t0 >= g.t_lim[n % g.t_lim_mod]) return;      // ragged batch: this tile lies past the item's last needed frame
     const int cin = g.c0 + g.c1 + g.c2;
     const int nch_all = cin >> 6;
     const int cb = kz * nch_all / ks, nch = (kz + 1) * nch_all / ks;      // this block's chunks [cb, nch)
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(64 * WC * WF, 2) void conv_gemm3_kernel(const ConvG
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
     const int cbase = tc * BC, t0 = tf * BFV;
+    if (g.t_lim && t0 >= g.t_lim[n % g.t_lim_mod]) return;      // ragged batch: this tile lies past the item's last needed frame
     const int cin = g.c0 + g.c1;
     const int nch = cin >> 6;
     const int nst = nch * 3;

@@ -73,6 +73,7 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
     const int tf = rest % g.tiles_f;
     const int n = rest / g.tiles_f;
     const int cbase = tc * BC, t0 = tf * BFV;
+    if (g.t_lim && t0 >= g.t_lim[n % g.t_lim_mod]) return;      // ragged batch: this tile lies past the item's last needed frame
 
     const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
     const unsigned char* a1 = TWO_SRC ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;

@@ -111,6 +111,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         ks = (int)std::min<int64_t>(ks, (int64_t)e->kpart_bytes / plane);
         if (ks >= 2 && nch * taps >= e->splitk_min_stages) {
             ConvGemmArgs pa = a;
+            pa.t_lim = nullptr;
             pa.bias = nullptr; pa.flags = 0; pa.mask = nullptr; pa.add32 = nullptr; pa.out16 = nullptr; pa.out16_lo = nullptr;
             pa.ln_h16 = nullptr; pa.gate = nullptr; pa.out32 = e->kpart; pa.ksplit = ks;
             const int pcfg = e->small_tiles ? G2_T64 : G2_T128;
@@ -181,6 +182,7 @@ struct Plan {
     // fp32
     float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
     int *n_full, *kv_end;
+    int* t_lim;         // [B + 1] frames of every utterance that are computed (mask_prep: last valid + 1 + halo), [B] = the longest
     float* kbias;
     float* maskbuf;     // engine-owned copy of the caller's (B,1,T) mask: the solve body touches arena memory only
     struct Slot { void** dst; size_t off; };
@@ -232,6 +234,7 @@ size_t layout_plan(st_engine* e, int B, int T, bool cfg, int n_t, size_t off, Pl
     want((void**)&p->ada, (size_t)L * N * 6 * C * 4);
     want((void**)&p->n_full, (size_t)B * 4);
     want((void**)&p->kv_end, (size_t)B * 4);
+    want((void**)&p->t_lim, (size_t)(B + 1) * 4);
     want((void**)&p->kbias, (size_t)B * p->Tp * 4);
     want((void**)&p->maskbuf, (size_t)B * TT * 4);
     return off;
@@ -242,6 +245,9 @@ int ensure_ws(st_engine* e, size_t bytes) {
     e->drop_graphs();      // instantiated graphs hold arena pointers
     if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
     HIPCHK(e, hipMalloc((void**)&e->ws, bytes));
+    // Ragged batches leave frame tiles past an utterance's end uncomputed; whatever they hold is only ever read by
+    // don't-care positions, but it must be FINITE (0 x NaN would leak through a mask multiply): start from zeros.
+    HIPCHK(e, hipMemset(e->ws, 0, bytes));
     e->ws_cap = bytes;
     return ST_OK;
 }
@@ -293,6 +299,10 @@ ConvGemmArgs base_args(const st_engine* e, const Plan& p, const Conv& cv, int n_
     a.tiles_c = cv.cout / kGemmChannelsPerTile;
     a.a0_mod = n_items; a.a1_mod = n_items; a.mask_mod = p.B;
     a.zeros = e->zeros;
+    // ragged batches: tiles past an utterance's last needed frame are skipped (every frame is computed under debug
+    // capture, whose taps are compared over the whole padded tensor).  The shared uncond prenet item (index B of B + 1)
+    // is needed as far as the longest utterance: entry B of t_lim.
+    if (e->ragged_skip && !e->capture && e->kind == 0) { a.t_lim = p.t_lim; a.t_lim_mod = (n_items == p.B + 1) ? p.B + 1 : p.B; }
     return a;
 }
 
@@ -424,6 +434,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.kbias = p.kbias; a.mask_mod = p.B; a.zeros = e->zeros;
             a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
             a.small_max_blocks = e->conc == 1 ? e->attn_small_blocks : 0;
+            if (e->ragged_skip && !cap) a.t_lim = p.t_lim;
             ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
@@ -766,6 +777,7 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     e->kind = kind; e->n_vocab = n_vocab;
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
+    if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);     // 0: compute every padded frame tile (A/B runs)
     if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
         if (atoi(v) == 0) {                               // key-split attention): results independent of the batch composition
             e->splitk_target = 0; e->small_tiles = 0; e->attn_small_blocks = 0;
@@ -983,7 +995,8 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
     if ((rc = ensure_rope(e, T, s))) return rc;
     {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
+        HIPCHK(e, launch_mask_prep(mask, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, p.t_lim, s));
+        HIPCHK(e, hipMemsetAsync(p.v32, 0, (size_t)p.N * T * e->Mp * 4, s));      // frames of skipped tiles: v = 0 (estimator.py:138)
         HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, e->Mp, nullptr, p.mu16, nullptr, s));
         HIPCHK(e, launch_to_time_major(e->dt, x, B, e->M, T, e->Mp, nullptr, p.x16, p.x16lo, s));
         HIPCHK(e, hipMemcpyAsync(p.cvec, c, (size_t)B * e->G * 4, hipMemcpyDeviceToDevice, s));
@@ -1072,7 +1085,8 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         const Plan& p = pt.p;
         ProfScope ps(e, s, PC_PREP, 0);
         HIPCHK(e, launch_set_values(p.tvals, tv.data(), (int)tv.size(), s));   // by kernel argument: no copy, no sync
-        HIPCHK(e, launch_mask_prep(mask + (int64_t)pt.b0 * T, pt.nb, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
+        HIPCHK(e, launch_mask_prep(mask + (int64_t)pt.b0 * T, pt.nb, T, p.Tp, p.n_full, p.kv_end, p.kbias, p.t_lim, s));
+        HIPCHK(e, hipMemsetAsync(p.v32, 0, (size_t)p.N * T * e->Mp * 4, s));      // frames of skipped tiles: v = 0 (estimator.py:138)
         HIPCHK(e, launch_cvec_prep(mask + (int64_t)pt.b0 * T, nullptr, pt.nb, T, p.maskbuf, s));      // plain copy of the (B,1,T) mask
         pt.mask = p.maskbuf;
         HIPCHK(e, launch_to_time_major(e->dt, mu + pt.b0 * bct, pt.nb, e->M, T, e->Mp, nullptr, p.mu16, nullptr, s));
@@ -1222,7 +1236,7 @@ int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* 
         // embedding * sqrt(C) * mask -> residual stream; the (B,1,T) mask is written straight into the caller's tensor
         HIPCHK(e, launch_embed_tokens((const long long*)tokens, (const long long*)lengths, P(e, "emb.weight"), e->n_vocab,
                                       e->C, sqrtf((float)e->C), B, T, p.X, mask_out, s));
-        HIPCHK(e, launch_mask_prep(mask_out, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, s));
+        HIPCHK(e, launch_mask_prep(mask_out, B, T, p.Tp, p.n_full, p.kv_end, p.kbias, nullptr, s));
         HIPCHK(e, launch_cvec_prep(c, nullptr, B, e->G, p.cvec, s));
     }
     if ((rc = run_adaln(e, p, s))) return rc;
@@ -1344,7 +1358,7 @@ int st_profile_read(st_engine* e, int cls, int64_t* launches, double* total_ms, 
 
 int64_t st_device_bytes(const st_engine* e) {
     if (!e) return ST_ERR_INVALID;
-    int64_t n = e->weight_bytes + (int64_t)e->ws_cap;
+    int64_t n = e->weight_bytes + (int64_t)e->ws_cap + train_bytes(e);
     for (auto& kv : e->params) if (kv.second.dev && !kv.second.borrowed) n += kv.second.numel() * 4;
     return n;
 }

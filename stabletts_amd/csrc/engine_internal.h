@@ -92,6 +92,7 @@ struct st_engine {
     // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     int big_min_blocks = 192;
+    int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
     int phased = 1;                     // k = 3 convs on 256-wide tiles use the phased K loop (conv_gemm_phased.h); ST_PHASED=0: A/B runs
     int splitk_max = kSplitKMax, splitk_min_stages = 4;
     int small_tiles = 256;              // conv launches of <= this many 128x128 tiles use the 64-frame tile variants (0: never)
@@ -155,5 +156,6 @@ struct ProfScope {
 int train_prepare(st_engine* e, hipStream_t s);       // packs the transposed (dgrad) weights if the parameters changed
 void train_invalidate(st_engine* e);                  // called by st_finalize
 void train_destroy(st_engine* e);
+int64_t train_bytes(const st_engine* e);              // device bytes held by the training state
 
 }  // namespace sthost

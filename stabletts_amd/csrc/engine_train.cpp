@@ -53,7 +53,9 @@ struct TrainState {
     // backward scratch
     float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
           *gin, *gsc;
-    unsigned *gbits, *dsmax;
+    unsigned *gbits, *dsmax, *qbits;
+    float* qs;                                  // local scales of the attention-input gradients (launch_qkv_grad_scales)
+    void* g16w;                                 // d [q | k | v] with per-tensor scales: the dY operand of their weight gradients
     void *g16a, *g16b, *vnat, *vnat_lo, *qT, *kT, *dOT, *xt, *dyt;
     size_t partial_cap = 0, xt_cap = 0, dyt_cap = 0;
 };
@@ -133,6 +135,18 @@ int train_prepare(st_engine* e, hipStream_t s) {
     return ST_OK;
 }
 
+int64_t train_bytes(const st_engine* e) {      // transposed weights + gradient buffers + activation / scratch arena
+    if (!e->train) return 0;
+    int64_t n = (int64_t)e->train->ws_cap;
+    for (auto& kv : e->train->grads) if (kv.second) n += e->params.at(kv.first).numel() * 4;
+    auto add = [&](const Conv& c) { if (c.w) n += (int64_t)c.cout * c.taps * c.cin * 2; };
+    add(e->train->finT); add(e->train->inxT); add(e->train->incT);
+    for (auto& c : e->train->preT) add(c);
+    for (auto* v : {&e->train->ffn1T, &e->train->ffn2T, &e->train->oprojT, &e->train->qkvT, &e->train->lscTa, &e->train->lscTb})
+        for (auto& c : *v) add(c);
+    return n;
+}
+
 void train_destroy(st_engine* e) {
     if (!e->train) return;
     for (void* p : e->train->owned) hipFree(p);
@@ -175,7 +189,8 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->dX, R * C * 4);
     for (int j = 0; j < L / 2; ++j) want((void**)&ts->dskip[j], R * C * 4);
     want((void**)&ts->tmpC, R * C * 4); want((void**)&ts->tmpF, R * F * 4); want((void**)&ts->gin, R * Mp * 4);
-    want(&ts->g16a, R * F * 2); want(&ts->g16b, R * 3 * C * 2);
+    want(&ts->g16a, R * F * 2); want(&ts->g16b, R * 3 * C * 2); want(&ts->g16w, R * 3 * C * 2);
+    want((void**)&ts->qs, 64); want((void**)&ts->qbits, 16);
     want(&ts->vnat, R * C * 2); want(&ts->vnat_lo, R * C * 2); want((void**)&ts->dsmax, N * H * 4); want(&ts->qT, N * C * Tp * 2); want(&ts->kT, N * C * Tp * 2); want(&ts->dOT, N * C * Tp * 2);
     want((void**)&ts->Dbuf, N * H * TT * 4); want((void**)&ts->Fbuf, N * H * TT * 4); want((void**)&ts->abuf, N * H * TT * 4);
     want((void**)&ts->vmean, N * H * 64 * 4); want((void**)&ts->qmean, N * H * 64 * 4); want((void**)&ts->kmean, N * H * 64 * 4);
@@ -232,7 +247,7 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
     const int C = e->C, F = e->F, Mp = e->Mp, L = e->L, H = e->H, N = B, Tp = ts->Tp;
     const int64_t R = (int64_t)N * T;
     ts->p_drop = p_dropout; ts->seed = seed;
-    HIPCHK(e, launch_mask_prep(mask, B, T, Tp, ts->n_full, ts->kv_end, ts->kbias, s));
+    HIPCHK(e, launch_mask_prep(mask, B, T, Tp, ts->n_full, ts->kv_end, ts->kbias, nullptr, s));
     HIPCHK(e, launch_cvec_prep(mask, nullptr, B, T, ts->maskbuf, s));
     const float* m = ts->maskbuf;
     HIPCHK(e, launch_to_time_major(e->dt, mu, B, e->M, T, Mp, nullptr, ts->mu16, nullptr, s));
@@ -362,7 +377,8 @@ namespace {
 
 // dW / db of one convolution through the forward kernel.  X: up to two 16-bit sources [R][c0 | c1]; dY: [R][cout16]
 // (16 bit, cout16 = padded channel count of the tensor); gradients go to the reference-layout fp32 tensors.
-struct WgradOut { float* dW; int cin_total; int ci_off; int ci_cnt; int co_start; int co_cnt; float* db; };
+struct WgradOut { float* dW; int cin_total; int ci_off; int ci_cnt; int co_start; int co_cnt; float* db;
+                  const float* unscale = nullptr; };     // {scale, 1 / scale} pair of the dY operand (default: the pass-wide ts->gsc)
 int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, int c1, const void* dy, int cout16, int taps,
           const WgradOut* outs, int n_outs, hipStream_t s) {
     const int N = ts->B, T = ts->T;
@@ -388,8 +404,9 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     for (int k = 0; k < n_outs; ++k) {
         const WgradOut& o = outs[k];
-        if (o.dW) HIPCHK(e, launch_wgrad_reduce(ts->partial, S, cin, cout16, taps, o.dW, o.cin_total, o.ci_off, o.ci_cnt, o.co_start, o.co_cnt, ts->gsc, s));
-        if (o.db) HIPCHK(e, launch_bias_reduce(ts->part_b, (int)((int64_t)S * Rs / 64), cout16, o.db, o.co_start, o.co_cnt, ts->gsc, s));
+        const float* us = o.unscale ? o.unscale : ts->gsc;
+        if (o.dW) HIPCHK(e, launch_wgrad_reduce(ts->partial, S, cin, cout16, taps, o.dW, o.cin_total, o.ci_off, o.ci_cnt, o.co_start, o.co_cnt, us, s));
+        if (o.db) HIPCHK(e, launch_bias_reduce(ts->part_b, (int)((int64_t)S * Rs / 64), cout16, o.db, o.co_start, o.co_cnt, us, s));
     }
     return ST_OK;
 }
@@ -457,7 +474,7 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
             ConvGemmArgs a = cargs(e, ts->ffn1T[i], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->tmpC;
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
         }
-        HIPCHK(e, launch_ln_bwd(A.x2, ts->tmpC, ada_i, 6 * C, 4 * C, m, B, 1, T, N, ts->dX, ts->red, s));
+        HIPCHK(e, launch_ln_bwd(A.x2, ts->tmpC, ada_i, 6 * C, 4 * C, m, B, 1, T, N, ts->dX, ts->red, nullptr, s));
         { const int off[2] = {4 * C, 3 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
         if (cap) capture(e, "g.x2_" + std::to_string(i), ts->dX, R * C, false, s);
         // ---- x2 = x1 + g_msa * o
@@ -484,7 +501,10 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
             a.drop = make_drop(ts->p_drop, ts->seed, 2 * i + 1); a.zeros = e->zeros;
             HIPCHK(e, launch_attn_bwd_dq(e->dt, a, s));
             HIPCHK(e, launch_attn_bwd_dkv(e->dt, a, s));
-            HIPCHK(e, launch_qkv_grad_pack(e->dt, ts->dq, ts->dk, ts->dv, e->rope_cos, e->rope_sin, N, H, T, ts->g16b, s));
+            // d q, d k are ~1/T of d v: each gets its own power-of-two factor before the rounding to 16 bits (f16's normal
+            // range ends at 6e-5); the fused dgrad GEMM takes the copy with one common factor
+            HIPCHK(e, launch_qkv_grad_scales(ts->dq, ts->dk, ts->dv, R * C, ts->gsc, ts->qbits, ts->qs, s));
+            HIPCHK(e, launch_qkv_grad_pack(e->dt, ts->dq, ts->dk, ts->dv, e->rope_cos, e->rope_sin, N, H, T, ts->qs, ts->g16b, ts->g16w, s));
         }
         if (cap) { capture(e, "g.dq_" + std::to_string(i), ts->dq, R * C, false, s); capture(e, "g.dk_" + std::to_string(i), ts->dk, R * C, false, s);
                    capture(e, "g.dv_" + std::to_string(i), ts->dv, R * C, false, s); capture(e, "g.dattn_" + std::to_string(i), ts->g16a, R * C, true, s); }
@@ -492,14 +512,14 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
             WgradOut o[3];
             int r = 0;
             for (const char* nm : {"q", "k", "v"}) {
-                o[r] = {G(ts, b + "attn.conv_" + nm + ".weight"), C, 0, C, r * C, C, G(ts, b + "attn.conv_" + nm + ".bias")};
+                o[r] = {G(ts, b + "attn.conv_" + nm + ".weight"), C, 0, C, r * C, C, G(ts, b + "attn.conv_" + nm + ".bias"), ts->qs + 2 + 2 * r};
                 ++r;
             }
-            if ((rc = wgrad(e, ts, A.h1, C, nullptr, 0, ts->g16b, 3 * C, 1, o, 3, s))) return rc;
+            if ((rc = wgrad(e, ts, A.h1, C, nullptr, 0, ts->g16w, 3 * C, 1, o, 3, s))) return rc;
             ConvGemmArgs a = cargs(e, ts->qkvT[i], N, T, B); a.a0 = ts->g16b; a.c0 = 3 * C; a.out32 = ts->tmpC;
             HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
         }
-        HIPCHK(e, launch_ln_bwd(A.x1, ts->tmpC, ada_i, 6 * C, C, m, B, 0, T, N, ts->dX, ts->red, s));
+        HIPCHK(e, launch_ln_bwd(A.x1, ts->tmpC, ada_i, 6 * C, C, m, B, 0, T, N, ts->dX, ts->red, ts->qs, s));
         { const int off[2] = {C, 0}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
         if (cap) capture(e, "g.x1_" + std::to_string(i), ts->dX, R * C, false, s);
         // ---- x1 = (gamma * xpre + beta) * mask

@@ -44,6 +44,10 @@ struct ConvGemmArgs {
     const float* ln_film; int ln_film_stride; int ln_film_mod;     // gamma = film[(n%mod)*stride + ch], beta = +256
     const float* ln_ada; int ln_ada_stride; int ln_shift_off; int ln_scale_off;
     int ln_mask_out;
+    // Ragged batches: frame tiles of item n that start at or beyond t_lim[n % t_lim_mod] are not computed at all
+    // (nullptr: every tile).  t_lim = last valid frame + 1 + kFrameHalo (mask_prep), so every frame a VALID output
+    // frame depends on -- including the reference's pad leak through the unmasked tensors, SURVEY A.5 -- is computed.
+    const int* t_lim; int t_lim_mod;
     int ksplit;                       // > 1: split-K launch (EPI_F32 only): out32 = partial planes [ksplit][items][T][cout], raw sums
     unsigned long long* dbg;          // diagnostics (ST_STAGE_TIMING builds of tools/gemm2_bench only), else nullptr
 };
@@ -76,6 +80,7 @@ struct AttnArgs {
     const void* zeros;                     // >= 16 zero bytes in global memory (out-of-range K rows)
     float* lse;                            // training: [item][H][T] log2-sum-exp of the scores (nullptr: inference kernel)
     DropCfg drop;                          // training: dropout on the attention probabilities (diffusion_transformer.py:77)
+    const int* t_lim;                      // query tiles of mask row mb that start at or beyond t_lim[mb] are skipped (nullptr: none)
     int small_max_blocks;                  // inference: launches of <= this many 256-query blocks use the key-split small-grid kernel (0: never)
 };
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
@@ -98,7 +103,10 @@ hipError_t launch_time_embed(const float* t, int n_t, int dim, float* emb, hipSt
 // out[n][o] = act_out(bias[o] + sum_i W[o][i] * act_in(in[n][i]))
 hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
                          float* out, int silu_in, int silu_out, hipStream_t s);
-hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, hipStream_t s);
+// t_lim (optional, B + 1 ints): t_lim[b] = min(T, kv_end[b] + kFrameHalo), t_lim[B] = max over the rows
+constexpr int kFrameHalo = 4;   // frames past the last valid one that valid outputs depend on: in_proj's long skip reads cond one
+                                // frame out (k = 3), cond = three k = 3 convs of the unmasked mu (estimator.py:83-89,118,131)
+hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, int* t_lim, hipStream_t s);
 
 // (B, C, T) fp32 -> time-major (B, T, Cp): fp32 and/or 16-bit (+ optional 16-bit rounding residual out16lo),
 // channels >= C zero-filled

@@ -105,7 +105,7 @@ hipError_t launch_linear(const float* in, int n, int k, const float* W, const fl
 // per mask row: n_full = length of the leading run of non-zeros, kv_end = last non-zero + 1,
 // kbias[t] = 0 for valid keys, -1e30 for masked keys and for t in [T, Tp)
 __global__ __launch_bounds__(256) void mask_prep_kernel(const float* mask, int T, int Tp, int* n_full, int* kv_end,
-                                                        float* kbias) {
+                                                        float* kbias, int* t_lim) {
     __shared__ int s_first_zero, s_last_nz;
     const int b = blockIdx.x;
     if (threadIdx.x == 0) { s_first_zero = T; s_last_nz = -1; }
@@ -122,11 +122,19 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const float* mask, int T
     atomicMin(&s_first_zero, fz);
     atomicMax(&s_last_nz, ln);
     __syncthreads();
-    if (threadIdx.x == 0) { n_full[b] = s_first_zero; kv_end[b] = s_last_nz + 1; }
+    if (threadIdx.x == 0) {
+        n_full[b] = s_first_zero; kv_end[b] = s_last_nz + 1;
+        if (t_lim) {
+            const int lim = min(T, s_last_nz + 1 + kFrameHalo);
+            t_lim[b] = lim;
+            atomicMax(&t_lim[gridDim.x], lim);      // entry B: the longest row (zeroed by the launcher)
+        }
+    }
 }
 
-hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, hipStream_t s) {
-    hipLaunchKernelGGL(mask_prep_kernel, dim3(B), dim3(256), 0, s, mask, T, Tp, n_full, kv_end, kbias);
+hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full, int* kv_end, float* kbias, int* t_lim, hipStream_t s) {
+    if (t_lim) { hipError_t e = hipMemsetAsync(t_lim + B, 0, sizeof(int), s); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(mask_prep_kernel, dim3(B), dim3(256), 0, s, mask, T, Tp, n_full, kv_end, kbias, t_lim);
     return hipGetLastError();
 }
 

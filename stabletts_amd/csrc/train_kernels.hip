@@ -212,14 +212,15 @@ hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, cons
 // h = (LN(x) * (1 + sc) + sh) [* mask]
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float* dH, const float* ada, int ada_stride,
                                                      int scale_off, const float* mask, int mask_mod, int mask_out, int T,
-                                                     float* dX, float* part) {
+                                                     float* dX, float* part, const float* dh_scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x, n = blockIdx.y, chunks = gridDim.x;
+    const float dhs = dh_scale ? dh_scale[1] : 1.0f;
     const float4 sc = *(const float4*)(ada + (size_t)n * ada_stride + scale_off + lane * 4);
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     for (int t = chunk * kRedRows + wave; t < T && t < (chunk + 1) * kRedRows; t += 4) {
         const size_t o = ((size_t)n * T + t) * 256 + lane * 4;
-        const float mm = (mask_out && mask) ? mask[(size_t)(n % mask_mod) * T + t] : 1.0f;
+        const float mm = ((mask_out && mask) ? mask[(size_t)(n % mask_mod) * T + t] : 1.0f) * dhs;
         const float4 xv = *(const float4*)(x + o);
         float4 g = *(const float4*)(dH + o);
         g.x *= mm; g.y *= mm; g.z *= mm; g.w *= mm;
@@ -243,9 +244,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float
 
 hipError_t launch_ln_bwd(const float* x, const float* dH, const float* ada, int ada_stride, int scale_off,
                          const float* mask, int mask_mod, int mask_out, int T, int n_items, float* dX, float* part,
-                         hipStream_t s) {
+                         const float* dh_scale, hipStream_t s) {
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(red_chunks(T), n_items), dim3(256), 0, s, x, dH, ada, ada_stride, scale_off,
-                       mask, mask_mod, mask_out, T, dX, part);
+                       mask, mask_mod, mask_out, T, dX, part, dh_scale);
     return hipGetLastError();
 }
 
@@ -336,6 +337,32 @@ hipError_t launch_grad_scale(const float* g, int64_t n, unsigned* bits, float* s
     int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, g, n, bits);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, s, bits, sc);
+    return hipGetLastError();
+}
+__global__ void qkv_scales_kernel(const unsigned* bits3, const float* gsc, float* qs) {
+    float f[3], mx = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        const float m = __uint_as_float(bits3[i]);
+        mx = fmaxf(mx, m);
+        int ex = m > 0.f ? 8 - (int)floorf(log2f(m)) : 0;
+        ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+        f[i] = exp2f((float)ex);
+    }
+    int exc = mx > 0.f ? 8 - (int)floorf(log2f(mx)) : 0;
+    exc = exc < -60 ? -60 : (exc > 60 ? 60 : exc);
+    const float fc = exp2f((float)exc);
+    qs[0] = fc; qs[1] = 1.0f / fc;
+    for (int i = 0; i < 3; ++i) { qs[2 + 2 * i] = f[i] * gsc[0]; qs[3 + 2 * i] = 1.0f / (f[i] * gsc[0]); qs[8 + i] = f[i]; }
+}
+hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float* dv, int64_t n, const float* gsc,
+                                  unsigned* bits3, float* qs, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(bits3, 0, 12, s);
+    if (e != hipSuccess) return e;
+    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dq, n, bits3);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dk, n, bits3 + 1);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dv, n, bits3 + 2);
+    hipLaunchKernelGGL(qkv_scales_kernel, dim3(1), dim3(1), 0, s, bits3, gsc, qs);
     return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float* a, int64_t n, const float* sc) {

@@ -50,9 +50,10 @@ hipError_t launch_unscale_inplace(float* a, int64_t n, const float* sc, hipStrea
 hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, const float* gate, int gate_stride,
                            const float* mask, int mask_mod, int T, int n_items, void* dB16, float* part, hipStream_t s);
 // h = (LN(x) (1 + sc) + sh) [* mask]:  dX += LN'(dH ...) ; part[.][0] = d scale, part[.][1] = d shift
+// dh_scale (optional): dH is multiplied by dh_scale[1] on load (a GEMM result computed from locally re-scaled operands)
 hipError_t launch_ln_bwd(const float* x, const float* dH, const float* ada, int ada_stride, int scale_off,
                          const float* mask, int mask_mod, int mask_out, int T, int n_items, float* dX, float* part,
-                         hipStream_t s);
+                         const float* dh_scale, hipStream_t s);
 // x = (gamma * xpre + beta) * mask:  part[.][0] = d gamma, part[.][1] = d beta ; dX = dX * mask * gamma (in place) (+ 16-bit copy)
 hipError_t launch_film_bwd(int dtype, const float* xpre, const float* film, int film_stride, int film_mod,
                            const float* mask, int mask_mod, int T, int n_items, float* dX, void* dX16, float* part,
@@ -131,8 +132,19 @@ struct AttnBwdArgs {
 };
 hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s);
-// RoPE^T on dq, dk, the 1/8 and ln2 factors, and packing into the time-major 16-bit operand [item][T][3*H*64]
+// Local power-of-two scales of the attention-input gradients.  d q and d k are ~1/T of d v in magnitude (P ~ 1/T), far
+// below f16's normal range at the pass-wide gradient scale, so each of the three gets its own factor before it is
+// rounded to 16 bits.  From the device-side maxima of |dq|, |dk|, |dv| (n values each) and the pass-wide pair gsc:
+//   qs[0..1] = {f_c, 1 / f_c}        one common factor (max of the three -> ~2^8): operand of the fused q/k/v DGRAD GEMM,
+//                                     whose fp32 result the consumer multiplies by qs[1]
+//   qs[2..3], [4..5], [6..7]          {f_x gsc[0], 1 / (f_x gsc[0])} for x = q, k, v: unscale pairs of the three WGRAD outputs
+//   qs[8..10]                         f_q, f_k, f_v (each tensor's own maximum -> ~2^8): operand of the WGRAD GEMM
+hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float* dv, int64_t n, const float* gsc,
+                                  unsigned* bits3, float* qs, hipStream_t s);
+// RoPE^T on dq, dk, the 1/8 and ln2 factors, and packing into the time-major 16-bit operands [item][T][3*H*64]:
+// d16 (common factor qs[0], dgrad) and w16 (per-tensor factors qs[8..10], wgrad)
 hipError_t launch_qkv_grad_pack(int dtype, const float* dq, const float* dk, const float* dv, const float* rope_cos,
-                                const float* rope_sin, int n_items, int H, int T, void* dqkv16, hipStream_t s);
+                                const float* rope_sin, int n_items, int H, int T, const float* qs, void* d16, void* w16,
+                                hipStream_t s);
 
 }  // namespace st

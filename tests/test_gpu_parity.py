@@ -67,7 +67,7 @@ def test_native_library_loaded(decoders):
     from stabletts_amd import _lib
     assert isinstance(_lib.load(), ctypes.CDLL)
     eng = decoders["bf16"].estimator.engine()
-    assert eng.num_params() == 116 and eng.device_bytes() > 100e6
+    assert eng.num_params() == 116 and eng.device_bytes() > 30e6      # packed 16-bit weights (the fp32 tensors stay torch's)
     maps = open("/proc/self/maps").read()
     assert "libstabletts_hip.so" in maps
 

@@ -20,4 +20,4 @@ torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
 eng = d.estimator.engine(); eng.profile_enable(True); run(); torch.cuda.synchronize()
 pr = eng.profile_read()
 print(os.environ.get("STABLETTS_HIP_LIB", "default").split("/")[-1], "phased=" + os.environ.get("ST_PHASED", "0"), f"{ms:.2f} ms",
-      {k: round(v["total_ms"], 2) for k, v in pr.items() if v["launches"] and k in ("qkv_rope", "out_proj", "ffn_conv1", "ffn_conv2", "lsc_conv")})
+      {k: round(v["total_ms"], 2) for k, v in pr.items() if v["launches"] and k in ("qkv_rope", "attention", "out_proj", "ffn_conv1", "ffn_conv2", "lsc_conv")})
