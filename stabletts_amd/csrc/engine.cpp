@@ -245,11 +245,22 @@ int ensure_ws(st_engine* e, size_t bytes) {
     e->drop_graphs();      // instantiated graphs hold arena pointers
     if (e->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(e->ws)); e->ws = nullptr; e->ws_cap = 0; }
     HIPCHK(e, hipMalloc((void**)&e->ws, bytes));
-    // Ragged batches leave frame tiles past an utterance's end uncomputed; whatever they hold is only ever read by
-    // don't-care positions, but it must be FINITE (0 x NaN would leak through a mask multiply): start from zeros.
-    HIPCHK(e, hipMemset(e->ws, 0, bytes));
     e->ws_cap = bytes;
+    e->ws_sig = 0;
     return ST_OK;
+}
+
+int arena_fresh(st_engine* e, uint64_t sig, size_t used_bytes, hipStream_t s) {
+    if (sig == e->ws_sig) return ST_OK;
+    HIPCHK(e, hipMemsetAsync(e->ws, 0, used_bytes, s));
+    e->ws_sig = sig;
+    return ST_OK;
+}
+
+static uint64_t layout_sig(int entry, int B, int T, int cfg, int n_t, int parts) {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)entry, (uint64_t)B, (uint64_t)T, (uint64_t)cfg, (uint64_t)n_t, (uint64_t)parts}) { h ^= v + 0x9E3779B97F4A7C15ull; h *= 1099511628211ull; }
+    return h | 1ull;
 }
 
 void bind_plan(st_engine* e, Plan* p) {
@@ -992,6 +1003,8 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
     hipStream_t s = (hipStream_t)stream;
     Plan p;
     if ((rc = make_plan(e, B, T, false, t_len, &p))) return rc;
+    if ((rc = arena_fresh(e, layout_sig(1, B, T, 0, t_len, 1), layout_plan(e, B, T, false, t_len, 0, &p), s))) return rc;
+    bind_plan(e, &p);
     if ((rc = ensure_rope(e, T, s))) return rc;
     {
         ProfScope ps(e, s, PC_PREP, 0);
@@ -1059,6 +1072,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
             off = layout_plan(e, parts[k].nb, T, use_cfg != 0, n_t, off, &parts[k].p);
         }
         if ((rc = ensure_ws(e, off))) return rc;
+        if ((rc = arena_fresh(e, layout_sig(2, B, T, use_cfg != 0, n_t, nparts), off, s))) return rc;
         for (auto& pt : parts) bind_plan(e, &pt.p);
     }
     if ((rc = ensure_rope(e, T, s))) return rc;
@@ -1230,6 +1244,7 @@ int st_text_encoder_forward(st_engine* e, const int64_t* tokens, const int64_t* 
     hipStream_t s = (hipStream_t)stream;
     Plan p;
     if ((rc = make_plan(e, B, T, false, 1, &p))) return rc;
+    e->ws_sig = 0;         // (the text encoder computes every frame; whatever uses the arena next re-zeroes it)
     if ((rc = ensure_rope(e, T, s))) return rc;
     {
         ProfScope ps(e, s, PC_PREP, 0);

@@ -73,6 +73,7 @@ struct st_engine {
 
     // workspace arena
     char* ws = nullptr; size_t ws_cap = 0;
+    uint64_t ws_sig = 0;                // layout signature of what the arena last held (see arena_fresh)
 
     // debug / profile
     bool capture = false;
@@ -138,6 +139,11 @@ hipError_t gemm(st_engine* e, int taps, int epi, const st::ConvGemmArgs& a, hipS
 void prof_collect(st_engine* e);
 void capture(st_engine* e, const std::string& name, const void* dev, int64_t n, bool is16, hipStream_t s);
 int ensure_ws(st_engine* e, size_t bytes);
+// Ragged batches leave frame tiles past an utterance's end uncomputed; whatever the arena holds there is only ever read by
+// don't-care positions (masked keys, frames whose results are multiplied by the mask), but it must be FINITE: 0 x NaN would
+// leak.  Stale values of the SAME layout are real activations of an earlier call (finite); when the layout changes (other B, T,
+// CFG, part count, entry point) the bytes would be re-interpreted under another type, so the used range is zeroed once, on `s`.
+int arena_fresh(st_engine* e, uint64_t sig, size_t used_bytes, hipStream_t s);
 int ensure_rope(st_engine* e, int T, hipStream_t s);
 int check_ready(st_engine* e, int B, int T);
 extern std::string g_create_error;
