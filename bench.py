@@ -96,7 +96,7 @@ def cpu_baseline(sd, cfg_params, budget_s=20.0):
                        f"os.cpu_count()={os.cpu_count()}")
 
 
-def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5):
+def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
     """BASELINE config 5 on ONE GPU (train.py:78-82 shape: B=64 utterances per GPU, T <= 1000 ragged, dropout on):
     CFMDecoder.compute_loss forward (native, keeps activations) + loss.backward() (native dgrad / wgrad / attention
     backward) + AdamW step, timed phase by phase (a device sync between phases) and as whole back-to-back steps (one
@@ -106,7 +106,7 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5):
     from stabletts_amd.flow_matching import CFMDecoder
     dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dtype)
     dec.estimator.load_state_dict(sd)
-    dec = dec.to(dev).train()
+    dec = dec.to(dev).train(dropout)
     opt = torch.optim.AdamW(dec.parameters(), lr=1e-4)
     raw = make_inputs(B, T, seed=0, ragged=True)
     inp = {k: v.to(dev) for k, v in raw.items() if k != "lengths"}
@@ -140,7 +140,7 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5):
     fwd_flops = 2.0 * (12320768 + 3072 * T + 4325376) * B * T           # one evaluation incl. the prenet, padded frames
     fb = (times["fwd"] + times["bwd"]) / steps
     res = {"workload": f"BASELINE config 5 on one GPU: compute_loss forward + backward + AdamW, B={B} x T={T} ragged "
-                       f"({valid} valid frames), per-item t, dropout 0.1, {dtype} operands",
+                       f"({valid} valid frames), per-item t, dropout {'0.1' if dropout else 'off (eval mode)'}, {dtype} operands",
            "ms_forward": times["fwd"] / steps * 1e3, "ms_backward": times["bwd"] / steps * 1e3,
            "ms_optimizer_incl_repack": times["opt"] / steps * 1e3, "ms_step_back_to_back": whole * 1e3,
            "mel_frames_per_sec_step": valid / whole, "tflops_fwd_bwd_3x_forward": 3 * fwd_flops / fb / 1e12,

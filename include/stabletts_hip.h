@@ -207,6 +207,10 @@ int st_train_backward(st_engine* e, int64_t serial, int B, int T, const float* g
 /* Copies the gradient of one parameter (reference state_dict name, `numel` fp32 values) to the device pointer dst. */
 int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, void* stream);
 
+/* All parameter gradients in ONE copy: dst receives them back to back in st_param_info's order (index 0 first), `numel` =
+ * the sum of all parameter sizes.  What loss.backward() of the autograd binding uses (one 81 MB copy instead of 116). */
+int st_param_grads_flat(st_engine* e, float* dst, int64_t numel, void* stream);
+
 /* Function evaluations, attempted steps and rejected steps of the last st_cfm_solve (adaptive solvers vary). */
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects);
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "st_finalize", "st_bind_param", "st_repack", "st_train_serial", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
-    "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad",
+    "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad", "st_param_grads_flat",
     "st_durations", "st_generate_path", "st_align", "st_create_vocoder", "st_vocos_forward",
 ]
 
@@ -127,6 +127,8 @@ def load():
     lib.st_train_backward.restype = c_int
     lib.st_param_grad.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64, c_void_p]
     lib.st_param_grad.restype = c_int
+    lib.st_param_grads_flat.argtypes = [c_void_p, c_void_p, ctypes.c_int64, c_void_p]
+    lib.st_param_grads_flat.restype = c_int
     lib.st_durations.argtypes = [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.st_durations.restype = c_int
     lib.st_generate_path.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
@@ -266,6 +268,25 @@ class Engine:
 
     def param_grad(self, name, dst, stream):
         self._check(self.lib.st_param_grad(self.handle, name.encode(), dst.data_ptr(), dst.numel(), ctypes.c_void_p(stream)))
+
+    def param_grads_flat(self, dst, stream):
+        """Every parameter gradient in one copy: dst (fp32, sum of all parameter sizes) in param_info() order."""
+        self._check(self.lib.st_param_grads_flat(self.handle, dst.data_ptr(), dst.numel(), ctypes.c_void_p(stream)))
+
+    def grad_layout(self):
+        """{reference name: (offset, numel, shape)} of param_grads_flat's layout (cached)."""
+        lay = getattr(self, "_grad_layout", None)
+        if lay is None:
+            lay, off = {}, 0
+            for name, shape in self.param_info():
+                n = 1
+                for d in shape:
+                    n *= d
+                lay[name] = (off, n, shape)
+                off += n
+            lay[None] = off
+            self._grad_layout = lay
+        return lay
 
     def last_solve_stats(self):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()

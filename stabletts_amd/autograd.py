@@ -57,14 +57,17 @@ class _EstimatorFn(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             eng.train_backward(ctx.serial, g, gx, gmu, gc, stream)     # the C ABI re-checks serial, B, T (ST_ERR_STATE)
+            # all 116 parameter gradients in one device copy; each parameter's gradient is a view into it
+            lay = eng.grad_layout()
+            flat = torch.empty(lay[None], **f32)
+            eng.param_grads_flat(flat, stream)
             pgrads = []
             for name, p, nd in zip(ctx.names, decoder.parameters(), need[7:]):
                 if not nd:
                     pgrads.append(None)
                     continue
-                gp = torch.empty(p.shape, device=dev, dtype=torch.float32)
-                eng.param_grad(name, gp, stream)
-                pgrads.append(gp)
+                off, n, _ = lay[name]
+                pgrads.append(flat[off:off + n].view(p.shape))
         return (None, None, None, gx, None, gmu, gc, *pgrads)
 
 

@@ -451,15 +451,40 @@ hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------ operand copies
 // natural rows -> T layout.  Source rows may be strided (time-major dO: row stride H*64, head offset h*64).
 // mean[nh][d] = mean over t < T of nat[t][d]  (natural [item][H][T][64])
+// one block per (item, head): thread (row group ty of 32, lane tx of 8) reads 16 bytes = head dims tx*8 .. +8 of row t,
+// four rows in flight; the 32 row-group partials are combined in a fixed order (deterministic)
 template <class P>
 __global__ __launch_bounds__(256) void attn_mean_nat_kernel(const typename P::elem* nat, int T, float* mean) {
-    __shared__ float part[4][64];
-    const int nh = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    float v = 0.f;
-    for (int t = ty; t < T; t += 4) v += (float)nat[((size_t)nh * T + t) * 64 + tx];
-    part[ty][tx] = v;
+    __shared__ float part[32][64 + 1];
+    const int nh = blockIdx.x, tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const typename P::elem* base = nat + (size_t)nh * T * 64 + tx * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int t = ty;
+    for (; t + 96 < T; t += 128) {
+        uint4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = *(const uint4*)(base + (size_t)(t + 32 * u) * 64);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const typename P::vec8 x = as_vec8<P>(r[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)x[e];
+        }
+    }
+    for (; t < T; t += 32) {
+        const typename P::vec8 x = as_vec8<P>(*(const uint4*)(base + (size_t)t * 64));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)x[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[ty][tx * 8 + e] = v[e];
     __syncthreads();
-    if (ty == 0) mean[(size_t)nh * 64 + tx] = (part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]) / (float)T;
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) s += part[g][threadIdx.x];
+        mean[(size_t)nh * 64 + threadIdx.x] = s / (float)T;
+    }
 }
 
 hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, int T, float* mean, hipStream_t s) {
@@ -505,10 +530,14 @@ template <class P>
 __global__ __launch_bounds__(256) void attn_vmean_kernel(const typename P::elem* inT, int T, int Tp, float* vmean) {
     // one block per (item, head); wave w handles head dims w, w+4, ...; lanes stride over the positions
     const int nh = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = wave; d < 64; d += 4) {
+    for (int d = wave; d < 64; d += 4) {          // 16 bytes (8 positions) per lane and load; Tp is a multiple of 64
         const typename P::elem* row = inT + ((size_t)nh * 64 + d) * Tp;
         float v = 0.f;
-        for (int c = lane; c < Tp; c += 64) v += (float)row[c];
+        for (int c = lane * 8; c < Tp; c += 512) {
+            const typename P::vec8 x = as_vec8<P>(*(const uint4*)(row + c));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v += (float)x[e];
+        }
         v = wave_sum(v);
         if (lane == 0) vmean[(size_t)nh * 64 + d] = v / (float)T;
     }

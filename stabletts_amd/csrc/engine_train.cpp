@@ -37,7 +37,8 @@ struct TrainState {
     Conv finT, inxT, incT, preT[3];
     std::vector<Conv> ffn1T, ffn2T, oprojT, qkvT, lscTa, lscTb;
     std::vector<void*> owned;
-    std::map<std::string, float*> grads;       // fp32 gradient buffers, reference shapes
+    std::map<std::string, float*> grads;       // fp32 gradient buffers, reference shapes: slices of grad_flat in parameter-name order
+    float* grad_flat = nullptr; int64_t grad_numel = 0;
     // activation + scratch arena of the last train_forward
     char* ws = nullptr; size_t ws_cap = 0;
     int B = 0, T = 0, Tp = 0;
@@ -127,9 +128,13 @@ int train_prepare(st_engine* e, hipStream_t s) {
         if ((rc = pack_T(e, ts, ts->lscTa[j], n, C, 2 * C, K, 0, C, C, C, s))) return rc;
         if ((rc = pack_T(e, ts, ts->lscTb[j], n, C, 2 * C, K, C, C, C, C, s))) return rc;
     }
-    for (auto& kv : e->params) {
-        float*& g = ts->grads[kv.first];
-        if (!g) { HIPCHK(e, hipMalloc((void**)&g, (size_t)kv.second.numel() * 4)); ts->owned.push_back(g); }
+    if (!ts->grad_flat) {      // one allocation, parameter-name order (st_param_info's order): st_param_grads_flat copies it in one piece
+        int64_t total = 0;
+        for (auto& kv : e->params) total += kv.second.numel();
+        HIPCHK(e, hipMalloc((void**)&ts->grad_flat, (size_t)total * 4)); ts->owned.push_back(ts->grad_flat);
+        ts->grad_numel = total;
+        int64_t off = 0;
+        for (auto& kv : e->params) { ts->grads[kv.first] = ts->grad_flat + off; off += kv.second.numel(); }
     }
     ts->packed = true;
     return ST_OK;
@@ -138,7 +143,7 @@ int train_prepare(st_engine* e, hipStream_t s) {
 int64_t train_bytes(const st_engine* e) {      // transposed weights + gradient buffers + activation / scratch arena
     if (!e->train) return 0;
     int64_t n = (int64_t)e->train->ws_cap;
-    for (auto& kv : e->train->grads) if (kv.second) n += e->params.at(kv.first).numel() * 4;
+    n += e->train->grad_numel * 4;
     auto add = [&](const Conv& c) { if (c.w) n += (int64_t)c.cout * c.taps * c.cin * 2; };
     add(e->train->finT); add(e->train->inxT); add(e->train->incT);
     for (auto& c : e->train->preT) add(c);
@@ -599,6 +604,15 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
     HIPCHK(e, launch_linear_bwd_in(ts->th_pre, ts->dtau, P(e, "time_mlp.layer.2.weight"), N, F, C, 1, ts->dth, 0, s));
     HIPCHK(e, launch_linear_bwd_w(ts->emb, ts->dth, N, C, F, 0, G(ts, "time_mlp.layer.0.weight"), G(ts, "time_mlp.layer.0.bias"), s));
     if (grad_c) HIPCHK(e, hipMemcpyAsync(grad_c, ts->dcvec, (size_t)N * C * 4, hipMemcpyDeviceToDevice, s));
+    return ST_OK;
+}
+
+int st_param_grads_flat(st_engine* e, float* dst, int64_t numel, void* stream) {
+    if (!e || !dst) return ST_ERR_INVALID;
+    if (!e->train || !e->train->grad_flat) return e->fail(ST_ERR_STATE, "no training state");
+    if (numel != e->train->grad_numel) return e->fail(ST_ERR_INVALID, "st_param_grads_flat: numel must be the sum of all parameter sizes");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(dst, e->train->grad_flat, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return ST_OK;
 }
 

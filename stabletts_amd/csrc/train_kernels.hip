@@ -313,10 +313,18 @@ hipError_t launch_cast16(int dtype, const float* x, const float* mask, int mask_
 // host synchronisation).
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, int64_t n, unsigned* out_bits) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = fabsf(x[i]);
-        if (v == v && v < 3.0e38f) m = fmaxf(m, v);
+    auto take = [&](float v) { v = fabsf(v); if (v == v && v < 3.0e38f) m = fmaxf(m, v); };      // NaN / inf do not set the scale
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four 16-byte loads in flight per lane
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(x + 4 * (i + u * stride));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { take(v[u].x); take(v[u].y); take(v[u].z); take(v[u].w); }
     }
+    for (; i < n4; i += stride) { const float4 v = *(const float4*)(x + 4 * i); take(v.x); take(v.y); take(v.z); take(v.w); }
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) take(x[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));        // non-negative floats order like their bits
@@ -334,7 +342,7 @@ __global__ void grad_scale_kernel(const unsigned* bits, float* sc) {
 hipError_t launch_grad_scale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s) {
     hipError_t e = hipMemsetAsync(bits, 0, 4, s);
     if (e != hipSuccess) return e;
-    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, g, n, bits);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, s, bits, sc);
     return hipGetLastError();
@@ -358,7 +366,7 @@ hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float*
                                   unsigned* bits3, float* qs, hipStream_t s) {
     hipError_t e = hipMemsetAsync(bits3, 0, 12, s);
     if (e != hipSuccess) return e;
-    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dq, n, bits3);
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dk, n, bits3 + 1);
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dv, n, bits3 + 2);
@@ -496,21 +504,22 @@ hipError_t launch_wgrad_reduce(const float* partial, int S, int cin, int cout, i
     return hipGetLastError();
 }
 
-// block = 64 channels x 16 row-block groups; fixed summation order (group partials combined 0..15): deterministic
+// block = 16 channels x 64 row-block groups (cout / 16 blocks: the earlier 64 x 16 shape ran a 256-channel bias on 4 blocks);
+// fixed summation order (group partials combined 0..63): deterministic
 __global__ __launch_bounds__(1024) void bias_reduce_kernel(const float* part_b, int rowblocks, int cout, float* db, int co_start,
                                                            int co_cnt, const float* unscale) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int co = blockIdx.x * 64 + tx;
+    __shared__ float red[64][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int co = blockIdx.x * 16 + tx;
     float v = 0.f;
     if (co < cout)
-        for (int rb = ty; rb < rowblocks; rb += 16) v += part_b[(size_t)rb * cout + co];
+        for (int rb = ty; rb < rowblocks; rb += 64) v += part_b[(size_t)rb * cout + co];
     red[ty][tx] = v;
     __syncthreads();
     if (ty == 0 && co < cout && co >= co_start && co < co_start + co_cnt) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][tx];
+        for (int g = 0; g < 64; ++g) t += red[g][tx];
         if (unscale) t *= unscale[1];
         db[co - co_start] = t;
     }
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(1024) void bias_reduce_kernel(const float* part_b, 
 
 hipError_t launch_bias_reduce(const float* part_b, int rowblocks, int cout, float* db, int co_start, int co_cnt,
                               const float* unscale, hipStream_t s) {
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3((cout + 63) / 64), dim3(1024), 0, s, part_b, rowblocks, cout, db, co_start, co_cnt, unscale);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((cout + 15) / 16), dim3(1024), 0, s, part_b, rowblocks, cout, db, co_start, co_cnt, unscale);
     return hipGetLastError();
 }
 

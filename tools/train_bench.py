@@ -19,10 +19,12 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--no-dropout", action="store_true")
     args = ap.parse_args()
     import oracle
     from bench import train_step_leg
-    print(json.dumps(train_step_leg(torch.device("cuda", 0), oracle.make_state_dict(1234), args.batch, args.frames, args.dtype, args.steps)))
+    print(json.dumps(train_step_leg(torch.device("cuda", 0), oracle.make_state_dict(1234), args.batch, args.frames, args.dtype, args.steps,
+                                    dropout=not args.no_dropout)))
 
 
 if __name__ == "__main__":
