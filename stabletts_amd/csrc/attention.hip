@@ -39,7 +39,7 @@ namespace st {
 // TRAIN: also writes the log2-sum-exp of every query row (for the backward's recomputation of P) and applies
 // dropout to the probabilities that enter P.V (not to the normaliser), as SDPA's dropout_p does.
 template <class P, bool TRAIN>
-__global__ __launch_bounds__(64 * ST_ATTN_WAVES, (ST_ATTN_WAVES >= 16 || TRAIN) ? 2 : 4) void attention_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) void attention_kernel(const AttnArgs a) {
     constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW, QTILE = QB;      // waves and queries per block
     using vec8 = typename P::vec8;
     constexpr int TILE_BYTES = 64 * 128;
@@ -71,6 +71,17 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, (ST_ATTN_WAVES >= 16 || TRAIN) 
     const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
     const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
     const unsigned char* vbase = (const unsigned char*)a.vt + ((size_t)nh * 64) * Tp * 2;
+    if constexpr (TRAIN) {
+        if (qt * QB >= kvend) {      // ragged batch: queries past the item's last valid frame -- their rows are multiplied by the
+            if (query < T) {         // mask downstream (diffusion_transformer.py:111); the backward reads them: defined zeros
+                unsigned char* orow = (unsigned char*)a.out + (((size_t)n * T + query) * (H * 64) + h * 64) * 2 + hi * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint4*)(orow + 16 * i) = make_uint4(0, 0, 0, 0);
+                if (hi == 0) a.lse[(size_t)nh * T + query] = 0.f;
+            }
+            return;
+        }
+    }
 
     // Q fragments (B operand): lane (query, hi) holds head dims ks*16 + hi*8 .. +8
     vec8 qf[4];
@@ -133,6 +144,8 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, (ST_ATTN_WAVES >= 16 || TRAIN) 
     // stays inside f16's range, and since m_ref >= the first tile's exact maximum, smaller terms only underflow when
     // they are negligible.  The first tile always takes the correction path (m_ref starts at 0).
     constexpr float kLazy = 8.0f, kFloor = -20000.0f;
+    unsigned drop_rh = 0;
+    if constexpr (TRAIN) { if (a.drop.thresh16) drop_rh = a.drop.rowh[(size_t)nh * T + (query < T ? query : T - 1)]; }
     float m_ref = 0.f, l_run = 0.f;
     vec8 qaug, kaug;
 #pragma unroll
@@ -205,14 +218,19 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, (ST_ATTN_WAVES >= 16 || TRAIN) 
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[kb][r]);
-                psum[r & 1] = add_f32_scalar(psum[r & 1], p);
+            for (int r = 0; r < 16; r += 2) {
+                float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                psum[0] = add_f32_scalar(psum[0], p0);
+                psum[1] = add_f32_scalar(psum[1], p1);
                 if constexpr (TRAIN) {
-                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    p *= drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key);
+                    if (a.drop.thresh16) {      // elements r, r+1 are keys 2j, 2j+1: one hash decides both (DropCfg, launch.h)
+                        const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float2 f = drop_factors2(a.drop, drop_pair(drop_rh, a.drop.colh[key >> 1]));
+                        p0 *= f.x; p1 *= f.y;
+                    }
                 }
-                pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p);
+                pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p0);
+                pf[kb * 2 + (r >> 3)][(r & 7) + 1] = to16<P>(p1);
             }
         l_run += psum[0] + psum[1];
 

@@ -108,6 +108,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     const int l31 = lane & 31, hi = lane >> 5;
     const int query = qt * QB + wave * 32 + l31;
     const bool qok = query < T;
+    if (qt * QB >= kvend) {
+        // Ragged batch: every query of this tile lies past the item's last valid frame.  d attn is exactly 0 there (the
+        // out-projection's output is multiplied by the mask, diffusion_transformer.py:111), so dq = 0, D' = 0: no key loop.
+        if (qok) {
+            float* dst = a.dq + ((size_t)nh * T + query) * 64 + hi * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(float4*)(dst + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hi == 0) { a.Dq[(size_t)nh * T + query] = 0.f; a.Fq[(size_t)nh * T + query] = 1.f; a.aq[(size_t)nh * T + query] = 0.f; }
+        }
+        return;
+    }
 
     const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
     const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         a_q = xor32_sum(a_q);
     }
     constexpr bool dropping = DROP;
+    const unsigned drop_rh = DROP ? a.drop.rowh[(size_t)nh * T + (qok ? query : T - 1)] : 0u;
 
     const int ntiles = (kvend + 63) >> 6;
     auto issue = [&](int kt, int buf) {     // 8 pieces per tile, one per wave
@@ -187,12 +199,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
             for (int g4 = 0; g4 < 4; ++g4) {
                 const float4 bz = *(const float4*)(kbias + kt * 64 + kb * 32 + 8 * g4 + 4 * hi);
                 const float bzv[4] = {bz.x, bz.y, bz.z, bz.w};
+                float fv4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (DROP) {     // keys 8 g4 + 4 hi + {0, 1} and + {2, 3}: two pair hashes (DropCfg, launch.h)
+                    const int key0 = kt * 64 + kb * 32 + 8 * g4 + 4 * hi;
+                    const uint2 ch = *(const uint2*)(a.drop.colh + (key0 >> 1));
+                    const float2 f01 = drop_factors2(a.drop, drop_pair(drop_rh, ch.x)), f23 = drop_factors2(a.drop, drop_pair(drop_rh, ch.y));
+                    fv4[0] = f01.x; fv4[1] = f01.y; fv4[2] = f23.x; fv4[3] = f23.y;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const int key = kt * 64 + kb * 32 + 8 * g4 + 4 * hi + e;
                     const float p = __builtin_amdgcn_exp2f(s[kb][r] + bzv[e] - lse_q);
-                    const float f = DROP ? drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key) : 1.0f;
+                    const float f = fv4[e];
                     if (!second) {
                         Dacc += p * f * dp[kb][r]; Facc += p * f;
                         mxpd = fmaxf(mxpd, fabsf(p * f * dp[kb][r])); mxp = fmaxf(mxp, p);
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 
 // ------------------------------------------------------------------------------------------ dK, dV
 template <class P, bool DROP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     constexpr int NW = 4, KB = 32 * NW;
     using vec8 = typename P::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // kDkvLds bytes
@@ -278,6 +296,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs 
     const int l31 = lane & 31, hi = lane >> 5;
     const int key = kblk * KB + wave * 32 + l31;
     const bool kok = key < T;
+    const int kvend = a.kv_end[mb];
+    if (kblk * KB >= kvend) {       // ragged batch: every key of this block is past the item's last valid frame (P = 0): dk = dv = 0
+        if (kok) {
+            float* d1 = a.dk + ((size_t)nh * T + key) * 64 + hi * 32;
+            float* d2 = a.dv + ((size_t)nh * T + key) * 64 + hi * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { *(float4*)(d1 + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(d2 + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+        return;
+    }
 
     const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
     const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
@@ -309,8 +337,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs 
         }
     }
     const float bias_k = kok ? a.kbias[(size_t)mb * Tp + key] : -1e30f;
+    const unsigned drop_ch = DROP ? a.drop.colh[(key < Tp ? key : Tp - 1) >> 1] : 0u;
 
-    const int nq = (T + 63) >> 6;
+    const int nq = ((kvend < T ? kvend : T) + 63) >> 6;      // queries past the last valid frame have d attn = 0: they add nothing
     auto issue = [&](int qt, int buf) {     // 4 tiles x 8 pieces over 4 waves: each wave moves pieces 2*wave, 2*wave+1 of every tile
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -368,12 +397,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnBwdArgs 
                 const float4 az = *(const float4*)(a_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                 const float lv[4] = {lz.x, lz.y, lz.z, lz.w}, dvv[4] = {dz.x, dz.y, dz.z, dz.w};
                 const float fv[4] = {fz.x, fz.y, fz.z, fz.w}, av[4] = {az.x, az.y, az.z, az.w};
+                float fq4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (DROP) {     // this lane's key is one half of its pair: its own 16 bits of every query's pair hash (DropCfg, launch.h)
+                    const uint4 rh = *(const uint4*)(a.drop.rowh + (size_t)nh * T + qt * 64 + qb * 32 + 8 * g4 + 4 * hi);   // (table has a 64-entry tail)
+                    const unsigned rhv[4] = {rh.x, rh.y, rh.z, rh.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float2 f2 = drop_factors2(a.drop, drop_pair(rhv[e], drop_ch));
+                        fq4[e] = (key & 1) ? f2.y : f2.x;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const int query = qt * 64 + qb * 32 + 8 * g4 + 4 * hi + e;
                     const float p = __builtin_amdgcn_exp2f(s[qb][r] + bias_k - lv[e]);
-                    const float f = DROP ? drop_factor(a.drop, (unsigned)(nh * T + query), (unsigned)key) : 1.0f;
+                    const float f = fq4[e];
                     pdf[qb * 2 + (r >> 3)][r & 7] = to16<P>(p * f);
                     float ds = p * (dp[qb][r] * f - dvv[e]);
                     if (dropping) ds += p * av[e] * (f - fv[e]);
@@ -412,7 +450,8 @@ hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s) {
     const int qtiles = (a.T + 255) / 256;
     const int total = a.n_items * a.H * qtiles;
     const int grid = ((total + 7) / 8) * 8;
-    const bool drop = a.drop.thresh != 0;
+    const bool drop = a.drop.thresh16 != 0;
+    if (drop && (!a.drop.rowh || !a.drop.colh)) return hipErrorInvalidValue;
     if (dtype == DT_BF16) {
         if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, true>), dim3(grid), dim3(512), 0, s, a);
         else      hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, false>), dim3(grid), dim3(512), 0, s, a);
@@ -432,7 +471,8 @@ hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s) {
     static bool attr_done_dev[64][4] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
-    const bool drop = a.drop.thresh != 0;
+    const bool drop = a.drop.thresh16 != 0;
+    if (drop && (!a.drop.rowh || !a.drop.colh)) return hipErrorInvalidValue;
     const int di = (dtype == DT_BF16 ? 0 : 1) * 2 + (drop ? 1 : 0);
     const void* fns[4] = {(const void*)attn_bwd_dkv_kernel<OpBF16, false>, (const void*)attn_bwd_dkv_kernel<OpBF16, true>,
                           (const void*)attn_bwd_dkv_kernel<OpF16, false>, (const void*)attn_bwd_dkv_kernel<OpF16, true>};

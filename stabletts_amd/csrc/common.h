@@ -148,14 +148,23 @@ __host__ __device__ __forceinline__ unsigned drop_mix32(unsigned h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
 }
-__host__ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned a, unsigned b) {
-    const unsigned h = drop_mix32((unsigned)seed ^ (a * 0x9E3779B1u));
-    return drop_mix32(h ^ (unsigned)(seed >> 32) ^ (b * 0x85ebca77u));
+// (see DropCfg in launch.h)  pair mix: lowbias32
+__host__ __device__ __forceinline__ unsigned drop_pair(unsigned rh, unsigned ch) {
+    unsigned h = rh ^ ch;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
 }
+__host__ __device__ __forceinline__ unsigned drop_rowh(unsigned long long seed, unsigned row) { return drop_mix32((unsigned)seed ^ (row * 0x9E3779B1u)); }
+__host__ __device__ __forceinline__ unsigned drop_colh(unsigned long long seed, unsigned j) { return drop_mix32((unsigned)(seed >> 32) ^ (j * 0x85ebca77u)); }
+// the two keep factors (scale or 0) a 32-bit hash decides: .x for the even element of the pair, .y for the odd one
 template <class D>
-__device__ __forceinline__ float drop_factor(const D& d, unsigned a, unsigned b) {
-    if (d.thresh == 0) return 1.0f;
-    return drop_hash(d.seed, a, b) >= d.thresh ? d.scale : 0.0f;
+__device__ __forceinline__ float2 drop_factors2(const D& d, unsigned h) {
+    return make_float2((h & 0xFFFFu) >= d.thresh16 ? d.scale : 0.0f, (h >> 16) >= d.thresh16 ? d.scale : 0.0f);
+}
+// FFN sites: hash of the element pair containing element index i (i even)
+template <class D>
+__device__ __forceinline__ unsigned drop_ffn_hash(const D& d, unsigned long long i) {
+    return drop_mix32(((unsigned)d.seed ^ ((unsigned)(i >> 1) * 0x9E3779B1u)) + (unsigned)(d.seed >> 32));
 }
 
 }  // namespace st

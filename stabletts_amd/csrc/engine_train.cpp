@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 using namespace st;
@@ -55,6 +56,7 @@ struct TrainState {
     float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
           *gin, *gsc;
     unsigned *gbits, *dsmax, *qbits;
+    unsigned *drop_rowh, *drop_colh;            // dropout hash tables of the attention site being processed (launch_drop_tables)
     float* qs;                                  // local scales of the attention-input gradients (launch_qkv_grad_scales)
     void* g16w;                                 // d [q | k | v] with per-tensor scales: the dY operand of their weight gradients
     void *g16a, *g16b, *vnat, *vnat_lo, *qT, *kT, *dOT, *xt, *dyt;
@@ -196,6 +198,7 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->tmpC, R * C * 4); want((void**)&ts->tmpF, R * F * 4); want((void**)&ts->gin, R * Mp * 4);
     want(&ts->g16a, R * F * 2); want(&ts->g16b, R * 3 * C * 2); want(&ts->g16w, R * 3 * C * 2);
     want((void**)&ts->qs, 64); want((void**)&ts->qbits, 16);
+    want((void**)&ts->drop_rowh, (N * H * TT + 64) * 4); want((void**)&ts->drop_colh, (size_t)(Tp / 2 + 64) * 4);
     want(&ts->vnat, R * C * 2); want(&ts->vnat_lo, R * C * 2); want((void**)&ts->dsmax, N * H * 4); want(&ts->qT, N * C * Tp * 2); want(&ts->kT, N * C * Tp * 2); want(&ts->dOT, N * C * Tp * 2);
     want((void**)&ts->Dbuf, N * H * TT * 4); want((void**)&ts->Fbuf, N * H * TT * 4); want((void**)&ts->abuf, N * H * TT * 4);
     want((void**)&ts->vmean, N * H * 64 * 4); want((void**)&ts->qmean, N * H * 64 * 4); want((void**)&ts->kmean, N * H * 64 * 4);
@@ -318,6 +321,10 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
             a.q = A.q; a.k = A.k; a.vt = A.vt; a.out = A.attn16; a.kbias = ts->kbias; a.mask_mod = B; a.zeros = e->zeros;
             a.kv_end = ts->kv_end; a.n_full = ts->n_full; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
             a.lse = A.lse; a.drop = make_drop(p_dropout, seed, 2 * i + 1);
+            if (a.drop.thresh16) {
+                HIPCHK(e, launch_drop_tables(a.drop, N * H * T + 64, Tp / 2, ts->drop_rowh, ts->drop_colh, s));
+                a.drop.rowh = ts->drop_rowh; a.drop.colh = ts->drop_colh;
+            }
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
         {   // o = (Wo attn + b) * mask
@@ -392,7 +399,8 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     const int frames = taps * cin;
     // splits: enough blocks for the chip, bounded by the scratch capacities
     const int tiles = ((frames + 255) / 256) * std::max(1, cout16 / 256);
-    int S = std::max(1, std::min(64, (512 + tiles - 1) / tiles));
+    static const int target_blocks = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 512; }();
+    int S = std::max(1, std::min(64, (target_blocks + tiles - 1) / tiles));
     S = (int)std::min<int64_t>(S, (R + 63) / 64);
     while (S > 1 && (size_t)S * frames * cout16 * 4 > ts->partial_cap) --S;
     const int Rs = (int)(((R + S - 1) / S + 63) / 64 * 64);
@@ -504,6 +512,10 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
             a.Dq = ts->Dbuf; a.Fq = ts->Fbuf; a.aq = ts->abuf; a.kbias = ts->kbias; a.mask_mod = B;
             a.kv_end = ts->kv_end; a.dq = ts->dq; a.dk = ts->dk; a.dv = ts->dv; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
             a.drop = make_drop(ts->p_drop, ts->seed, 2 * i + 1); a.zeros = e->zeros;
+            if (a.drop.thresh16) {
+                HIPCHK(e, launch_drop_tables(a.drop, N * H * T + 64, Tp / 2, ts->drop_rowh, ts->drop_colh, s));
+                a.drop.rowh = ts->drop_rowh; a.drop.colh = ts->drop_colh;
+            }
             HIPCHK(e, launch_attn_bwd_dq(e->dt, a, s));
             HIPCHK(e, launch_attn_bwd_dkv(e->dt, a, s));
             // d q, d k are ~1/T of d v: each gets its own power-of-two factor before the rounding to 16 bits (f16's normal

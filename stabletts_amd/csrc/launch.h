@@ -67,9 +67,15 @@ constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 
 // ---------------------------------------------------------------- counter-based dropout (training; shared by forward and backward)
-// keep(seed, idx) = hash(seed, idx) >= thresh (= p * 2^32); kept values are scaled by 1 / (1 - p) like nn.Dropout and
-// SDPA's dropout_p.  thresh == 0: dropout off.
-struct DropCfg { unsigned long long seed; unsigned thresh; float scale; };
+// One 32-bit hash decides TWO neighbouring elements (its low / high 16 bits against thresh16 = p * 2^16); kept values are scaled
+// by 1 / (1 - p) like nn.Dropout and SDPA's dropout_p.  thresh16 == 0: dropout off.
+//   FFN sites (element index i):         h = mix32(((u32)seed ^ (i >> 1) * 0x9E3779B1) + (u32)(seed >> 32)), half = i & 1
+//   attention sites (row, key):          h = pair(rowh[row], colh[key >> 1]), half = key & 1, where the two tables
+//                                        rowh[row] = mix32((u32)seed ^ row * 0x9E3779B1), colh[j] = mix32((u32)(seed >> 32) ^ j * 0x85ebca77)
+//                                        are filled once per attention call (launch_drop_tables): whichever of (row, key) a
+//                                        kernel has on its lanes, the per-element work is one 2-multiply mix of rowh ^ colh
+struct DropCfg { unsigned long long seed; unsigned thresh16; float scale; const unsigned* rowh; const unsigned* colh; };
+hipError_t launch_drop_tables(const DropCfg& d, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh, hipStream_t s);
 
 // ---------------------------------------------------------------- attention
 struct AttnArgs {

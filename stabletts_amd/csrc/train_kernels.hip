@@ -11,12 +11,24 @@ namespace st {
 DropCfg make_drop(float p, unsigned long long seed, int salt) {
     DropCfg d;
     d.seed = seed * 0x100000001B3ull + (unsigned long long)(salt + 1) * 0xD6E8FEB86659FD93ull;
-    if (!(p > 0.f)) { d.thresh = 0; d.scale = 1.0f; return d; }
-    const double t = (double)p * 4294967296.0;
-    d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
-    if (d.thresh == 0) d.thresh = 1;
+    d.rowh = nullptr; d.colh = nullptr;
+    if (!(p > 0.f)) { d.thresh16 = 0; d.scale = 1.0f; return d; }
+    const double t = (double)p * 65536.0 + 0.5;
+    d.thresh16 = t >= 65535.0 ? 65535u : (unsigned)t;
+    if (d.thresh16 == 0) d.thresh16 = 1;
     d.scale = 1.0f / (1.0f - p);
     return d;
+}
+
+__global__ __launch_bounds__(256) void drop_tables_kernel(unsigned long long seed, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) rowh[i] = drop_rowh(seed, (unsigned)i);
+    if (i < n_colpairs) colh[i] = drop_colh(seed, (unsigned)i);
+}
+hipError_t launch_drop_tables(const DropCfg& d, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh, hipStream_t s) {
+    const int n = n_rows > n_colpairs ? n_rows : n_colpairs;
+    hipLaunchKernelGGL(drop_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d.seed, n_rows, n_colpairs, rowh, colh);
+    return hipGetLastError();
 }
 
 __device__ __forceinline__ float silu_grad(float a) {      // d/da [a * sigmoid(a)] = s * (1 + a * (1 - s))
@@ -83,22 +95,27 @@ hipError_t launch_train_ln(int dtype, const TrainLnArgs& a, hipStream_t s) {
 template <class P>
 __global__ __launch_bounds__(256) void silu_drop_kernel(const typename P::elem* a16, typename P::elem* u16, const float* mask,
                                                         int mask_mod, int T, int F, int64_t rows, DropCfg drop) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;       // 8 elements (16 bytes) per thread; F % 8 == 0
     if (i >= rows * F) return;
     const int64_t row = i / F;
     float m = 1.0f;
     if (mask) { const int64_t n = row / T; m = mask[(size_t)(n % mask_mod) * T + (row - n * T)]; }
-    const float4 a = load4_16<P>(a16 + i);
-    const float v0 = silu_f(a.x) * drop_factor(drop, (unsigned)i, (unsigned)(i >> 32)) * m;
-    const float v1 = silu_f(a.y) * drop_factor(drop, (unsigned)i + 1u, (unsigned)(i >> 32)) * m;
-    const float v2 = silu_f(a.z) * drop_factor(drop, (unsigned)i + 2u, (unsigned)(i >> 32)) * m;
-    const float v3 = silu_f(a.w) * drop_factor(drop, (unsigned)i + 3u, (unsigned)(i >> 32)) * m;
-    *(uint2*)(u16 + i) = pack4<P>(v0, v1, v2, v3);
+    const typename P::vec8 a = as_vec8<P>(*(const uint4*)(a16 + i));
+    typename P::vec8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        float2 f = make_float2(1.0f, 1.0f);
+        if (drop.thresh16) f = drop_factors2(drop, drop_ffn_hash(drop, (unsigned long long)(i + e)));
+        o[e] = to16<P>(silu_f((float)a[e]) * f.x * m);
+        o[e + 1] = to16<P>(silu_f((float)a[e + 1]) * f.y * m);
+    }
+    *(uint4*)(u16 + i) = __builtin_bit_cast(uint4, o);
 }
 
 hipError_t launch_silu_drop(int dtype, const void* a16, void* u16, const float* mask, int mask_mod, int T, int F,
                             int64_t rows, DropCfg drop, hipStream_t s) {
-    const int64_t n4 = rows * F / 4;
+    if (F % 8) return hipErrorInvalidValue;
+    const int64_t n4 = rows * F / 8;
     const int grid = (int)((n4 + 255) / 256);
     if (dtype == DT_BF16)
         hipLaunchKernelGGL((silu_drop_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, (const __bf16*)a16, (__bf16*)u16, mask, mask_mod, T, F, rows, drop);
@@ -111,22 +128,29 @@ template <class P>
 __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* dU, const typename P::elem* a16, const float* mask,
                                                        int mask_mod, int T, int F, int64_t rows, DropCfg drop,
                                                        typename P::elem* dA16) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;       // 8 elements per thread; F % 8 == 0
     if (i >= rows * F) return;
     const int64_t row = i / F;
     float m = 1.0f;
     if (mask) { const int64_t n = row / T; m = mask[(size_t)(n % mask_mod) * T + (row - n * T)]; }
-    const float4 a = load4_16<P>(a16 + i);
-    const float4 g = *(const float4*)(dU + i);
-    *(uint2*)(dA16 + i) = pack4<P>(g.x * m * drop_factor(drop, (unsigned)i, (unsigned)(i >> 32)) * silu_grad(a.x),
-                                   g.y * m * drop_factor(drop, (unsigned)i + 1u, (unsigned)(i >> 32)) * silu_grad(a.y),
-                                   g.z * m * drop_factor(drop, (unsigned)i + 2u, (unsigned)(i >> 32)) * silu_grad(a.z),
-                                   g.w * m * drop_factor(drop, (unsigned)i + 3u, (unsigned)(i >> 32)) * silu_grad(a.w));
+    const typename P::vec8 a = as_vec8<P>(*(const uint4*)(a16 + i));
+    const float4 g0 = *(const float4*)(dU + i), g1 = *(const float4*)(dU + i + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    typename P::vec8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        float2 f = make_float2(1.0f, 1.0f);
+        if (drop.thresh16) f = drop_factors2(drop, drop_ffn_hash(drop, (unsigned long long)(i + e)));
+        o[e] = to16<P>(g[e] * m * f.x * silu_grad((float)a[e]));
+        o[e + 1] = to16<P>(g[e + 1] * m * f.y * silu_grad((float)a[e + 1]));
+    }
+    *(uint4*)(dA16 + i) = __builtin_bit_cast(uint4, o);
 }
 
 hipError_t launch_silu_bwd(int dtype, const float* dU, const void* a16, const float* mask, int mask_mod, int T, int F,
                            int64_t rows, DropCfg drop, void* dA16, hipStream_t s) {
-    const int64_t n4 = rows * F / 4;
+    if (F % 8) return hipErrorInvalidValue;
+    const int64_t n4 = rows * F / 8;
     const int grid = (int)((n4 + 255) / 256);
     if (dtype == DT_BF16)
         hipLaunchKernelGGL((silu_bwd_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, dU, (const __bf16*)a16, mask, mask_mod, T, F, rows, drop, (__bf16*)dA16);
@@ -327,7 +351,11 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, int64_t n, 
     for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) take(x[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));        // non-negative floats order like their bits
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // ONE atomic per block (thousands of same-address atomics serialise in the L2: they, not the 65 MB read, set this kernel's time)
+    if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like their bits
 }
 __global__ void grad_scale_kernel(const unsigned* bits, float* sc) {
     const float m = __uint_as_float(*bits);
@@ -342,7 +370,7 @@ __global__ void grad_scale_kernel(const unsigned* bits, float* sc) {
 hipError_t launch_grad_scale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s) {
     hipError_t e = hipMemsetAsync(bits, 0, 4, s);
     if (e != hipSuccess) return e;
-    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, g, n, bits);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, s, bits, sc);
     return hipGetLastError();
@@ -366,7 +394,7 @@ hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float*
                                   unsigned* bits3, float* qs, hipStream_t s) {
     hipError_t e = hipMemsetAsync(bits3, 0, 12, s);
     if (e != hipSuccess) return e;
-    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dq, n, bits3);
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dk, n, bits3 + 1);
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dv, n, bits3 + 2);

@@ -357,15 +357,40 @@ def _mix32(h):
     return h ^ (h >> np.uint64(16))
 
 
-def _drop_factor(seed, salt, p, a, b):
-    s64 = (seed * 0x100000001B3 + (salt + 1) * 0xD6E8FEB86659FD93) % (1 << 64)
-    lo, hi = np.uint64(s64 & 0xFFFFFFFF), np.uint64(s64 >> 32)
-    a = a.astype(np.uint64); b = b.astype(np.uint64)
-    h = _mix32(lo ^ ((a * np.uint64(0x9E3779B1)) & _M))
-    h = _mix32(h ^ hi ^ ((b * np.uint64(0x85ebca77)) & _M))
-    thresh = min(int(p * 4294967296.0), 4294967295)
+def _lowbias32(h):
+    h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x7feb352d)) & _M
+    h = h ^ (h >> np.uint64(15)); h = (h * np.uint64(0x846ca68b)) & _M
+    return h ^ (h >> np.uint64(16))
+
+
+def _seed_words(seed, salt):
+    s64 = (seed * 0x100000001B3 + (salt + 1) * 0xD6E8FEB86659FD93) % (1 << 64)        # make_drop (train_kernels.hip)
+    return np.uint64(s64 & 0xFFFFFFFF), np.uint64(s64 >> 32)
+
+
+def _keep16(h, odd, p):
+    """Low / high 16 bits of a pair hash against thresh16 = round(p * 2^16): kept -> 1 / (1 - p), dropped -> 0 (DropCfg, launch.h)."""
+    t16 = np.uint64(min(max(int(p * 65536.0 + 0.5), 1), 65535))
+    bits = np.where(odd, h >> np.uint64(16), h & np.uint64(0xFFFF))
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
-    return np.where(h >= np.uint64(thresh), scale, np.float32(0.0)).astype(np.float32)
+    return np.where(bits >= t16, scale, np.float32(0.0)).astype(np.float32)
+
+
+def _drop_ffn(seed, salt, p, idx):
+    """FFN site, element index idx: h = mix32(((u32)seed ^ (idx >> 1) * 0x9E3779B1) + (u32)(seed >> 32)), half = idx & 1."""
+    lo, hi = _seed_words(seed, salt)
+    idx = idx.astype(np.uint64)
+    h = _mix32(((lo ^ (((idx >> np.uint64(1)) * np.uint64(0x9E3779B1)) & _M)) + hi) & _M)
+    return _keep16(h, (idx & np.uint64(1)) == 1, p)
+
+
+def _drop_attn(seed, salt, p, row, key):
+    """Attention site (row = (item * H + head) * T + query, key): pair(rowh[row], colh[key >> 1]), half = key & 1."""
+    lo, hi = _seed_words(seed, salt)
+    row = row.astype(np.uint64); key = key.astype(np.uint64)
+    rh = _mix32(lo ^ ((row * np.uint64(0x9E3779B1)) & _M))
+    ch = _mix32(hi ^ (((key >> np.uint64(1)) * np.uint64(0x85ebca77)) & _M))
+    return _keep16(_lowbias32(rh ^ ch), (key & np.uint64(1)) == 1, p)
 
 
 @pytest.mark.parametrize("dt", ["f16"])
@@ -401,9 +426,9 @@ def test_dropout_forward_and_backward_match_oracle_with_same_masks(sd, dt):
     idx = ((n_ * T + t_) * F_ + c_).astype(np.uint64)
     nn, hh, qq, kk = np.meshgrid(np.arange(B), np.arange(H), np.arange(T), np.arange(T), indexing="ij")
     for i in range(6):
-        f = _drop_factor(seed, 2 * i, p, idx & _M, idx >> np.uint64(32))                      # [B][T][F] time-major
+        f = _drop_ffn(seed, 2 * i, p, idx)                                                    # [B][T][F] time-major
         drop["ffn"].append(torch.from_numpy(f).permute(0, 2, 1).contiguous())
-        a = _drop_factor(seed, 2 * i + 1, p, ((nn * H + hh) * T + qq).astype(np.uint64), kk.astype(np.uint64))
+        a = _drop_attn(seed, 2 * i + 1, p, ((nn * H + hh) * T + qq).astype(np.uint64), kk.astype(np.uint64))
         drop["attn"].append(torch.from_numpy(a))
     assert 0.85 < float((drop["ffn"][0] > 0).float().mean()) < 0.95
     pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
