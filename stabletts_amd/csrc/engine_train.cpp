@@ -397,6 +397,27 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     const int64_t R = (int64_t)N * T;
     const int cin = c0 + c1;
     const int frames = taps * cin;
+    static const bool use_tn = [] { const char* v = getenv("ST_WGRAD_TN"); return !(v && atoi(v) == 0); }();
+    if (use_tn && cout16 % 256 == 0 && !(c0 & 63) && !(c1 & 63) && (!c1 || c0 % 256 == 0)) {
+        // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip); K is split over items
+        const int tiles_tn = taps * ((cin + 255) / 256) * (cout16 / 256);
+        int ipb = std::max(1, (int)((int64_t)N * tiles_tn / 512));
+        while ((size_t)((N + ipb - 1) / ipb) * frames * cout16 * 4 > ts->partial_cap && ipb < N) ++ipb;
+        const int S_tn = (N + ipb - 1) / ipb;
+        if ((size_t)S_tn * frames * cout16 * 4 <= ts->partial_cap) {
+            HIPCHK(e, launch_wgrad_tn(e->dt, dy, cout16, x0, c0, x1, c1, taps, N, T, ipb, e->zeros, ts->partial, s));
+            bool need_b = false;
+            for (int k = 0; k < n_outs; ++k) need_b = need_b || outs[k].db;
+            if (need_b) HIPCHK(e, launch_colsum_rows(e->dt, dy, cout16, R, ts->part_b, s));
+            for (int k = 0; k < n_outs; ++k) {
+                const WgradOut& o = outs[k];
+                const float* us = o.unscale ? o.unscale : ts->gsc;
+                if (o.dW) HIPCHK(e, launch_wgrad_reduce(ts->partial, S_tn, cin, cout16, taps, o.dW, o.cin_total, o.ci_off, o.ci_cnt, o.co_start, o.co_cnt, us, s));
+                if (o.db) HIPCHK(e, launch_bias_reduce(ts->part_b, (int)((R + 63) / 64), cout16, o.db, o.co_start, o.co_cnt, us, s));
+            }
+            return ST_OK;
+        }
+    }
     // splits: enough blocks for the chip, bounded by the scratch capacities
     const int tiles = ((frames + 255) / 256) * std::max(1, cout16 / 256);
     static const int target_blocks = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 512; }();
