@@ -398,10 +398,11 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     const int cin = c0 + c1;
     const int frames = taps * cin;
     static const bool use_tn = [] { const char* v = getenv("ST_WGRAD_TN"); return !(v && atoi(v) == 0); }();
+    static const int target_blocks = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 512; }();
     if (use_tn && cout16 % 256 == 0 && !(c0 & 63) && !(c1 & 63) && (!c1 || c0 % 256 == 0)) {
         // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip); K is split over items
         const int tiles_tn = taps * ((cin + 255) / 256) * (cout16 / 256);
-        int ipb = std::max(1, (int)((int64_t)N * tiles_tn / 512));
+        int ipb = std::max(1, (int)((int64_t)N * tiles_tn / target_blocks));
         while ((size_t)((N + ipb - 1) / ipb) * frames * cout16 * 4 > ts->partial_cap && ipb < N) ++ipb;
         const int S_tn = (N + ipb - 1) / ipb;
         if ((size_t)S_tn * frames * cout16 * 4 <= ts->partial_cap) {
@@ -420,7 +421,6 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     }
     // splits: enough blocks for the chip, bounded by the scratch capacities
     const int tiles = ((frames + 255) / 256) * std::max(1, cout16 / 256);
-    static const int target_blocks = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 512; }();
     int S = std::max(1, std::min(64, (target_blocks + tiles - 1) / tiles));
     S = (int)std::min<int64_t>(S, (R + 63) / 64);
     while (S > 1 && (size_t)S * frames * cout16 * 4 > ts->partial_cap) --S;
