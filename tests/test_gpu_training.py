@@ -6,8 +6,12 @@ masks, and a 2-process DDP run.  Run with ``-m gpu``.
 Gates (max |native - ref| / max |ref| per tensor): f16 operands 3e-3, bf16 operands 2e-2 -- except the q / k
 projections of the attention: d loss / d q and d loss / d k subtract two nearly equal terms (dP - D) and, at these
 random-init weights where V and K are almost uncorrelated over the keys, a 5e-4 relative difference in V (the size of
-the 16-bit FORWARD's own deviation from the fp32 reference) moves them by several percent (oracle experiment recorded
-in DESIGN.md).  The backward kernels themselves are checked to operand precision at matched inputs below.
+the 16-bit FORWARD's own deviation from the fp32 reference) moves them by several percent at T = 44 and by tens of
+percent at T = 1000.  For those tensors the gate is the matched-operand chain of test_gradients_at_config5_size: the
+attention backward kernels vs fp64 on the native q, k, v, d attn; RoPE^T + pack + weight-gradient GEMM vs fp64 on the native
+dq, dk, h1; and END TO END against the oracle's autograd evaluated at the native forward's own q, k, v
+(oracle.attention(subst=...)): 4e-3 (f16) at B=4 x T=1000.  (That comparison is what exposed, in round 3, that f16 rounded
+d q / d k to subnormals at the pass-wide gradient scale; they now carry their own power-of-two scales.)
 """
 import math
 import os
@@ -124,9 +128,12 @@ def test_attention_backward_at_matched_inputs(sd, dt):
 
 # ---------------------------------------------------------------- BASELINE config 5 shapes (train.py:78-81 at T = 1000)
 SIZE_B, SIZE_T, SIZE_LENS = 4, 1000, [1000, 873, 655, 512]
-TOL_QK_SIZE = {"f16": 1.0, "bf16": 2.0}      # placeholders until measured on the GPU
-COS_QK_SIZE = {"f16": 0.5, "bf16": 0.2}
-TOL_QK_MATCHED = {"f16": 5e-2, "bf16": 3e-1}  # placeholder until measured
+# q / k projections at T = 1000 (measured on MI355X, f16 / bf16):
+#   end to end vs the fp32 oracle       2.2e-1 / 1.46, cosine 0.992 / 0.83   -- conditioning of d q, d k in the forward's operand rounding
+#   vs the oracle AT the native q, k, v  4.2e-3 / 2.6e-2, cosine 0.999995 / 0.99978  -- the native backward chain itself (the gate)
+TOL_QK_SIZE = {"f16": 4e-1, "bf16": 2.5}
+COS_QK_SIZE = {"f16": 0.98, "bf16": 0.7}
+TOL_QK_MATCHED = {"f16": 1e-2, "bf16": 6e-2}
 
 
 @pytest.fixture(scope="module")
