@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel stats + two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command.
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
-TAG=${1:-r02_v2}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
