@@ -30,7 +30,11 @@
 
 namespace st {
 
-template <int BC, int BF, int WC, int WF, int TAPS>
+// WBUF = 1: ONE weight buffer (the next stage's weights are requested only after every wave has finished the current
+// one: the DMA round trip is exposed inside the block and hidden by a SECOND resident block instead).  Used for the fused
+// q/k/v projection on 256 x 128 tiles: 2 x 16 KB + 32 KB = 64 KB of loop buffers under the 74 KB of its epilogue image, so two
+// blocks share a CU and one block's HBM-bound epilogue runs beside the other's K loop.
+template <int BC, int BF, int WC, int WF, int TAPS, int WBUF = 2>
 struct G2Cfg {
     static constexpr int NW = WC * WF, NT = 64 * NW;
     static constexpr int TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32;
@@ -39,7 +43,7 @@ struct G2Cfg {
     static constexpr int PITCH = BC + 4;                       // fp32 words per staged frame row
     static constexpr int STAGE_BYTES = (NW == 8 ? TF : BF) * PITCH * 4;
     static constexpr int STAGE16_BYTES = BF * (BC * 2 + 16);  // 16-bit [frame][channel] image of the whole tile (EPI_ACT16)
-    static constexpr int LOOP_BYTES = 2 * A_BYTES + 2 * W_BYTES;
+    static constexpr int LOOP_BYTES = 2 * A_BYTES + WBUF * W_BYTES;
     static constexpr int LDS_MAX2 = LOOP_BYTES > STAGE_BYTES ? LOOP_BYTES : STAGE_BYTES;
     static constexpr int LDS_BYTES = LDS_MAX2 > STAGE16_BYTES ? LDS_MAX2 : STAGE16_BYTES;
     static_assert((BC / 8) % NW == 0 && (BF / 8) % NW == 0, "DMA pieces must split evenly over the waves");
@@ -393,11 +397,11 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
     }
 }
 
-template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF>
-__global__ __launch_bounds__(64 * WC * WF, 2)
+template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF, int WBUF = 2>
+__global__ __launch_bounds__(64 * WC * WF, WBUF == 1 ? 4 : 2)          // WBUF = 1 exists to keep two 8-wave blocks on a CU: <= 128 VGPRs
 void conv_gemm2_kernel(const ConvGemmArgs g) {
     using vec8 = typename P::vec8;
-    using K = G2Cfg<BC, BF, WC, WF, TAPS>;
+    using K = G2Cfg<BC, BF, WC, WF, TAPS, WBUF>;
     constexpr int NW = K::NW, FC = K::FC, FF = K::FF, TC = K::TC, TF = K::TF;
     constexpr int A_BYTES = K::A_BYTES, W_BYTES = K::W_BYTES;
 
@@ -541,6 +545,16 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) {
             const bool last = (c == nch - 1) && (j == TAPS - 1);
+            if constexpr (WBUF == 1) {
+                if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
+                compute(c & 1, 0, j);
+                __syncthreads();                // every wave is done with the one weight buffer ...
+                if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, 0); else issueW(c, j + 1, 0); }
+                ST_DMA_WAIT(0);                 // ... its refill (and the next activation chunk) has landed
+                __syncthreads();
+                ++it;
+                continue;
+            }
             if ((j == 0) && (c + 1 < nch)) issueA(c + 1, (c + 1) & 1);
             if (!last) { if (j == TAPS - 1) issueW(c + 1, 0, (it + 1) & 1); else issueW(c, j + 1, (it + 1) & 1); }
 #if ST_STAGE_TIMING
@@ -791,9 +805,9 @@ static hipError_t launch_g3(const ConvGemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF>
+template <class P, int TAPS, int EPI, int BC, int BF, int WC, int WF, int WBUF = 2>
 static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
-    using K = G2Cfg<BC, BF, WC, WF, TAPS>;
+    using K = G2Cfg<BC, BF, WC, WF, TAPS, WBUF>;
     constexpr int qkv_lds = (EPI == EPI_QKV) ? g2_qkv_lds_bytes<BC, BF>() : 0;
     constexpr int LDS = K::LDS_BYTES > qkv_lds ? K::LDS_BYTES : qkv_lds;
     // the >64 KB dynamic-LDS opt-in is per device: remember it per device id (engines may live on several GPUs)
@@ -802,7 +816,7 @@ static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     bool& attr_done = attr_done_dev[dev_];
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF, WBUF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
@@ -819,7 +833,7 @@ static hipError_t launch_g2(const ConvGemmArgs& a, hipStream_t s) {
     const int total = b.n_items * b.tiles_f * b.tiles_c * (a.ksplit > 1 ? a.ksplit : 1);
     const int grid = ((total + 7) / 8) * 8;
     if (EPI == EPI_QKV && (a.cout != 3 * BC || a.n_heads * 64 != BC || !a.q || !a.k || !a.vt)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF>), dim3(grid), dim3(K::NT), LDS, s, b);
+    hipLaunchKernelGGL((conv_gemm2_kernel<P, TAPS, EPI, BC, BF, WC, WF, WBUF>), dim3(grid), dim3(K::NT), LDS, s, b);
     return hipGetLastError();
 }
 

@@ -121,7 +121,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         }
     }
     int cfg;
-    if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = (e->phased && taps == 3) ? G2_PHASED : G2_BIG;
+    if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = (e->phased && taps == 3) ? G2_PHASED : (epi == EPI_QKV && e->qkv_rc1) ? G2_RC1 : G2_BIG;
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
     else if (taps == 3 && a.c0 + a.c1 >= 512 && a.c2 == 0) cfg = G2_K3PIPE;
     else cfg = G2_T128;
@@ -788,7 +788,8 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     e->kind = kind; e->n_vocab = n_vocab;
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
-    if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);     // 0: compute every padded frame tile (A/B runs)
+    if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);
+    if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)
     if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
         if (atoi(v) == 0) {                               // key-split attention): results independent of the batch composition
             e->splitk_target = 0; e->small_tiles = 0; e->attn_small_blocks = 0;

@@ -93,6 +93,7 @@ struct st_engine {
     // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     int big_min_blocks = 192;
+    int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
     int phased = 1;                     // k = 3 convs on 256-wide tiles use the phased K loop (conv_gemm_phased.h); ST_PHASED=0: A/B runs
     int splitk_max = kSplitKMax, splitk_min_stages = 4;

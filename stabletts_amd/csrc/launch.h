@@ -57,7 +57,8 @@ struct ConvGemmArgs {
 enum { G2_T128 = 0, G2_RC = 1, G2_K3PIPE = 2,   // K3PIPE: k=3 only, three weight buffers, counted vmcnt
        G2_BIG = 3,                               // 256 x 256 tile, 8 waves of 128 x 64 (cout % 256 == 0)
        G2_T64 = 4, G2_RC64 = 5,                  // 64-frame versions of T128 / RC (QKV only) for small, latency-bound grids
-       G2_PHASED = 6 };                          // BIG tile, phased K loop (conv_gemm_phased.h)
+       G2_PHASED = 6,                            // BIG tile, phased K loop (conv_gemm_phased.h)
+       G2_RC1 = 7 };                             // RC tile with ONE weight buffer: 74 KB of LDS -> two resident blocks (fused q/k/v projection)
 hipError_t launch_conv_gemm2_bf16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 hipError_t launch_conv_gemm2_f16(int cfg, int taps, int epi, const ConvGemmArgs& a, hipStream_t s);
 // epilogue `epi` (EPI_F32 / EPI_RESGATE, cout == 256) of the sum of the S partial planes a split-K launch left in `part`
