@@ -57,6 +57,7 @@ struct TrainState {
           *gin, *gsc;
     unsigned *gbits, *dsmax, *qbits;
     unsigned *drop_rowh, *drop_colh;            // dropout hash tables of the attention site being processed (launch_drop_tables)
+    float* skip_sc;                             // {scale, 1 / scale} each long-skip gradient was written at
     float* qs;                                  // local scales of the attention-input gradients (launch_qkv_grad_scales)
     void* g16w;                                 // d [q | k | v] with per-tensor scales: the dY operand of their weight gradients
     void *g16a, *g16b, *vnat, *vnat_lo, *qT, *kT, *dOT, *xt, *dyt;
@@ -214,7 +215,7 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->dada, (size_t)L * N * 6 * C * 4); want((void**)&ts->dfilm, (size_t)L * N * 2 * C * 4);
     want((void**)&ts->dtau, N * C * 4); want((void**)&ts->dth, N * F * 4); want((void**)&ts->demb, N * C * 4);
     want((void**)&ts->dcvec, N * G * 4);
-    want((void**)&ts->gsc, 16); want((void**)&ts->gbits, 16);
+    want((void**)&ts->gsc, 16); want((void**)&ts->gbits, 16); want((void**)&ts->skip_sc, 64);
     if (off > ts->ws_cap) {
         if (ts->ws) { HIPCHK(e, hipDeviceSynchronize()); HIPCHK(e, hipFree(ts->ws)); ts->ws = nullptr; ts->ws_cap = 0; }
         HIPCHK(e, hipMalloc((void**)&ts->ws, off));
@@ -492,6 +493,17 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         const std::string b = e->blk(i);
         const float* ada_i = ts->ada + (size_t)i * N * 6 * C;
         float* dada_i = ts->dada + (size_t)i * N * 6 * C;
+        // The gradient's magnitude changes by orders of magnitude from block to block (FiLM's gamma multiplies the whole residual
+        // stream: ~0.05 at initialisation): re-centre the pass-wide power-of-two scale on the running gradient whenever its
+        // maximum has left [2^4, 2^12), so that every 16-bit operand derived from it inside this block sits in f16's normal range.
+        // dX, which lives in scaled units, is multiplied by the same factor (the kernel returns at once when it is 1); every fp32
+        // result is un-scaled by the pair current at the time it is written; a long-skip gradient remembers the scale it was
+        // written at (skip_sc) and is converted when it is added.
+        if (i < L - 1) {
+            HIPCHK(e, launch_grad_rescale(ts->dX, R * C, ts->gbits, ts->gsc, s));
+            HIPCHK(e, launch_scale_by(ts->dX, R * C, ts->gsc, s));
+        }
+        if (cap) capture(e, "g.scale_" + std::to_string(i), ts->gsc, 2, false, s);      // the scale block i's captured tensors carry
         // ---- x3 = x2 + g_mlp * f
         HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.f32b, ada_i + 5 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
         { const int off[1] = {5 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 1, dada_i, 6 * C, off, 0, ts->gsc, s)); }
@@ -571,12 +583,13 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
             WgradOut o = {G(ts, n + ".weight"), 2 * C, 0, 2 * C, 0, C, G(ts, n + ".bias")};
             if ((rc = wgrad(e, ts, ts->L[i - 1].x3_16, C, skip16, C, ts->g16b, C, K, &o, 1, s))) return rc;
             ConvGemmArgs a = cargs(e, ts->lscTb[j], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->dskip[src];
+            HIPCHK(e, launch_copy_scalars(ts->skip_sc + 2 * src, ts->gsc, 2, s));
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
             a = cargs(e, ts->lscTa[j], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->dX;
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
         }
         // x3_{i-1} (or the in_proj output) is also a long-skip source of a later block: add that gradient
-        if (i < L / 2) HIPCHK(e, launch_add_inplace(ts->dX, ts->dskip[i], R * C, s));
+        if (i < L / 2) HIPCHK(e, launch_add_rescaled(ts->dX, ts->dskip[i], R * C, ts->gsc, ts->skip_sc + 2 * i, s));
         if (cap) capture(e, "g.xin_" + std::to_string(i), ts->dX, R * C, false, s);
     }
     // ---- in_proj: h0 = Wx x + Wc cond + b

@@ -401,6 +401,42 @@ hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float*
     hipLaunchKernelGGL(qkv_scales_kernel, dim3(1), dim3(1), 0, s, bits3, gsc, qs);
     return hipGetLastError();
 }
+__global__ void grad_rescale_kernel(const unsigned* bits, float* sc) {
+    const float m = __uint_as_float(*bits);
+    float f = 1.0f;
+    if (m > 0.f && (m < 16.0f || m >= 4096.0f)) {
+        int ex = 8 - (int)floorf(log2f(m));
+        const int cur = (int)floorf(log2f(sc[0]));
+        if (cur + ex > 100) ex = 100 - cur;              // keep the total scale a finite fp32 power of two
+        if (cur + ex < -100) ex = -100 - cur;
+        f = exp2f((float)ex);
+    }
+    sc[2] = f;
+    sc[0] *= f; sc[1] = 1.0f / sc[0];
+}
+hipError_t launch_grad_rescale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(bits, 0, 4, s);
+    if (e != hipSuccess) return e;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, g, n, bits);
+    hipLaunchKernelGGL(grad_rescale_kernel, dim3(1), dim3(1), 0, s, bits, sc);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void scale_by_kernel(float* a, int64_t n4, const float* sc) {
+    const float f = sc[2];
+    if (f == 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = *(float4*)(a + 4 * i);
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        *(float4*)(a + 4 * i) = v;
+    }
+}
+hipError_t launch_scale_by(float* a, int64_t n, const float* sc, hipStream_t s) {
+    if (n & 3) return hipErrorInvalidValue;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid), dim3(256), 0, s, a, n / 4, sc);
+    return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float* a, int64_t n, const float* sc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] *= sc[1];
@@ -417,6 +453,24 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* a, const float*
     const float4 y = *(const float4*)(b + i);
     x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
     *(float4*)(a + i) = x;
+}
+__global__ __launch_bounds__(256) void add_rescaled_kernel(float* a, const float* b, int64_t n, const float* sc, const float* sc_b) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float f = sc[0] / sc_b[0];
+    float4 x = *(float4*)(a + i);
+    const float4 y = *(const float4*)(b + i);
+    x.x += y.x * f; x.y += y.y * f; x.z += y.z * f; x.w += y.w * f;
+    *(float4*)(a + i) = x;
+}
+hipError_t launch_add_rescaled(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, hipStream_t s) {
+    hipLaunchKernelGGL(add_rescaled_kernel, dim3((int)((n / 4 + 255) / 256)), dim3(256), 0, s, a, b, n, sc, sc_b);
+    return hipGetLastError();
+}
+__global__ void copy_scalars_kernel(float* dst, const float* src, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
+hipError_t launch_copy_scalars(float* dst, const float* src, int n, hipStream_t s) {
+    hipLaunchKernelGGL(copy_scalars_kernel, dim3(1), dim3(64), 0, s, dst, src, n);
+    return hipGetLastError();
 }
 hipError_t launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(add_inplace_kernel, dim3((int)((n / 4 + 255) / 256)), dim3(256), 0, s, a, b, n);

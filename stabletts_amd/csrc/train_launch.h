@@ -45,6 +45,11 @@ hipError_t launch_reduce_parts(const float* part, int n_items, int chunks, int K
 // Kernels that take `scale` multiply by sc[0]; kernels that take `unscale` multiply by sc[1] (nullptr: 1).
 hipError_t launch_grad_scale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s);
 hipError_t launch_unscale_inplace(float* a, int64_t n, const float* sc, hipStream_t s);
+// Block-boundary re-centring of the pass-wide scale: if max |g| (g = the running fp32 gradient, in scaled units) has left
+// [2^4, 2^12), sc[2] = the power of two that brings it back to ~2^8 (else 1), and sc[0] *= sc[2], sc[1] = 1 / sc[0].
+// launch_scale_by then multiplies a tensor that lives in scaled units by sc[2] (returns at once when it is 1).
+hipError_t launch_grad_rescale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s);
+hipError_t launch_scale_by(float* a, int64_t n, const float* sc, hipStream_t s);
 
 // x_out = x_in + gate * branch:   d branch16 = dX * gate * mask ; part[.][0] = sum_t dX * branch
 hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, const float* gate, int gate_stride,
@@ -65,6 +70,9 @@ hipError_t launch_silu_bwd(int dtype, const float* dU, const void* a16, const fl
 hipError_t launch_cast16(int dtype, const float* x, const float* mask, int mask_mod, int T, int C, int64_t rows,
                          const float* scale, void* y16, hipStream_t s);
 hipError_t launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t s);
+// a += b * sc[0] / sc_b[0]: b was written when the pass-wide scale was sc_b[0], a lives at the current scale sc[0] (both powers of two)
+hipError_t launch_add_rescaled(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, hipStream_t s);
+hipError_t launch_copy_scalars(float* dst, const float* src, int n, hipStream_t s);
 
 // ---------------------------------------------------------------- weight gradient as a forward GEMM
 // dW[co][j][ci] = sum_{n,t} dY[n][t][co] * X[n][t + j - taps/2][ci].  With K-contiguous transposed copies

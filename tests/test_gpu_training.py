@@ -102,10 +102,10 @@ def test_attention_backward_at_matched_inputs(sd, dt):
         Tp = (T + 63) // 64 * 64
         tt = np.arange(Tp)
         pos = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)
-        scale = float(eng.debug_fetch("g.scale")[0])
         m = inp["mask"][:, 0].double().numpy()
         bias = (1 - m)[:, None, None, :] * (-1e30)
         for i in (5, 2):
+            scale = float(eng.debug_fetch(f"g.scale_{i}")[0])      # the pass-wide power-of-two scale is re-centred block by block
             q = eng.debug_fetch(f"t{i}.q").reshape(B, 4, T, 64).astype(np.float64)        # q_s = q_r * log2(e) / 8
             k = eng.debug_fetch(f"t{i}.k").reshape(B, 4, T, 64).astype(np.float64)
             v = eng.debug_fetch(f"t{i}.vt").reshape(B, 4, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)
@@ -218,10 +218,10 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
         Tp = (T + 63) // 64 * 64
         tt = np.arange(Tp)
         pos = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)
-        scale = float(eng.debug_fetch("g.scale")[0])
         m = inp["mask"][:, 0].double().numpy()
         bias = (1 - m)[:, None, None, :] * (-1e30)
         for i in (5, 0):
+            scale = float(eng.debug_fetch(f"g.scale_{i}")[0])      # the pass-wide power-of-two scale is re-centred block by block
             q = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64).astype(np.float64)
             k = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64).astype(np.float64)
             v = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)

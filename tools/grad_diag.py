@@ -39,8 +39,8 @@ def main():
     torch.cuda.synchronize()
     H, Tp = 4, (T + 63) // 64 * 64
     tt = np.arange(Tp); pos = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)
-    scale = float(eng.debug_fetch("g.scale")[0])
-    print(f"dtype {dt} B={B} T={T} loss {float(loss.detach()):.6f} gradient scale {scale:g}")
+    print(f"dtype {dt} B={B} T={T} loss {float(loss.detach()):.6f} gradient scale per block " +
+          ", ".join(f"{float(eng.debug_fetch(f'g.scale_{i}')[0]):g}" for i in range(5, -1, -1)))
     subst = []
     for i in range(6):
         qn = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64) * (8.0 / math.log2(math.e))
@@ -62,6 +62,7 @@ def main():
     l2.backward()
     params = dict(dec.estimator.named_parameters())
     for i in range(5, -1, -1):
+        scale = float(eng.debug_fetch(f"g.scale_{i}")[0])
         da = eng.debug_fetch(f"g.dattn_{i}").reshape(B, T, H * 64) / scale                      # time-major
         ra = keep[(i, "attn")].grad.permute(0, 2, 1).numpy()
         row = [f"block {i}: d attn {rel(da, ra):.2e} (max |ref| {np.abs(ra).max():.2e}, scaled max {np.abs(ra).max() * scale:.2e}, "
