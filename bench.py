@@ -446,7 +446,7 @@ def main():
                                          "into a launch's event-bracketed duration"},
             "whole_solve_tflops": falg * B_PER_GPU * T_batch / (elapsed / args.steps) / 1e12 * world,
             "solve_parts": int(os.environ.get("ST_SPLIT", "-1")),
-            "solve_parts_note": "-1 = library default: batches >= 24000 (CFG-doubled) frames run as two half-batch launch sequences on two streams",
+            "solve_parts_note": "-1 = library default: batches >= 24000 (CFG-doubled) frames run as two part-batch launch sequences on two streams, >= 48000 with B >= 32 as four",
             "whole_solve_hbm": (lambda b: None if b is None else {
                 "bytes_per_solve_pmc": b, "achieved": b / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS})(pmc_solve_bytes() if N_STEPS == 10 else None),

@@ -1047,8 +1047,8 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     const int stages = solver == ST_SOLVER_EULER ? 1 : (solver == ST_SOLVER_MIDPOINT ? 2 : 4);
     const int n_t = adaptive ? 1 : n_steps * stages;
 
-    // Utterances are independent ODE solves.  A large fixed-grid batch is solved as TWO parts (utterances
-    // [0, B/2) and [B/2, B)) on two streams: every kernel of this path alternates an MFMA-bound K loop with an
+    // Utterances are independent ODE solves.  A large fixed-grid batch is solved as TWO (from B = 32 at T = 1000: FOUR) parts
+    // (contiguous utterance ranges) on as many streams: every kernel of this path alternates an MFMA-bound K loop with an
     // HBM-bound epilogue, and with one launch at a time all CUs sit in the same phase (1 block per CU, lock step).
     // Two half-size launch sequences, started one evaluation apart, put different kernels / phases on the chip at
     // the same time, so the matrix pipes of one part's blocks run under the other part's epilogues.  Results are
@@ -1060,6 +1060,9 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         const int want = sv ? atoi(sv) : kDefaultSplit;
         const int64_t frames = (int64_t)(use_cfg ? 2 : 1) * B * T;
         if (!adaptive && !e->capture && B >= 2 && (want >= 2 || (want != 0 && want != 1 && frames >= 24000 && B >= 8))) nparts = 2;
+        // four parts from 48 000 CFG-doubled frames on (B >= 32 at T = 1000): 25.5 -> 24.8 ms at the headline size, interleaved A/B
+        // (profiles/r03_ab_solve_parts.txt); six or eight parts are much slower (31 / 29.5 ms: 40-block launches from 6-8 queues)
+        if (!adaptive && !e->capture && want != 0 && want != 1 && want != 2 && frames >= 48000 && B >= 32) nparts = 4;
         if (want > 2 && B >= want) nparts = std::min(want, kMaxParts);
         if (want == 1 || want == 0) nparts = 1;
     }
