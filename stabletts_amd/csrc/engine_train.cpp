@@ -49,6 +49,7 @@ struct TrainState {
     bool packed = false;                       // dgrad weights match the current parameters
     // saved tensors
     void *mu16, *x16, *x16lo, *a1, *p1, *a2, *p2, *cond16, *cond16lo, *h0_16, *x3lo;
+    float *ada_pre, *dada_pre;                  // gin != hidden: output of adaLN_modulation.0 per block [L][N][C], and its gradient [N][C]
     float *maskbuf, *kbias, *cvec, *tvals, *emb, *th_pre, *tau, *film, *ada, *cpart, *h0, *v32;
     int *n_full, *kv_end;
     std::vector<LayerAct> L;
@@ -180,6 +181,7 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->maskbuf, R * 4); want((void**)&ts->kbias, N * Tp * 4);
     want((void**)&ts->n_full, N * 4); want((void**)&ts->kv_end, N * 4);
     want((void**)&ts->cvec, N * G * 4); want((void**)&ts->tvals, N * 4);
+    want((void**)&ts->ada_pre, (size_t)L * N * C * 4); want((void**)&ts->dada_pre, N * C * 4);
     want((void**)&ts->emb, N * C * 4); want((void**)&ts->th_pre, N * F * 4); want((void**)&ts->tau, N * C * 4);
     want((void**)&ts->film, (size_t)L * N * 2 * C * 4); want((void**)&ts->ada, (size_t)L * N * 6 * C * 4);
     want((void**)&ts->cpart, R * C * 4); want((void**)&ts->h0, R * C * 4); want((void**)&ts->v32, R * Mp * 4);
@@ -243,7 +245,6 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
     int rc = check_ready(e, B, T); if (rc) return rc;
     if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is not a CFM decoder (st_create)");
     if (!t || !x || !mu || !mask || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
-    if (e->G != e->C) return e->fail(ST_ERR_UNSUPPORTED, "training path is built for gin_channels == hidden_channels");
     if (!(p_dropout >= 0.f && p_dropout < 1.f)) return e->fail(ST_ERR_INVALID, "p_dropout must be in [0, 1)");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
@@ -271,7 +272,14 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
         HIPCHK(e, launch_linear(ts->tau, B, C, P(e, pf + "weight"), P(e, pf + "bias"), 2 * C, ts->film + (size_t)i * N * 2 * C, 0, 0, s));
         const std::string pa = e->blk(i) + "adaLN_modulation.2.";
-        HIPCHK(e, launch_linear(ts->cvec, N, C, P(e, pa + "weight"), P(e, pa + "bias"), 6 * C, ts->ada + (size_t)i * N * 6 * C, 1, 0, s));
+        const float* ain = ts->cvec;       // adaLN_modulation = [Linear(gin, hidden) if gin != hidden else Identity, SiLU, Linear(hidden, 6 hidden)]
+        if (e->G != C) {                   // (diffusion_transformer.py:92-96)
+            const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
+            float* pre = ts->ada_pre + (size_t)i * N * C;
+            HIPCHK(e, launch_linear(ts->cvec, N, e->G, P(e, p0 + "weight"), P(e, p0 + "bias"), C, pre, 0, 0, s));
+            ain = pre;
+        }
+        HIPCHK(e, launch_linear(ain, N, C, P(e, pa + "weight"), P(e, pa + "bias"), 6 * C, ts->ada + (size_t)i * N * 6 * C, 1, 0, s));
     }
     const DropCfg nodrop = make_drop(0.f, 0, 0);
     // cond prenet (estimator.py:83-89,118): pre-activations kept for SiLU'
@@ -630,15 +638,26 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         }
     }
     // ---- per-item vectors: adaLN (-> d c), FiLM (-> d tau), time MLP
-    HIPCHK(e, hipMemsetAsync(ts->dcvec, 0, (size_t)N * C * 4, s));
+    HIPCHK(e, hipMemsetAsync(ts->dcvec, 0, (size_t)N * e->G * 4, s));
     HIPCHK(e, hipMemsetAsync(ts->dtau, 0, (size_t)N * C * 4, s));
     for (int i = 0; i < L; ++i) {
         const std::string pa = e->blk(i) + "adaLN_modulation.2.";
         float* gw = G(ts, pa + "weight"); float* gb = G(ts, pa + "bias");
         HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)6 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)6 * C * 4, s));
         const float* dout = ts->dada + (size_t)i * N * 6 * C;
-        HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, s));
-        HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, 1, s));
+        if (e->G == C) {
+            HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, s));
+            HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, 1, s));
+        } else {        // through SiLU into adaLN_modulation.0, then into c
+            const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
+            const float* pre = ts->ada_pre + (size_t)i * N * C;
+            float* g0w = G(ts, p0 + "weight"); float* g0b = G(ts, p0 + "bias");
+            HIPCHK(e, hipMemsetAsync(g0w, 0, (size_t)C * e->G * 4, s)); HIPCHK(e, hipMemsetAsync(g0b, 0, (size_t)C * 4, s));
+            HIPCHK(e, launch_linear_bwd_w(pre, dout, N, C, 6 * C, 1, gw, gb, s));
+            HIPCHK(e, launch_linear_bwd_in(pre, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dada_pre, 0, s));
+            HIPCHK(e, launch_linear_bwd_w(ts->cvec, ts->dada_pre, N, e->G, C, 0, g0w, g0b, s));
+            HIPCHK(e, launch_linear_bwd_in(ts->cvec, ts->dada_pre, P(e, p0 + "weight"), N, e->G, C, 0, ts->dcvec, 1, s));
+        }
         const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
         gw = G(ts, pf + "weight"); gb = G(ts, pf + "bias");
         HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)2 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)2 * C * 4, s));
@@ -649,7 +668,7 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
     HIPCHK(e, launch_linear_bwd_w(ts->th_pre, ts->dtau, N, F, C, 1, G(ts, "time_mlp.layer.2.weight"), G(ts, "time_mlp.layer.2.bias"), s));
     HIPCHK(e, launch_linear_bwd_in(ts->th_pre, ts->dtau, P(e, "time_mlp.layer.2.weight"), N, F, C, 1, ts->dth, 0, s));
     HIPCHK(e, launch_linear_bwd_w(ts->emb, ts->dth, N, C, F, 0, G(ts, "time_mlp.layer.0.weight"), G(ts, "time_mlp.layer.0.bias"), s));
-    if (grad_c) HIPCHK(e, hipMemcpyAsync(grad_c, ts->dcvec, (size_t)N * C * 4, hipMemcpyDeviceToDevice, s));
+    if (grad_c) HIPCHK(e, hipMemcpyAsync(grad_c, ts->dcvec, (size_t)N * e->G * 4, hipMemcpyDeviceToDevice, s));
     return ST_OK;
 }
 

@@ -275,6 +275,47 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
         eng.debug_capture(False)
 
 
+@pytest.mark.parametrize("dt", ["f16"])
+def test_gin_channels_not_equal_hidden(dt):
+    """gin_channels != hidden_channels adds a Linear(gin, hidden) in front of every block's adaLN modulation
+    (models/diffusion_transformer.py:92-96): one evaluation and every gradient -- the extra linears' and d loss / d c through
+    them included -- against the oracle's autograd."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    cfg = oracle.DecoderConfig(gin_channels=128)
+    sdg = oracle.make_state_dict(4242, cfg)
+    assert "blocks.0.block.adaLN_modulation.0.weight" in sdg
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 128, operand_dtype=dt)
+    dec.estimator.load_state_dict(sdg)
+    dec = dec.cuda().eval()
+    B, T, lengths = 2, 52, [52, 37]
+    inp = make_inputs(B, T, seed=91, lengths=lengths, gin=128)
+    x1 = make_inputs(B, T, seed=92, gin=128)["z"]
+    g0 = torch.Generator().manual_seed(23)
+    t_rand = torch.rand(B, 1, 1, generator=g0); z = torch.randn(B, 128, T, generator=g0)
+    with torch.no_grad():
+        tt = torch.tensor(0.37)
+        ref = oracle.decoder_forward(sdg, tt, inp["z"], inp["mask"], inp["mu"], inp["c"])
+        out = dec.estimator(tt.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+    assert _rel(out.numpy(), ref.numpy()) <= 1e-3
+    c = inp["c"].cuda().requires_grad_(True)
+    loss, _ = dec.compute_loss(x1.cuda(), inp["mask"].cuda(), inp["mu"].cuda(), c, t_rand=t_rand.cuda(), z=z.cuda())
+    loss.backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in sdg.items()}
+    cr = inp["c"].clone().requires_grad_(True)
+    lref, _ = oracle.compute_loss(pr, x1, inp["mask"], inp["mu"], cr, t_rand, z)
+    lref.backward()
+    assert abs(float(loss.detach()) - float(lref.detach())) <= 5e-4 * float(lref.detach())
+    params = dict(dec.estimator.named_parameters())
+    assert set(params) == set(pr)
+    worst = {n: _rel(params[n].grad.cpu().numpy(), pr[n].grad.numpy()) for n in params}
+    # (q / k projections: conditioning-limited end to end at random init, gated by the matched-operand chain of the size test)
+    bad = {k: v for k, v in worst.items() if v > (2e-1 if _is_qk(k) else TOL[dt])}
+    print(f"[gin=128 {dt}] worst non-q/k {max(v for k, v in worst.items() if not _is_qk(k)):.2e}; adaLN.0 "
+          f"{max(v for k, v in worst.items() if 'adaLN_modulation.0' in k):.2e}; d c {_rel(c.grad.cpu().numpy(), cr.grad.numpy()):.2e}")
+    assert not bad, bad
+    assert _rel(c.grad.cpu().numpy(), cr.grad.numpy()) <= TOL[dt]
+
+
 def test_backward_of_replaced_activations_fails_loudly(sd):
     """The engine keeps the activations of ONE grad-enabled forward: a backward whose activations were
     replaced by a later forward must raise (autograd Function) / return ST_ERR_STATE (C ABI) before any memory is
