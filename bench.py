@@ -156,8 +156,8 @@ CLASS_KERNEL = {
     "ffn_conv2": "conv_gemm_phased3_kernel<st::Op{DT}, 2, false>",
     "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
     "attention": "attention_kernel<st::Op{DT}, false>",
-    "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 256, 2, 4>",
-    "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4>",
+    "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 128, 4, 2, 1>",
+    "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4, 2>",
 }
 
 
