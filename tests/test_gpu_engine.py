@@ -196,3 +196,29 @@ def test_bench_self_launches_its_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["dtype"] == "f16"
     assert j["config"]["global_batch"] == 64 and j["value"] > 0 and j["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_ragged_tile_skipping_and_qkv_two_block_tiles_are_bitwise_neutral(sd, cfg_params, monkeypatch, dtype):
+    """Round-3 launch-level changes must not change a single bit of the result:
+      * ST_RAGGED_SKIP (default on): frame tiles past an utterance's last needed frame (last valid + 4, the reach of the
+        reference's pad leak) are not computed -- valid frames, and the padded frames (= z), must equal the run that computes
+        every tile;
+      * ST_QKV_RC1 (default on): the fused q/k/v projection on 256 x 128 tiles with one weight buffer (two blocks per CU)
+        accumulates every output element over the same k order as the 256 x 256 tile.
+    Ragged batch at T = 1000 with lengths that leave one, two and three whole tiles unused, CFG on, 3 Euler steps."""
+    kw = _kw(cfg_params, 3.0)
+    lengths = [1000, 997, 760, 759, 508, 505, 300, 254, 251, 1, 640, 900]
+    inp = make_inputs(len(lengths), 1000, seed=95, lengths=lengths)
+    base = _fresh(sd, monkeypatch, dtype, ST_BIG_MIN_BLOCKS="1")
+    ref = _solve(base, inp, 3, "euler", kw)
+    pad = ~inp["mask"].bool().expand_as(ref)
+    assert torch.equal(ref[pad], inp["z"][pad])
+    for env in (dict(ST_RAGGED_SKIP="0"), dict(ST_QKV_RC1="0"), dict(ST_RAGGED_SKIP="0", ST_QKV_RC1="0")):
+        other = _fresh(sd, monkeypatch, dtype, ST_BIG_MIN_BLOCKS="1", **env)
+        out = _solve(other, inp, 3, "euler", kw)
+        assert torch.equal(out, ref), env
+    # ... and a second, differently shaped solve on the same engine (the arena is re-laid-out and zeroed), then the first again
+    inp2 = make_inputs(3, 700, seed=96, lengths=[700, 333, 90])
+    _solve(base, inp2, 2, "euler", kw)
+    assert torch.equal(_solve(base, inp, 3, "euler", kw), ref)
