@@ -80,11 +80,14 @@ __device__ __forceinline__ void store_acc_rows(float* dst_row, const f32x16_t (&
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ dQ
-template <class P, bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+// PASS 1: only the first pass over the keys (D', F, the dS bound -> Dq / Fq / aq / alphaq and the per-(item, head) maximum);
+// no dQ accumulators, no K^T tiles: 128 VGPRs, two 8-wave blocks per CU.  PASS 2: only the second pass (dS, dQ), with D', F and
+// the column scale read back.  (One kernel doing both passes ran the cheap first pass at the second pass's 2 waves per SIMD.)
+template <class P, bool DROP, int PASS>
+__global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
     constexpr int NW = 8, QB = 32 * NW;
     using vec8 = typename P::vec8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * kTile];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(PASS == 1 ? 6 : 8) * kTile];
     unsigned char* Ks = smem;                 // K natural, 2 buffers
     unsigned char* Vs = smem + 2 * kTile;     // V' natural (hi)
     unsigned char* VLs = smem + 4 * kTile;    // V' natural (lo)
@@ -112,10 +115,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         // Ragged batch: every query of this tile lies past the item's last valid frame.  d attn is exactly 0 there (the
         // out-projection's output is multiplied by the mask, diffusion_transformer.py:111), so dq = 0, D' = 0: no key loop.
         if (qok) {
-            float* dst = a.dq + ((size_t)nh * T + query) * 64 + hi * 32;
+            if constexpr (PASS == 2) {
+                float* dst = a.dq + ((size_t)nh * T + query) * 64 + hi * 32;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *(float4*)(dst + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hi == 0) { a.Dq[(size_t)nh * T + query] = 0.f; a.Fq[(size_t)nh * T + query] = 1.f; a.aq[(size_t)nh * T + query] = 0.f; }
+                for (int i = 0; i < 8; ++i) *(float4*)(dst + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (hi == 0) {
+                a.Dq[(size_t)nh * T + query] = 0.f; a.Fq[(size_t)nh * T + query] = 1.f; a.aq[(size_t)nh * T + query] = 0.f;
+                a.alphaq[(size_t)nh * T + query] = 1.f;
+            }
         }
         return;
     }
@@ -153,11 +160,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
     const unsigned drop_rh = DROP ? a.drop.rowh[(size_t)nh * T + (qok ? query : T - 1)] : 0u;
 
     const int ntiles = (kvend + 63) >> 6;
+    auto sgpr_ptr = [](const unsigned char* p) {
+        const uintptr_t v = (uintptr_t)p;
+        return (const unsigned char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+    };
     auto issue = [&](int kt, int buf) {     // 8 pieces per tile, one per wave
+        if constexpr (PASS == 1) {
+            // SGPR base + one 32-bit per-lane offset for the three tiles (128 VGPRs); rows >= T are clamped to row T-1, a
+            // valid row whose probability the key bias sends to 0 (those tiles are never inside the bias-free leading run)
+            const int row = wave * 8 + (lane >> 3);
+            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned voff = (unsigned)(min(kt * 64 + row, T - 1) * 128 + seg * 16);
+            glds16s(sgpr_ptr(kbase), voff, Ks + buf * kTile + wave * 1024);
+            glds16s(sgpr_ptr(vbase), voff, Vs + buf * kTile + wave * 1024);
+            glds16s(sgpr_ptr(vlbase), voff, VLs + buf * kTile + wave * 1024);
+            return;
+        }
         dma_rows(kbase, 128, kt * 64, T, zeros, Ks + buf * kTile, wave, lane);
         dma_rows(vbase, 128, kt * 64, T, zeros, Vs + buf * kTile, wave, lane);
         dma_rows(vlbase, 128, kt * 64, T, zeros, VLs + buf * kTile, wave, lane);
-        dma_cols(ktbase, Tp, kt * 64, KTs + buf * kTile, wave, lane);
+        if constexpr (PASS == 2) dma_cols(ktbase, Tp, kt * 64, KTs + buf * kTile, wave, lane);
     };
     int row_off[2], swz[2];
 #pragma unroll
@@ -170,31 +193,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float Dacc = 0.f, Facc = 0.f, D_q = 0.f, F_q = 1.f, rs = 0.f;       // rs = sum_k dS[q][k] (fp32)
     float mxpd = 0.f, mxp = 0.f, alpha = 1.f;      // bounds for |dS| (first pass) -> power-of-two operand scale of this lane's column
+    if constexpr (PASS == 2) {
+        if (qok) { D_q = a.Dq[(size_t)nh * T + query]; F_q = a.Fq[(size_t)nh * T + query]; alpha = a.alphaq[(size_t)nh * T + query]; }
+    }
 
     if (ntiles > 0) issue(0, 0);
     ST_DMA_WAIT(0);
     __syncthreads();
     // pass 0 over the key tiles: D' and F;  pass 1: dS and dQ
-    for (int it = 0; it < 2 * ntiles; ++it) {
-        const bool second = it >= ntiles;
-        const int kt = second ? it - ntiles : it;
+    for (int it = 0; it < ntiles; ++it) {
+        constexpr bool second = PASS == 2;
+        const int kt = it;
         const int buf = it & 1;
-        if (it + 1 < 2 * ntiles) issue(it + 1 >= ntiles ? it + 1 - ntiles : it + 1, buf ^ 1);
+        if (it + 1 < ntiles) issue(it + 1, buf ^ 1);
         f32x16_t s[2], dp[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s[kb] = P::mfma(frag<P>(Ks + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), qf[ks], s[kb]);
-                dp[kb] = P::mfma(frag<P>(Vs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
-                dp[kb] = P::mfma(frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
-            }
-        }
         vec8 dsf[4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        auto elems = [&](int kb) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const float4 bz = *(const float4*)(kbias + kt * 64 + kb * 32 + 8 * g4 + 4 * hi);
@@ -222,7 +236,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
                     }
                 }
             }
-        if (!second) {
+        };
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s[kb] = P::mfma(frag<P>(Ks + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), qf[ks], s[kb]);
+                dp[kb] = P::mfma(frag<P>(Vs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
+                dp[kb] = P::mfma(frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
+            }
+            if constexpr (PASS == 1) { __builtin_amdgcn_sched_barrier(0); elems(kb); __builtin_amdgcn_sched_barrier(0); }   // one key block live at a time: 128 VGPRs
+        }
+        if constexpr (PASS == 2) { elems(0); elems(1); }
+        if constexpr (!second) {
             if (it == ntiles - 1) {
                 D_q = xor32_sum(Dacc); F_q = xor32_sum(Facc);
                 // |dS| <= max p|f dP| + max p (|D| + |a| (1/(1-p) + F)): scale this query's column to ~2^10
@@ -249,8 +277,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
         ST_DMA_WAIT(0);
         __syncthreads();
     }
-    if (qok && hi == 0) {
-        a.Dq[(size_t)nh * T + query] = D_q; a.Fq[(size_t)nh * T + query] = F_q; a.aq[(size_t)nh * T + query] = a_q;
+    if constexpr (PASS == 1) {
+        if (qok && hi == 0) {
+            a.Dq[(size_t)nh * T + query] = D_q; a.Fq[(size_t)nh * T + query] = F_q; a.aq[(size_t)nh * T + query] = a_q;
+            a.alphaq[(size_t)nh * T + query] = alpha;
+        }
+        return;
     }
     {   // undo the operand scale; K^T was centred: add kmean[d] * sum_k dS back (fp32)
         rs = xor32_sum(rs);
@@ -452,12 +484,17 @@ hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s) {
     const int grid = ((total + 7) / 8) * 8;
     const bool drop = a.drop.thresh16 != 0;
     if (drop && (!a.drop.rowh || !a.drop.colh)) return hipErrorInvalidValue;
+    if (!a.alphaq) return hipErrorInvalidValue;
     if (dtype == DT_BF16) {
-        if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, true>), dim3(grid), dim3(512), 0, s, a);
-        else      hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, false>), dim3(grid), dim3(512), 0, s, a);
+        if (drop) { hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, true, 1>), dim3(grid), dim3(512), 0, s, a);
+                    hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, true, 2>), dim3(grid), dim3(512), 0, s, a); }
+        else      { hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, false, 1>), dim3(grid), dim3(512), 0, s, a);
+                    hipLaunchKernelGGL((attn_bwd_dq_kernel<OpBF16, false, 2>), dim3(grid), dim3(512), 0, s, a); }
     } else {
-        if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, true>), dim3(grid), dim3(512), 0, s, a);
-        else      hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, false>), dim3(grid), dim3(512), 0, s, a);
+        if (drop) { hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, true, 1>), dim3(grid), dim3(512), 0, s, a);
+                    hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, true, 2>), dim3(grid), dim3(512), 0, s, a); }
+        else      { hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, false, 1>), dim3(grid), dim3(512), 0, s, a);
+                    hipLaunchKernelGGL((attn_bwd_dq_kernel<OpF16, false, 2>), dim3(grid), dim3(512), 0, s, a); }
     }
     return hipGetLastError();
 }

@@ -54,7 +54,7 @@ struct TrainState {
     int *n_full, *kv_end;
     std::vector<LayerAct> L;
     // backward scratch
-    float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
+    float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *alphabuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
           *gin, *gsc;
     unsigned *gbits, *dsmax, *qbits;
     unsigned *drop_rowh, *drop_colh;            // dropout hash tables of the attention site being processed (launch_drop_tables)
@@ -204,6 +204,7 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->drop_rowh, (N * H * TT + 64) * 4); want((void**)&ts->drop_colh, (size_t)(Tp / 2 + 64) * 4);
     want(&ts->vnat, R * C * 2); want(&ts->vnat_lo, R * C * 2); want((void**)&ts->dsmax, N * H * 4); want(&ts->qT, N * C * Tp * 2); want(&ts->kT, N * C * Tp * 2); want(&ts->dOT, N * C * Tp * 2);
     want((void**)&ts->Dbuf, N * H * TT * 4); want((void**)&ts->Fbuf, N * H * TT * 4); want((void**)&ts->abuf, N * H * TT * 4);
+    want((void**)&ts->alphabuf, N * H * TT * 4);
     want((void**)&ts->vmean, N * H * 64 * 4); want((void**)&ts->qmean, N * H * 64 * 4); want((void**)&ts->kmean, N * H * 64 * 4);
     want((void**)&ts->dq, R * C * 4); want((void**)&ts->dk, R * C * 4); want((void**)&ts->dv, R * C * 4);
     // weight-gradient operands: the largest are (taps*Cin, Cout) = (3F, F) [cond_proj.2]; rows padded per split
@@ -550,7 +551,7 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
             AttnBwdArgs a; memset(&a, 0, sizeof(a));
             a.q = A.q; a.k = A.k; a.v = ts->vnat; a.vlo = ts->vnat_lo; a.dsmax = ts->dsmax; a.qT = ts->qT; a.kT = ts->kT; a.dOT = ts->dOT;
             a.dO = ts->g16a; a.dO_row_stride = C; a.lse = A.lse; a.vmean = ts->vmean; a.qmean = ts->qmean; a.kmean = ts->kmean;
-            a.Dq = ts->Dbuf; a.Fq = ts->Fbuf; a.aq = ts->abuf; a.kbias = ts->kbias; a.mask_mod = B;
+            a.Dq = ts->Dbuf; a.Fq = ts->Fbuf; a.aq = ts->abuf; a.alphaq = ts->alphabuf; a.kbias = ts->kbias; a.mask_mod = B;
             a.kv_end = ts->kv_end; a.dq = ts->dq; a.dk = ts->dk; a.dv = ts->dv; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
             a.drop = make_drop(ts->p_drop, ts->seed, 2 * i + 1); a.zeros = e->zeros;
             if (a.drop.thresh16) {

@@ -136,6 +136,7 @@ struct AttnBwdArgs {
     const float* qmean; const float* kmean;            // [item][H][64]: what was subtracted from qT / kT
     const void* dO; int dO_row_stride;                 // time-major [item][T][H*64] (row stride H*64)
     const float* lse;                                  // [item][H][T]: log2-sum-exp of the forward
+    float* alphaq;                                     // [item][H][T]: power-of-two operand scale of each query's dS column (first pass -> second pass)
     float* Dq; float* Fq; float* aq;                   // [item][H][T]: sum_k P f dP', sum_k P f, dO . vmean -- written by the dQ
                                                        // kernel (first pass), read by the dK/dV kernel
     const float* kbias; int mask_mod;                  // [mask_mod][Tp]
