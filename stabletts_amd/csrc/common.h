@@ -50,11 +50,19 @@ __device__ __forceinline__ typename P::vec8 as_vec8(uint4 v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad(float a) {      // d/da [a * sigmoid(a)] = s * (1 + a * (1 - s))
+    const float s = 1.0f / (1.0f + expf(-a));
+    return s * (1.0f + a * (1.0f - s));
+}
 
 // SiLU on the hardware transcendental units (v_exp_f32 + v_rcp_f32, ~1 ulp each): used where the
 // result is rounded to a 16-bit MFMA operand anyway.  exp2 overflow (x << 0) gives rcp(inf) = 0.
 __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float silu_grad_fast(float a) {      // silu_grad on the same two hardware units
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a));
+    return s * (1.0f + a * (1.0f - s));
 }
 
 // Cross-lane reductions on the VALU (DPP row rotations + gfx950 v_permlane{16,32}_swap): __shfl_xor lowers to

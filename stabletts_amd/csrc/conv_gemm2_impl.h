@@ -90,7 +90,44 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
     for (int u = 0; u < R; ++u) grow[u] = (size_t)n * g.T + t[u];
     static_assert(EPI != EPI_ACT16, "EPI_ACT16 has its own epilogue (g2_epilogue_act16)");
     {
-        if constexpr (EPI == EPI_F32) {
+        if constexpr (EPI == EPI_SILU) {
+            // training FFN: the element-wise step between conv_1 and conv_2 (forward) / between their dgrads (backward),
+            // same arithmetic as silu_drop_kernel / silu_bwd_kernel (train_kernels.hip) on the same rounded inputs
+            struct { unsigned long long seed; unsigned thresh16; float scale; } d = {g.drop_seed, g.drop_thresh16, g.drop_scale};
+            float2 f01[R], f23[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                f01[u] = make_float2(1.0f, 1.0f); f23[u] = f01[u];
+                if (d.thresh16) {
+                    const unsigned long long i = (unsigned long long)grow[u] * g.cout + ch;
+                    f01[u] = drop_factors2(d, drop_ffn_hash(d, i)); f23[u] = drop_factors2(d, drop_ffn_hash(d, i + 2));
+                }
+            }
+            if (g.act16) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const typename P::elem a0 = to16<P>(v[u].x + k.bias.x), a1 = to16<P>(v[u].y + k.bias.y),
+                                           a2 = to16<P>(v[u].z + k.bias.z), a3 = to16<P>(v[u].w + k.bias.w);
+                    if (ok[u]) {
+                        store_row8((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2, pack4<P>((float)a0, (float)a1, (float)a2, (float)a3));
+                        store_row8((unsigned char*)g.act16 + (grow[u] * g.cout + ch) * 2,
+                                   pack4<P>(silu_fast((float)a0) * f01[u].x * m[u], silu_fast((float)a1) * f01[u].y * m[u],
+                                            silu_fast((float)a2) * f23[u].x * m[u], silu_fast((float)a3) * f23[u].y * m[u]));
+                    }
+                }
+            } else {
+                typedef __attribute__((ext_vector_type(4))) typename P::elem v4;
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const v4 a = *(const v4*)((const unsigned char*)g.dact16 + (grow[ok[u] ? u : 0] * g.cout + ch) * 2);
+                    if (ok[u])
+                        store_row8((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2,
+                                   pack4<P>(v[u].x * m[u] * f01[u].x * silu_grad_fast((float)a[0]), v[u].y * m[u] * f01[u].y * silu_grad_fast((float)a[1]),
+                                            v[u].z * m[u] * f23[u].x * silu_grad_fast((float)a[2]), v[u].w * m[u] * f23[u].y * silu_grad_fast((float)a[3])));
+                }
+            }
+            return;
+        } else if constexpr (EPI == EPI_F32) {
             const bool msk = g.flags & GF_MASK;
 #pragma unroll
             for (int u = 0; u < R; ++u) {

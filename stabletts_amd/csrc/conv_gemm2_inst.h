@@ -40,6 +40,7 @@ static hipError_t launch_conv_gemm2_t(int cfg, int taps, int epi, const ConvGemm
         if (taps == 3 && epi == EPI_ACT16) return launch_phased3<P, EPI_ACT16>(a, s);
         if (taps == 3 && epi == EPI_F32) return launch_phased3<P, EPI_F32>(a, s);
         if (taps == 3 && epi == EPI_RESGATE) return launch_phased3<P, EPI_RESGATE>(a, s);
+        if (taps == 3 && epi == EPI_SILU) return launch_phased3<P, EPI_SILU>(a, s);      // training FFN (the only tile that carries it)
     } else if (cfg == 7) {   // RC1: 256 ch x 128 frames with ONE weight buffer -> 74 KB, two resident blocks (QKV on big grids)
         if (taps == 1 && epi == EPI_QKV) return launch_g2<P, 1, EPI_QKV, 256, 128, 4, 2, 1>(a, s);
         // (EPI_RESGATE + fused LayerNorm -- out-proj -- does not fit 128 VGPRs on this tile: 54 spilled registers)

@@ -94,11 +94,19 @@ const float* P(st_engine* e, const std::string& name) { return e->params.at(name
 // 128-frame ones and the launch has enough of them for the chip (small grids would leave most CUs idle behind a
 // few long-running blocks); otherwise row-complete 256x128 tiles where the epilogue needs whole rows (fused
 // LayerNorm, QKV planes), the 3-buffer pipeline for deep k=3 convs, 128x128 tiles for the rest.
-hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
-    const bool bf = e->dt == DT_BF16;
+// 256 x 256 tiles (BIG / PHASED / RC1) are used when they waste little of the last frame tile and fill the chip
+static bool big_tiles(const st_engine* e, const ConvGemmArgs& a) {
     const int T = a.T;
     const bool fills = ((T + 255) / 256) * 256 * 10 <= ((T + 127) / 128) * 128 * 11;
     const bool big_fills_chip = (int64_t)e->conc * a.n_items * ((T + 255) / 256) * (a.cout / 256) >= e->big_min_blocks;
+    return a.cout % 256 == 0 && fills && big_fills_chip;
+}
+bool gemm_is_phased(const st_engine* e, int taps, const ConvGemmArgs& a) { return taps == 3 && e->phased && big_tiles(e, a); }
+
+hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStream_t s) {
+    const bool bf = e->dt == DT_BF16;
+    const int T = a.T;
+    if (epi == EPI_SILU && !gemm_is_phased(e, taps, a)) return hipErrorInvalidValue;      // callers ask gemm_is_phased first
     // Small grids (a few frame tiles in total: single-utterance synthesis): the K loop of one block is a serial chain
     // of DMA -> barrier -> MFMA stages, so a handful of blocks walking 24..48 stages each leaves the chip idle for
     // tens of microseconds.  Split the contraction over `ks` blocks per output tile (raw fp32 partial planes in
@@ -121,7 +129,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         }
     }
     int cfg;
-    if (a.cout % 256 == 0 && fills && big_fills_chip) cfg = (e->phased && taps == 3) ? G2_PHASED : (epi == EPI_QKV && e->qkv_rc1) ? G2_RC1 : G2_BIG;
+    if (big_tiles(e, a)) cfg = (e->phased && taps == 3) ? G2_PHASED : (epi == EPI_QKV && e->qkv_rc1) ? G2_RC1 : G2_BIG;
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
     else if (taps == 3 && a.c0 + a.c1 >= 512 && a.c2 == 0) cfg = G2_K3PIPE;
     else cfg = G2_T128;

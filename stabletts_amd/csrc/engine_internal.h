@@ -137,6 +137,7 @@ namespace sthost {
 int dev_alloc(st_engine* e, void** p, size_t bytes);
 const float* P(st_engine* e, const std::string& name);
 hipError_t gemm(st_engine* e, int taps, int epi, const st::ConvGemmArgs& a, hipStream_t s);
+bool gemm_is_phased(const st_engine* e, int taps, const st::ConvGemmArgs& a);   // gemm() would run the 256 x 254 phased kernel (the tile that has EPI_SILU)
 void prof_collect(st_engine* e);
 void capture(st_engine* e, const std::string& name, const void* dev, int64_t n, bool is16, hipStream_t s);
 int ensure_ws(st_engine* e, size_t bytes);

@@ -57,6 +57,7 @@ struct TrainState {
     float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *alphabuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
           *gin, *gsc;
     unsigned *gbits, *dsmax, *qbits;
+    bool fuse_silu = true;                      // ST_FUSE_SILU=0: stand-alone silu_drop / silu_bwd kernels (A/B and the bit-identity test)
     unsigned *drop_rowh, *drop_colh;            // dropout hash tables of the attention site being processed (launch_drop_tables)
     float* skip_sc;                             // {scale, 1 / scale} each long-skip gradient was written at
     float* qs;                                  // local scales of the attention-input gradients (launch_qkv_grad_scales)
@@ -98,7 +99,10 @@ void train_invalidate(st_engine* e) {
 // (re)packs the transposed weights after a parameter update; lazy: inference-only users never pay for it
 int train_prepare(st_engine* e, hipStream_t s) {
     if (e->kind != 0) return ST_OK;
-    if (!e->train) e->train = new TrainState();
+    if (!e->train) {
+        e->train = new TrainState();
+        if (const char* v = getenv("ST_FUSE_SILU")) e->train->fuse_silu = atoi(v) != 0;
+    }
     TrainState* ts = e->train;
     if (ts->packed) return ST_OK;
     ts->have_fwd = false;
@@ -352,8 +356,14 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         }
         {   // FFN (diffusion_transformer.py:25-30)
             ConvGemmArgs a = cargs(e, e->ffn1[i], N, T, B); a.a0 = A.h2; a.c0 = C; a.out16 = A.a16;
-            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
-            HIPCHK(e, launch_silu_drop(e->dt, A.a16, A.u16, m, B, T, F, R, make_drop(p_dropout, seed, 2 * i), s));
+            const DropCfg dc = make_drop(p_dropout, seed, 2 * i);
+            if (ts->fuse_silu && gemm_is_phased(e, 3, a)) {      // SiLU + dropout + mask in the GEMM's epilogue (bit-identical)
+                a.act16 = A.u16; a.mask = m; a.drop_seed = dc.seed; a.drop_thresh16 = dc.thresh16; a.drop_scale = dc.scale;
+                HIPCHK(e, gemm(e, 3, EPI_SILU, a, s));
+            } else {
+                HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+                HIPCHK(e, launch_silu_drop(e->dt, A.a16, A.u16, m, B, T, F, R, dc, s));
+            }
             a = cargs(e, e->ffn2[i], N, T, B); a.a0 = A.u16; a.c0 = F; a.mask = m; a.flags = GF_MASK; a.out32 = A.f32b;
             HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
         }
@@ -408,15 +418,21 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     const int cin = c0 + c1;
     const int frames = taps * cin;
     static const bool use_tn = [] { const char* v = getenv("ST_WGRAD_TN"); return !(v && atoi(v) == 0); }();
-    static const int target_blocks = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 512; }();
+    static const int blocks_env = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 0; }();
+    const int target_blocks = blocks_env ? blocks_env : 512;        // transposed-copy path: two rounds of its smaller blocks
+    const int target_tn = blocks_env ? blocks_env : 256;            // TN path: one block per CU
     if (use_tn && cout16 % 256 == 0 && !(c0 & 63) && !(c1 & 63) && (!c1 || c0 % 256 == 0)) {
-        // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip); K is split over items
+        // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip).  K (= items x 64-frame chunks) is split
+        // into S ranges such that tiles x S fills ONE round of blocks (the kernel holds 128 KB of LDS: one block per CU) --
+        // every block then carries the same share of the contraction and the reduce kernel reads the fewest planes
         const int tiles_tn = taps * ((cin + 255) / 256) * (cout16 / 256);
-        int ipb = std::max(1, (int)((int64_t)N * tiles_tn / target_blocks));
-        while ((size_t)((N + ipb - 1) / ipb) * frames * cout16 * 4 > ts->partial_cap && ipb < N) ++ipb;
-        const int S_tn = (N + ipb - 1) / ipb;
+        const int kchunks = N * ((T + 63) / 64);
+        const int S_want = std::max(1, std::min(kchunks, target_tn / tiles_tn));
+        int cps = (kchunks + S_want - 1) / S_want;
+        while ((size_t)((kchunks + cps - 1) / cps) * frames * cout16 * 4 > ts->partial_cap && cps < kchunks) ++cps;
+        const int S_tn = (kchunks + cps - 1) / cps;
         if ((size_t)S_tn * frames * cout16 * 4 <= ts->partial_cap) {
-            HIPCHK(e, launch_wgrad_tn(e->dt, dy, cout16, x0, c0, x1, c1, taps, N, T, ipb, e->zeros, ts->partial, s));
+            HIPCHK(e, launch_wgrad_tn(e->dt, dy, cout16, x0, c0, x1, c1, taps, N, T, cps, e->zeros, ts->partial, s));
             bool need_b = false;
             for (int k = 0; k < n_outs; ++k) need_b = need_b || outs[k].db;
             if (need_b) HIPCHK(e, launch_colsum_rows(e->dt, dy, cout16, R, ts->part_b, s));
@@ -519,10 +535,17 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         {   // conv_2
             WgradOut o = {G(ts, b + "mlp.conv_2.weight"), F, 0, F, 0, C, G(ts, b + "mlp.conv_2.bias")};
             if ((rc = wgrad(e, ts, A.u16, F, nullptr, 0, ts->g16b, C, K, &o, 1, s))) return rc;
-            ConvGemmArgs a = cargs(e, ts->ffn2T[i], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->tmpF;
-            HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+            ConvGemmArgs a = cargs(e, ts->ffn2T[i], N, T, B); a.a0 = ts->g16b; a.c0 = C;
+            const DropCfg dc = make_drop(ts->p_drop, ts->seed, 2 * i);
+            if (ts->fuse_silu && K == 3 && gemm_is_phased(e, 3, a) && !a.bias) {      // d pre-activation straight from the dgrad's epilogue
+                a.out16 = ts->g16a; a.dact16 = A.a16; a.mask = m; a.drop_seed = dc.seed; a.drop_thresh16 = dc.thresh16; a.drop_scale = dc.scale;
+                HIPCHK(e, gemm(e, K, EPI_SILU, a, s));
+            } else {
+                a.out32 = ts->tmpF;
+                HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+                HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, A.a16, m, B, T, F, R, dc, ts->g16a, s));
+            }
         }
-        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, A.a16, m, B, T, F, R, make_drop(ts->p_drop, ts->seed, 2 * i), ts->g16a, s));
         {   // conv_1
             WgradOut o = {G(ts, b + "mlp.conv_1.weight"), C, 0, C, 0, F, G(ts, b + "mlp.conv_1.bias")};
             if ((rc = wgrad(e, ts, A.h2, C, nullptr, 0, ts->g16a, F, K, &o, 1, s))) return rc;

@@ -12,7 +12,8 @@ enum { DT_BF16 = 0, DT_F16 = 1 };
 // Activations are TIME-MAJOR 16-bit tensors [item][T][C]; the K dimension may span two source
 // tensors (channel concat without materialising torch.cat: estimator.py:120,131).
 enum { EPI_ACT16 = 0, EPI_F32 = 1, EPI_RESGATE = 2, EPI_QKV = 3,
-       EPI_GELU16 = 4 };   // EPI_ACT16 with exact-erf GELU in place of SiLU (Vocos pwconv1, module.py:38-39)
+       EPI_GELU16 = 4,     // EPI_ACT16 with exact-erf GELU in place of SiLU (Vocos pwconv1, module.py:38-39)
+       EPI_SILU = 5 };     // training FFN (k = 3, phased kernel only): EPI_F32 + the SiLU / dropout step fused, see act16 / dact16
 enum { GF_SILU = 1, GF_MASK = 2 };
 
 struct ConvGemmArgs {
@@ -48,6 +49,12 @@ struct ConvGemmArgs {
     // (nullptr: every tile).  t_lim = last valid frame + 1 + kFrameHalo (mask_prep), so every frame a VALID output
     // frame depends on -- including the reference's pad leak through the unmasked tensors, SURVEY A.5 -- is computed.
     const int* t_lim; int t_lim_mod;
+    // EPI_SILU (training FFN, diffusion_transformer.py:25-30).  Forward (act16 != nullptr): out16 = the pre-activation, act16 =
+    // silu(float(out16)) * dropout factor * mask -- what silu_drop_kernel computes from out16.  Backward (dact16 != nullptr):
+    // out16 = acc * mask * dropout factor * silu'(float(dact16[row][ch])) -- what silu_bwd_kernel computes from the fp32 result.
+    // Same arithmetic order as the two stand-alone kernels: results are bit-identical.  Dropout = the FFN element-pair hash.
+    void* act16; const void* dact16;
+    unsigned long long drop_seed; unsigned drop_thresh16; float drop_scale;
     int ksplit;                       // > 1: split-K launch (EPI_F32 only): out32 = partial planes [ksplit][items][T][cout], raw sums
     unsigned long long* dbg;          // diagnostics (ST_STAGE_TIMING builds of tools/gemm2_bench only), else nullptr
 };

@@ -31,10 +31,6 @@ hipError_t launch_drop_tables(const DropCfg& d, int n_rows, int n_colpairs, unsi
     return hipGetLastError();
 }
 
-__device__ __forceinline__ float silu_grad(float a) {      // d/da [a * sigmoid(a)] = s * (1 + a * (1 - s))
-    const float s = 1.0f / (1.0f + expf(-a));
-    return s * (1.0f + a * (1.0f - s));
-}
 
 template <class P>
 __device__ __forceinline__ float4 load4_16(const void* p) {
@@ -106,8 +102,8 @@ __global__ __launch_bounds__(256) void silu_drop_kernel(const typename P::elem* 
     for (int e = 0; e < 8; e += 2) {
         float2 f = make_float2(1.0f, 1.0f);
         if (drop.thresh16) f = drop_factors2(drop, drop_ffn_hash(drop, (unsigned long long)(i + e)));
-        o[e] = to16<P>(silu_f((float)a[e]) * f.x * m);
-        o[e + 1] = to16<P>(silu_f((float)a[e + 1]) * f.y * m);
+        o[e] = to16<P>(silu_fast((float)a[e]) * f.x * m);
+        o[e + 1] = to16<P>(silu_fast((float)a[e + 1]) * f.y * m);
     }
     *(uint4*)(u16 + i) = __builtin_bit_cast(uint4, o);
 }
@@ -141,8 +137,8 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* dU, const ty
     for (int e = 0; e < 8; e += 2) {
         float2 f = make_float2(1.0f, 1.0f);
         if (drop.thresh16) f = drop_factors2(drop, drop_ffn_hash(drop, (unsigned long long)(i + e)));
-        o[e] = to16<P>(g[e] * m * f.x * silu_grad((float)a[e]));
-        o[e + 1] = to16<P>(g[e + 1] * m * f.y * silu_grad((float)a[e + 1]));
+        o[e] = to16<P>(g[e] * m * f.x * silu_grad_fast((float)a[e]));
+        o[e + 1] = to16<P>(g[e + 1] * m * f.y * silu_grad_fast((float)a[e + 1]));
     }
     *(uint4*)(dA16 + i) = __builtin_bit_cast(uint4, o);
 }

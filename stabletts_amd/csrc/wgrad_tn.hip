@@ -25,7 +25,7 @@ namespace st {
 struct WgradTnArgs {
     const void* dy; int cout;                    // [items * T][cout], 16 bit
     const void* x0; int c0; const void* x1; int c1;   // [items * T][c0], [items * T][c1] (channel concat; c1 may be 0)
-    int taps, n_items, T, ipb;                   // ipb: items per block (K range of a block)
+    int taps, n_items, T, cps;                   // cps: 64-frame chunks per split (K range of a block; chunks never straddle items)
     const void* zeros;
 };
 
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
     const int half = w.taps / 2;
     const int nblk_ci = (cin + BF - 1) / BF;
     const int tiles_n = w.taps * nblk_ci, tiles_m = w.cout / BC;
-    const int S = (w.n_items + w.ipb - 1) / w.ipb;
+    const int nchunk = (w.T + 63) >> 6, kchunks = w.n_items * nchunk;
+    const int S = (kchunks + w.cps - 1) / w.cps;
     const int total = S * tiles_n * tiles_m;
     const int per_xcd = gridDim.x >> 3;
     const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -150,16 +151,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
 #undef ST_TN_KSTEP
     };
 
-    // ---- K loop over the frames of this block's items, 64 at a time
-    const int item0 = s * w.ipb, item1 = min(w.n_items, item0 + w.ipb);
-    const int nchunk = (T + 63) >> 6;
-    const int nstage = (item1 - item0) * nchunk;
-    issue(item0, 0, 0);
+    // ---- K loop over this block's range of 64-frame chunks (item = chunk / chunks per item)
+    const int k0 = s * w.cps, nstage = min(kchunks, k0 + w.cps) - k0;
+    issue(k0 / nchunk, (k0 % nchunk) * 64, 0);
     ST_DMA_WAIT(0);
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
-        const int nx = st + 1;
-        if (nx < nstage) issue(item0 + nx / nchunk, (nx % nchunk) * 64, nx & 1);
+        const int nx = st + 1, kx = k0 + nx;
+        if (nx < nstage) issue(kx / nchunk, (kx % nchunk) * 64, nx & 1);
         compute(st & 1);
         ST_DMA_WAIT(0);
         __syncthreads();
@@ -182,7 +181,7 @@ static hipError_t launch_wgrad_tn_t(const WgradTnArgs& w, float* partial, int S,
         attr_done_dev[dev_] = true;
     }
     const int cin = w.c0 + w.c1;
-    if (!w.zeros || !partial || (w.cout % 256) || (w.c0 & 63) || (w.c1 & 63) || cin < 64 || w.ipb < 1 || (w.taps != 1 && w.taps != 3)) return hipErrorInvalidValue;
+    if (!w.zeros || !partial || (w.cout % 256) || (w.c0 & 63) || (w.c1 & 63) || cin < 64 || w.cps < 1 || (w.taps != 1 && w.taps != 3)) return hipErrorInvalidValue;
     if (w.c1 && (w.c0 % 256)) return hipErrorInvalidValue;      // an N tile never straddles the two sources
     ConvGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -195,11 +194,12 @@ static hipError_t launch_wgrad_tn_t(const WgradTnArgs& w, float* partial, int S,
 }
 
 hipError_t launch_wgrad_tn(int dtype, const void* dy, int cout, const void* x0, int c0, const void* x1, int c1, int taps,
-                           int n_items, int T, int ipb, const void* zeros, float* partial, hipStream_t s) {
+                           int n_items, int T, int cps, const void* zeros, float* partial, hipStream_t s) {
     WgradTnArgs w;
-    w.dy = dy; w.cout = cout; w.x0 = x0; w.c0 = c0; w.x1 = x1; w.c1 = c1; w.taps = taps; w.n_items = n_items; w.T = T; w.ipb = ipb;
+    w.dy = dy; w.cout = cout; w.x0 = x0; w.c0 = c0; w.x1 = x1; w.c1 = c1; w.taps = taps; w.n_items = n_items; w.T = T; w.cps = cps;
     w.zeros = zeros;
-    const int S = (n_items + ipb - 1) / ipb;
+    const int kchunks = n_items * ((T + 63) / 64);
+    const int S = (kchunks + cps - 1) / cps;
     return dtype == DT_BF16 ? launch_wgrad_tn_t<OpBF16>(w, partial, S, s) : launch_wgrad_tn_t<OpF16>(w, partial, S, s);
 }
 

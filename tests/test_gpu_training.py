@@ -441,14 +441,20 @@ def _drop_attn(seed, salt, p, row, key):
     return _keep16(_lowbias32(rh ^ ch), (key & np.uint64(1)) == 1, p)
 
 
-@pytest.mark.parametrize("dt", ["f16"])
-def test_dropout_forward_and_backward_match_oracle_with_same_masks(sd, dt):
+@pytest.mark.parametrize("dt,T,lengths,tiles", [("f16", 70, [70, 45], "policy"), ("f16", 250, [250, 181], "big")])
+def test_dropout_forward_and_backward_match_oracle_with_same_masks(sd, monkeypatch, dt, T, lengths, tiles):
     """Train mode (p_dropout = 0.1 on the FFN activations and the attention probabilities,
     diffusion_transformer.py:28,77): the native counter-based dropout is reproduced in numpy, the oracle is run under
     autograd with exactly those keep / (1 - p) factors, and loss + gradients must agree as in eval mode.  Also:
-    same torch seed -> bitwise identical loss; different seed -> different masks."""
-    B, T, lengths, p = 2, 70, [70, 45], 0.1
+    same torch seed -> bitwise identical loss; different seed -> different masks.
+    "big": ST_BIG_MIN_BLOCKS=1 puts every conv on the tiles of a B = 64 batch, where the FFN's SiLU + dropout + mask step
+    runs inside the phased kernel's epilogue (EPI_SILU, forward and dgrad); that case is additionally compared BITWISE with
+    the stand-alone silu_drop / silu_bwd kernels (ST_FUSE_SILU=0)."""
+    B, p = 2, 0.1
+    if tiles == "big":
+        monkeypatch.setenv("ST_BIG_MIN_BLOCKS", "1")
     dec = _decoder(sd, dt, train=True)
+    dec.estimator.engine()
     inp = make_inputs(B, T, seed=51, lengths=lengths)
     x1 = make_inputs(B, T, seed=52)["z"]
     g0 = torch.Generator().manual_seed(9)
@@ -466,6 +472,16 @@ def test_dropout_forward_and_backward_match_oracle_with_same_masks(sd, dt):
     l1b, _, _ = native(123)
     l2, _, _ = native(124)
     assert l1 == l1b and l1 != l2
+    if tiles == "big":
+        monkeypatch.setenv("ST_FUSE_SILU", "0")
+        fused = dec
+        dec = _decoder(sd, dt, train=True)
+        l3, gmu3, gp3 = native(123)
+        dec = fused
+        monkeypatch.delenv("ST_FUSE_SILU")
+        monkeypatch.delenv("ST_BIG_MIN_BLOCKS")
+        assert l3 == l1 and torch.equal(gmu3, gmu1)
+        assert all(torch.equal(gp3[n], gp1[n]) for n in gp1)
     torch.manual_seed(123)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     F_, H = 1024, 4
