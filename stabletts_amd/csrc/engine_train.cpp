@@ -422,12 +422,12 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     const int target_blocks = blocks_env ? blocks_env : 512;        // transposed-copy path: two rounds of its smaller blocks
     const int target_tn = blocks_env ? blocks_env : 256;            // TN path: one block per CU
     if (use_tn && cout16 % 256 == 0 && !(c0 & 63) && !(c1 & 63) && (!c1 || c0 % 256 == 0)) {
-        // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip).  K (= items x 64-frame chunks) is split
+        // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip).  K (= items x 32-frame chunks) is split
         // into S ranges such that tiles x S fills ONE round of blocks (the kernel holds 128 KB of LDS: one block per CU) --
         // every block then carries the same share of the contraction and the reduce kernel reads the fewest planes
         const int tiles_tn = taps * ((cin + 255) / 256) * (cout16 / 256);
-        const int kchunks = N * ((T + 63) / 64);
-        const int S_want = std::max(1, std::min(kchunks, target_tn / tiles_tn));
+        const int kchunks = N * ((T + 31) / 32);
+        const int S_want = std::max(1, std::min(std::min(kchunks, 64), target_tn / tiles_tn));      // <= 64 planes: the reduce kernel walks them serially
         int cps = (kchunks + S_want - 1) / S_want;
         while ((size_t)((kchunks + cps - 1) / cps) * frames * cout16 * 4 > ts->partial_cap && cps < kchunks) ++cps;
         const int S_tn = (kchunks + cps - 1) / cps;

@@ -86,8 +86,8 @@ hipError_t launch_wgrad_xt(int dtype, const void* x0, int c0, const void* x1, in
 hipError_t launch_wgrad_dyt(int dtype, const void* dy, int cout, int64_t R, int S, int Rs, void* dyt, float* part_b,
                             hipStream_t s);
 // The same weight gradient WITHOUT the transposed copies (wgrad_tn.hip): a "TN" GEMM that stages dY and X in LDS as they lie
-// in memory ([frame][channel]) and reads the k-strided MFMA fragments with ds_read_b64_tr_b16.  Splits K over ranges of 64-frame chunks (cps chunks
-// per block; a chunk lies inside one item): partial[S = ceil(n_items * ceil(T / 64) / cps)][taps*Cin][cout].  Needs cout % 256 == 0, c0 % 64 == c1 % 64 == 0.
+// in memory ([frame][channel]) and reads the k-strided MFMA fragments with ds_read_b64_tr_b16.  Splits K over ranges of 32-frame chunks (cps chunks
+// per block; a chunk lies inside one item): partial[S = ceil(n_items * ceil(T / 32) / cps)][taps*Cin][cout].  Needs cout % 256 == 0, c0 % 64 == c1 % 64 == 0.
 hipError_t launch_wgrad_tn(int dtype, const void* dy, int cout, const void* x0, int c0, const void* x1, int c1, int taps,
                            int n_items, int T, int cps, const void* zeros, float* partial, hipStream_t s);
 // part_b[rowblock][cout] = column sums of every 64-row block of dY [R][cout] (bias-gradient partials for launch_bias_reduce)

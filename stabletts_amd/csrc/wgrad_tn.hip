@@ -13,8 +13,11 @@
 // the 8 k-slots of a 32x32x16 operand.  Rows are XOR-swizzled at 16-byte granularity by ((frame >> 1) & 1) << 2 so that the
 // four frames x 64 bytes a half-wave touches fall into four different bank quarters (no conflicts).
 //
-// Block = 256 (cout) x 256 (one tap's cin slice) output tile, 8 waves of 128 x 64, K chunks of 64 frames, double-buffered
-// (2 x 64 KB); the fp32 partial tile of the block's items goes through the conv kernels' coalesced EPI_F32 epilogue into
+// Block = 256 (cout) x 256 (one tap's cin slice) output tile, 8 waves of 128 x 64, K stages of 32 frames in FOUR 32-KB buffers:
+// the LDS-DMA of stage s + 3 is issued while stage s is computed and retired by a counted `s_waitcnt vmcnt(8)` that leaves the
+// two younger stages in flight (with two 64-frame buffers and a full drain per stage the loop ran at the DMA round trip:
+// 2.4 us per 64 frames, 35 % of the MFMA rate).  One barrier per stage publishes the stage and frees the buffer read last.
+// The fp32 partial tile of the block's items goes through the conv kernels' coalesced EPI_F32 epilogue into
 // plane s of partial[S][taps * cin][cout]; launch_wgrad_reduce adds the planes in order (deterministic).
 #include "conv_gemm2_impl.h"
 #include "train_launch.h"
@@ -25,7 +28,7 @@ namespace st {
 struct WgradTnArgs {
     const void* dy; int cout;                    // [items * T][cout], 16 bit
     const void* x0; int c0; const void* x1; int c1;   // [items * T][c0], [items * T][c1] (channel concat; c1 may be 0)
-    int taps, n_items, T, cps;                   // cps: 64-frame chunks per split (K range of a block; chunks never straddle items)
+    int taps, n_items, T, cps;                   // cps: 32-frame chunks per split (K range of a block; chunks never straddle items)
     const void* zeros;
 };
 
@@ -48,7 +51,7 @@ __device__ __forceinline__ typename P::vec8 join8(uint2 lo, uint2 hi) {
 template <class P>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, const ConvGemmArgs g) {
     constexpr int BC = 256, BF = 256, WC = 2, WF = 4, FC = 4, FF = 2;
-    constexpr int TILE = 32768, BUF = 2 * TILE;          // A tile + B tile per buffer
+    constexpr int KF = 32, TILE = KF * 512, BUF = 2 * TILE, NBUF = 4;          // 32 frames x 256 channels per operand; A tile + B tile per buffer
     using vec8 = typename P::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
     const int half = w.taps / 2;
     const int nblk_ci = (cin + BF - 1) / BF;
     const int tiles_n = w.taps * nblk_ci, tiles_m = w.cout / BC;
-    const int nchunk = (w.T + 63) >> 6, kchunks = w.n_items * nchunk;
+    const int nchunk = (w.T + KF - 1) / KF, kchunks = w.n_items * nchunk;
     const int S = (kchunks + w.cps - 1) / w.cps;
     const int total = S * tiles_n * tiles_m;
     const int per_xcd = gridDim.x >> 3;
@@ -74,16 +77,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
     const int T = w.T;
     const unsigned char* zeros = (const unsigned char*)w.zeros;
 
-    // ---- LDS-DMA: 32 + 32 pieces of 1 KiB (8 frames x 128 B of one 64-channel block) per stage, 4 + 4 per wave
+    // ---- LDS-DMA: 16 + 16 pieces of 1 KiB (8 frames x 128 B of one 64-channel block) per stage, 2 + 2 per wave
     const int prow = lane >> 3;
     auto issue = [&](int item, int t0, int buf) {
         unsigned char* Ab = smem + buf * BUF;
         unsigned char* Bb = Ab + TILE;
         const size_t rbase = (size_t)item * T;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int piece = wave * 4 + k;                  // channel block = piece >> 3, frame group = piece & 7
-            const int cbk = piece >> 3, row = (piece & 7) * 8 + prow;
+        for (int k = 0; k < 2; ++k) {
+            const int piece = wave * 2 + k;                  // channel block = piece >> 2, frame group = piece & 3
+            const int cbk = piece >> 2, row = (piece & 3) * 8 + prow;
             const int sseg = (lane & 7) ^ (((row >> 1) & 1) << 2);
             {   // A: dY frames t0 + row, channels mb + cbk*64 + sseg*8 .. + 8
                 const int t = t0 + row;
@@ -112,11 +115,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;
     const unsigned rowb = (unsigned)rlane * 128u;
     // A operand (cout side): wave's 128 channels = channel blocks wc*2, wc*2+1; sub-block a: block a>>1, segment bit (a&1)<<2
-    const unsigned aA0 = lds0 + (unsigned)wc * 16384u + rowb + ((seg0 ^ swz) << 4) + within;
-    const unsigned aA1 = lds0 + (unsigned)wc * 16384u + rowb + (((seg0 | 4u) ^ swz) << 4) + within;
+    const unsigned aA0 = lds0 + (unsigned)wc * 8192u + rowb + ((seg0 ^ swz) << 4) + within;
+    const unsigned aA1 = lds0 + (unsigned)wc * 8192u + rowb + (((seg0 | 4u) ^ swz) << 4) + within;
     // B operand (cin side): wave's 64 channels = channel block wf; sub-block b: segment bit b << 2
-    const unsigned aB0 = lds0 + TILE + (unsigned)wf * 8192u + rowb + ((seg0 ^ swz) << 4) + within;
-    const unsigned aB1 = lds0 + TILE + (unsigned)wf * 8192u + rowb + (((seg0 | 4u) ^ swz) << 4) + within;
+    const unsigned aB0 = lds0 + TILE + (unsigned)wf * 4096u + rowb + ((seg0 ^ swz) << 4) + within;
+    const unsigned aB1 = lds0 + TILE + (unsigned)wf * 4096u + rowb + (((seg0 | 4u) ^ swz) << 4) + within;
 
     f32x16_t acc[FC][FF];
 #pragma unroll
@@ -133,8 +136,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
             uint2 al[FC], ah[FC], bl[FF], bh[FF];                                                                   \
             al[0] = tr_read<(KS) * 2048>(aA0 + bo);        ah[0] = tr_read<(KS) * 2048 + 512>(aA0 + bo);            \
             al[1] = tr_read<(KS) * 2048>(aA1 + bo);        ah[1] = tr_read<(KS) * 2048 + 512>(aA1 + bo);            \
-            al[2] = tr_read<8192 + (KS) * 2048>(aA0 + bo); ah[2] = tr_read<8192 + (KS) * 2048 + 512>(aA0 + bo);     \
-            al[3] = tr_read<8192 + (KS) * 2048>(aA1 + bo); ah[3] = tr_read<8192 + (KS) * 2048 + 512>(aA1 + bo);     \
+            al[2] = tr_read<4096 + (KS) * 2048>(aA0 + bo); ah[2] = tr_read<4096 + (KS) * 2048 + 512>(aA0 + bo);     \
+            al[3] = tr_read<4096 + (KS) * 2048>(aA1 + bo); ah[3] = tr_read<4096 + (KS) * 2048 + 512>(aA1 + bo);     \
             bl[0] = tr_read<(KS) * 2048>(aB0 + bo);        bh[0] = tr_read<(KS) * 2048 + 512>(aB0 + bo);            \
             bl[1] = tr_read<(KS) * 2048>(aB1 + bo);        bh[1] = tr_read<(KS) * 2048 + 512>(aB1 + bo);            \
             asm volatile("s_waitcnt lgkmcnt(0)"                                                                     \
@@ -147,22 +150,33 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
                 acc[a][1] = P::mfma(af, bf1, acc[a][1]);                                                            \
             }                                                                                                       \
         }
-        ST_TN_KSTEP(0) ST_TN_KSTEP(1) ST_TN_KSTEP(2) ST_TN_KSTEP(3)
+        ST_TN_KSTEP(0) ST_TN_KSTEP(1)
 #undef ST_TN_KSTEP
     };
 
     // ---- K loop over this block's range of 64-frame chunks (item = chunk / chunks per item)
     const int k0 = s * w.cps, nstage = min(kchunks, k0 + w.cps) - k0;
-    issue(k0 / nchunk, (k0 % nchunk) * 64, 0);
-    ST_DMA_WAIT(0);
-    __syncthreads();
+    auto issue_stage = [&](int st) { const int kx = k0 + st; issue(kx / nchunk, (kx % nchunk) * KF, st % NBUF); };
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p)
+        if (p < nstage) issue_stage(p);
     for (int st = 0; st < nstage; ++st) {
-        const int nx = st + 1, kx = k0 + nx;
-        if (nx < nstage) issue(kx / nchunk, (kx % nchunk) * 64, nx & 1);
-        compute(st & 1);
+        // stage st has landed when at most the pieces of the younger stages in flight (4 per wave and stage) are outstanding
+        const int younger = min(NBUF - 2, nstage - 1 - st);
+#ifdef ST_TN_NO_DMA      // ablation builds (tools/ab_wgrad.sh): the loop without its DMA / without its reads + MFMAs
         ST_DMA_WAIT(0);
-        __syncthreads();
+#else
+        if (younger >= 2) ST_DMA_WAIT(8); else if (younger == 1) ST_DMA_WAIT(4); else ST_DMA_WAIT(0);
+#endif
+        __syncthreads();      // every wave's pieces of stage st are in LDS; every wave is done reading buffer (st - 1) % NBUF
+#ifndef ST_TN_NO_DMA
+        if (st + NBUF - 1 < nstage) issue_stage(st + NBUF - 1);
+#endif
+#ifndef ST_TN_NO_MMA
+        compute(st % NBUF);
+#endif
     }
+    __syncthreads();
 
     // partial tile -> plane s of partial[S][taps*cin][cout] (rows = this tap's input channels cb .. cb + 256 of cin)
     const int fvalid = min(BF, cin - cb);
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
 
 template <class P>
 static hipError_t launch_wgrad_tn_t(const WgradTnArgs& w, float* partial, int S, hipStream_t s) {
-    constexpr int LDS = 4 * 32768;
+    constexpr int LDS = 4 * 32768;      // NBUF x (A tile + B tile)
     static bool attr_done_dev[64] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
@@ -198,7 +212,7 @@ hipError_t launch_wgrad_tn(int dtype, const void* dy, int cout, const void* x0, 
     WgradTnArgs w;
     w.dy = dy; w.cout = cout; w.x0 = x0; w.c0 = c0; w.x1 = x1; w.c1 = c1; w.taps = taps; w.n_items = n_items; w.T = T; w.cps = cps;
     w.zeros = zeros;
-    const int kchunks = n_items * ((T + 63) / 64);
+    const int kchunks = n_items * ((T + 31) / 32);
     const int S = (kchunks + cps - 1) / cps;
     return dtype == DT_BF16 ? launch_wgrad_tn_t<OpBF16>(w, partial, S, s) : launch_wgrad_tn_t<OpF16>(w, partial, S, s);
 }
