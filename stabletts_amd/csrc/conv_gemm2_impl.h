@@ -90,44 +90,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
     for (int u = 0; u < R; ++u) grow[u] = (size_t)n * g.T + t[u];
     static_assert(EPI != EPI_ACT16, "EPI_ACT16 has its own epilogue (g2_epilogue_act16)");
     {
-        if constexpr (EPI == EPI_SILU) {
-            // training FFN: the element-wise step between conv_1 and conv_2 (forward) / between their dgrads (backward),
-            // same arithmetic as silu_drop_kernel / silu_bwd_kernel (train_kernels.hip) on the same rounded inputs
-            struct { unsigned long long seed; unsigned thresh16; float scale; } d = {g.drop_seed, g.drop_thresh16, g.drop_scale};
-            float2 f01[R], f23[R];
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                f01[u] = make_float2(1.0f, 1.0f); f23[u] = f01[u];
-                if (d.thresh16) {
-                    const unsigned long long i = (unsigned long long)grow[u] * g.cout + ch;
-                    f01[u] = drop_factors2(d, drop_ffn_hash(d, i)); f23[u] = drop_factors2(d, drop_ffn_hash(d, i + 2));
-                }
-            }
-            if (g.act16) {
-#pragma unroll
-                for (int u = 0; u < R; ++u) {
-                    const typename P::elem a0 = to16<P>(v[u].x + k.bias.x), a1 = to16<P>(v[u].y + k.bias.y),
-                                           a2 = to16<P>(v[u].z + k.bias.z), a3 = to16<P>(v[u].w + k.bias.w);
-                    if (ok[u]) {
-                        store_row8((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2, pack4<P>((float)a0, (float)a1, (float)a2, (float)a3));
-                        store_row8((unsigned char*)g.act16 + (grow[u] * g.cout + ch) * 2,
-                                   pack4<P>(silu_fast((float)a0) * f01[u].x * m[u], silu_fast((float)a1) * f01[u].y * m[u],
-                                            silu_fast((float)a2) * f23[u].x * m[u], silu_fast((float)a3) * f23[u].y * m[u]));
-                    }
-                }
-            } else {
-                typedef __attribute__((ext_vector_type(4))) typename P::elem v4;
-#pragma unroll
-                for (int u = 0; u < R; ++u) {
-                    const v4 a = *(const v4*)((const unsigned char*)g.dact16 + (grow[ok[u] ? u : 0] * g.cout + ch) * 2);
-                    if (ok[u])
-                        store_row8((unsigned char*)g.out16 + (grow[u] * g.cout + ch) * 2,
-                                   pack4<P>(v[u].x * m[u] * f01[u].x * silu_grad_fast((float)a[0]), v[u].y * m[u] * f01[u].y * silu_grad_fast((float)a[1]),
-                                            v[u].z * m[u] * f23[u].x * silu_grad_fast((float)a[2]), v[u].w * m[u] * f23[u].y * silu_grad_fast((float)a[3])));
-                }
-            }
-            return;
-        } else if constexpr (EPI == EPI_F32) {
+        if constexpr (EPI == EPI_F32) {
             const bool msk = g.flags & GF_MASK;
 #pragma unroll
             for (int u = 0; u < R; ++u) {
@@ -207,7 +170,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
     const int T = g.T;
-    static_assert(EPI != EPI_QKV && EPI != EPI_ACT16, "QKV: g2_epilogue_qkv; ACT16: g2_epilogue_act16");
+    static_assert(EPI != EPI_QKV && EPI != EPI_ACT16 && EPI != EPI_SILU, "QKV: g2_epilogue_qkv; ACT16: g2_epilogue_act16; SILU: g2_epilogue_silu");
     static_assert(BC == 128 || BC == 256, "row walker handles 128 or 256 channels");
     constexpr bool LN = (BC == 256);
     // frames staged per pass: the 4-wave 128x128 tile goes in ONE pass (fewer barriers, one exposed global-load
@@ -338,6 +301,99 @@ __device__ __forceinline__ void g2_epilogue_act16(f32x16_t (&acc)[BC / WC / 32][
         const uint4 v = *(const uint4*)(stage + f * PB + cl * 16);
         if (t0 + f < T && f < fvalid) store_row16(obase + (size_t)f * g.cout * 2, v);
     }
+}
+
+// EPI_SILU epilogue (training FFN, diffusion_transformer.py:25-30): the element-wise step between conv_1 and conv_2 -- SiLU,
+// dropout, frame mask -- applied in the accumulator registers like EPI_ACT16, every global access a full coalesced row
+// through the 16-bit LDS image [frame][channel].
+//   forward  (g.act16):  image 1 = round16(acc + bias) -> out16 (the pre-activation the backward needs);
+//                        image 2 = silu(float(image 1)) * dropout factor * mask -> act16 (conv_2's operand).
+//   backward (g.dact16): the pre-activation tile is loaded row-wise into the image, every lane reads its own
+//                        (frame, 4 channels) groups back, out16 = acc * mask * dropout factor * silu'(pre) in place.
+// Same values as silu_drop_kernel / silu_bwd_kernel (train_kernels.hip) compute from the same rounded inputs.
+template <class P, int BC, int BF, int WC, int WF>
+__device__ __forceinline__ void g2_epilogue_silu(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], unsigned char* stage,
+                                                 const ConvGemmArgs& g, int n, int t0, int fvalid, int cbase, int wave, int lane) {
+    constexpr int NW = WC * WF, TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32, PB = BC * 2 + 16;
+    constexpr int LPR = BC / 8, RPI = 64 / LPR;        // lanes per row, rows per wave instruction
+    typedef __attribute__((ext_vector_type(4))) typename P::elem v4;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wave % WC, wf = wave / WC;
+    const int T = g.T;
+    const float* mrow = g.mask ? g.mask + (size_t)(n % g.mask_mod) * T : nullptr;
+    struct { unsigned long long seed; unsigned thresh16; float scale; } d = {g.drop_seed, g.drop_thresh16, g.drop_scale};
+    const int rsub = lane / LPR, cl = lane % LPR;
+    const size_t tile0 = (((size_t)n * T + t0) * g.cout + cbase) * 2 + cl * 16;
+    auto rows_out = [&](void* dst) {
+#pragma unroll
+        for (int i = 0; i < BF / (NW * RPI); ++i) {
+            const int f = (i * NW + wave) * RPI + rsub;
+            const uint4 v = *(const uint4*)(stage + f * PB + cl * 16);
+            if (t0 + f < T && f < fvalid) store_row16((unsigned char*)dst + tile0 + (size_t)f * g.cout * 2, v);
+        }
+    };
+    const bool fwd = g.act16 != nullptr;
+    if (!fwd) {     // pre-activation tile -> image (rows outside the tensor: zeros, their results are never stored)
+#pragma unroll
+        for (int i = 0; i < BF / (NW * RPI); ++i) {
+            const int f = (i * NW + wave) * RPI + rsub;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t0 + f < T && f < fvalid) v = *(const uint4*)((const unsigned char*)g.dact16 + tile0 + (size_t)f * g.cout * 2);
+            *(uint4*)(stage + f * PB + cl * 16) = v;
+        }
+        __syncthreads();
+    }
+    // element (fragment a, b; register group q4): frame fl = wf*TF + b*32 + l31, channels ch .. ch+3, ch = wc*TC + a*32 + 8*q4 + 4*hi
+    auto factors = [&](int t, int ch, float2& f01, float2& f23) {
+        f01 = make_float2(1.0f, 1.0f); f23 = f01;
+        if (d.thresh16) {       // FFN element-pair hash of element index row * cout + channel (launch.h: DropCfg)
+            const unsigned long long i = ((unsigned long long)n * T + t) * g.cout + cbase + ch;
+            f01 = drop_factors2(d, drop_ffn_hash(d, i)); f23 = drop_factors2(d, drop_ffn_hash(d, i + 2));
+        }
+    };
+    if (fwd) {
+#pragma unroll
+        for (int b = 0; b < FF; ++b) {
+            const int fl = wf * TF + b * 32 + l31;
+#pragma unroll
+            for (int a = 0; a < FC; ++a)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
+                    const float4 bv = g.bias ? *(const float4*)(g.bias + cbase + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(uint2*)(stage + fl * PB + ch * 2) = pack4<P>(acc[a][b][4 * q4 + 0] + bv.x, acc[a][b][4 * q4 + 1] + bv.y,
+                                                                   acc[a][b][4 * q4 + 2] + bv.z, acc[a][b][4 * q4 + 3] + bv.w);
+                }
+        }
+        __syncthreads();
+        rows_out(g.out16);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < FF; ++b) {
+        const int fl = wf * TF + b * 32 + l31;
+        const int t = t0 + fl;
+        const float m = mrow ? mrow[t < T ? t : T - 1] : 1.0f;
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
+                float2 f01, f23;
+                factors(t, ch, f01, f23);
+                const v4 pre = *(const v4*)(stage + fl * PB + ch * 2);
+                uint2 o;
+                if (fwd)
+                    o = pack4<P>(silu_fast((float)pre[0]) * f01.x * m, silu_fast((float)pre[1]) * f01.y * m,
+                                 silu_fast((float)pre[2]) * f23.x * m, silu_fast((float)pre[3]) * f23.y * m);
+                else
+                    o = pack4<P>(acc[a][b][4 * q4 + 0] * m * f01.x * silu_grad_fast((float)pre[0]), acc[a][b][4 * q4 + 1] * m * f01.y * silu_grad_fast((float)pre[1]),
+                                 acc[a][b][4 * q4 + 2] * m * f23.x * silu_grad_fast((float)pre[2]), acc[a][b][4 * q4 + 3] * m * f23.y * silu_grad_fast((float)pre[3]));
+                *(uint2*)(stage + fl * PB + ch * 2) = o;
+            }
+    }
+    __syncthreads();
+    rows_out(fwd ? g.act16 : g.out16);
 }
 
 // EPI_QKV epilogue (fused q/k/v projection of diffusion_transformer.py:60-62, cout = 3 x 256, tile = 256 channels

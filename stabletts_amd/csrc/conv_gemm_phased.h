@@ -198,6 +198,7 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
 
     if constexpr (EPI == EPI_ACT16 || EPI == EPI_GELU16)
         g2_epilogue_act16<P, BC, BF, WC, WF, EPI == EPI_GELU16>(acc, smem, g, n, t0, BFV, cbase, wave, lane);
+    else if constexpr (EPI == EPI_SILU) g2_epilogue_silu<P, BC, BF, WC, WF>(acc, smem, g, n, t0, BFV, cbase, wave, lane);
     else g2_epilogue<P, EPI, BC, BF, WC, WF>(acc, (float*)smem, g, n, t0, BFV, cbase, wave, lane);
 }
 
