@@ -30,6 +30,22 @@
 #include "common.h"
 #include "launch.h"
 
+// ablation builds of the inference kernel (tools/ab_attention_ablation.sh): the softmax without its exps / row sums / maxima
+#ifdef ST_ABL_NOEXP
+constexpr bool kAblNoExp = true;
+#else
+constexpr bool kAblNoExp = false;
+#endif
+#ifdef ST_ABL_NOSUM
+constexpr bool kAblNoSum = true;
+#else
+constexpr bool kAblNoSum = false;
+#endif
+#ifdef ST_ABL_NOMAX
+constexpr bool kAblNoMax = true;
+#else
+constexpr bool kAblNoMax = false;
+#endif
 #ifndef ST_ATTN_WAVES
 #define ST_ATTN_WAVES 8      // waves (x 32 queries) per block sharing one K/V tile stream: 4, 8 or 16
 #endif
@@ -43,10 +59,11 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW, QTILE = QB;      // waves and queries per block
     using vec8 = typename P::vec8;
     constexpr int TILE_BYTES = 64 * 128;
-    constexpr int SMEM = 4 * TILE_BYTES > NW * 32 * 144 ? 4 * TILE_BYTES : NW * 32 * 144;
+    constexpr int NBUF = 3;                      // K / V^T tile ring: tile kt+2 is in flight while tile kt is computed
+    constexpr int SMEM = 2 * NBUF * TILE_BYTES > NW * 32 * 144 ? 2 * NBUF * TILE_BYTES : NW * 32 * 144;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    unsigned char* Ks = smem;                    // 2 buffers
-    unsigned char* Vs = smem + 2 * TILE_BYTES;   // 2 buffers
+    unsigned char* Ks = smem;                       // NBUF buffers
+    unsigned char* Vs = smem + NBUF * TILE_BYTES;   // NBUF buffers
 
     const int T = a.T, Tp = a.Tp, H = a.H;
     const int qtiles = (T + QB - 1) / QB;
@@ -152,14 +169,18 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     for (int i = 0; i < 8; ++i) { qaug[i] = to16<P>(0.f); kaug[i] = to16<P>(0.f); }
     if (hi == 0) kaug[0] = to16<P>(1.0f);
 
+    // Counted waits: every wave issues the same number of 1-KiB pieces per tile, so `vmcnt(pieces of one tile)` retires
+    // everything but the youngest tile.  (With two buffers and a full drain per tile the iteration time was the LDS-DMA
+    // round trip, not the tile's MFMA + softmax work.)
     if (ntiles > 0) issueKV(0, 0);
-    ST_DMA_WAIT(0);
+    if (ntiles > 1) { issueKV(1, 1); if constexpr (NW <= 8) { if constexpr (NW == 8) ST_DMA_WAIT(2); else ST_DMA_WAIT(4); } else ST_DMA_WAIT(1); }
+    else ST_DMA_WAIT(0);
     __syncthreads();
 
     const int ntiles_run = ntiles;
+    int buf = 0;
     for (int kt = 0; kt < ntiles_run; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntiles_run) issueKV(kt + 1, buf ^ 1);
+        if (kt + 2 < ntiles_run) issueKV(kt + 2, buf >= 1 ? buf - 1 : NBUF - 1);      // (buf + 2) % 3
 
         f32x16_t s[2];
         const bool partial = (kt + 1) * 64 > nfull;       // tiles inside the valid prefix have no masked key
@@ -190,11 +211,13 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
         scores();
         // ---- tile maximum relative to the reference, one query per lane (pair lane^32 shares the query)
         float mx = s[0][0];
+        if constexpr (!(kAblNoMax && !TRAIN)) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = xor32_max(mx);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = xor32_max(mx);
+        }
         if (kt == 0 || __any(mx > kLazy)) {
             // Rare (and the first tile): raise the reference of the rows that need it, rescale their O and l, and
             // RECOMPUTE the tile's scores with the new reference (subtracting the step from s' instead would keep the
@@ -219,9 +242,13 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                psum[0] = add_f32_scalar(psum[0], p0);
-                psum[1] = add_f32_scalar(psum[1], p1);
+                float p0, p1;
+                if constexpr (kAblNoExp && !TRAIN) { p0 = s[kb][r] * 0.001f; p1 = s[kb][r + 1] * 0.001f; }
+                else { p0 = __builtin_amdgcn_exp2f(s[kb][r]); p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]); }
+                if constexpr (!(kAblNoSum && !TRAIN)) {
+                    psum[0] = add_f32_scalar(psum[0], p0);
+                    psum[1] = add_f32_scalar(psum[1], p1);
+                }
                 if constexpr (TRAIN) {
                     if (a.drop.thresh16) {      // elements r, r+1 are keys 2j, 2j+1: one hash decides both (DropCfg, launch.h)
                         const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -243,8 +270,11 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
             for (int g = 0; g < 4; ++g)
                 o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
         }
-        ST_DMA_WAIT(0);       // tile kt+1 (asm-issued LDS-DMA, flying under this tile's MFMAs and exps) has landed
-        __syncthreads();      // fence the buffer swap
+        // tile kt+1 (asm-issued LDS-DMA, flying under the MFMAs and exps of two tiles) has landed; tile kt+2 stays in flight
+        if (kt + 2 < ntiles_run) { if constexpr (NW <= 8) { if constexpr (NW == 8) ST_DMA_WAIT(2); else ST_DMA_WAIT(4); } else ST_DMA_WAIT(1); }
+        else ST_DMA_WAIT(0);
+        __syncthreads();      // publishes tile kt+1, frees buffer kt % 3 for tile kt+3
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
     const float m_run = m_ref;
 

@@ -148,6 +148,29 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(off) : "memory");
 }
+// the same transfer with the LDS destination given as a wave-uniform LDS byte offset (no generic -> LDS pointer cast, no
+// readfirstlane: scalar arithmetic only -- on a SIMD every VALU instruction of a K loop is issued instead of an MFMA)
+__device__ __forceinline__ void glds16o(const void* sbase, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void glds16bo(const void* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+// wave-uniform 64-bit pointer held in SGPRs
+__device__ __forceinline__ const unsigned char* sgpr_ptr64(const void* p) {
+    const uintptr_t v = (uintptr_t)p;
+    return (const unsigned char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+}
+__device__ __forceinline__ uint4 lds_read16(unsigned addr) {      // ds_read_b128 at an LDS byte address
+    typedef unsigned __attribute__((ext_vector_type(4))) u32x4_raw;
+    const u32x4_raw v = *(const __attribute__((address_space(3))) u32x4_raw*)(uintptr_t)addr;
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
 #define ST_DMA_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // counter-based dropout (DropCfg, launch.h): 32-bit murmur3-style mix of (seed, a, b) -- a, b = the two halves of the

@@ -33,6 +33,7 @@
 // Measured (MI355X, FFN conv_2 of the headline solve, 48 stages): K loop 64 us = 67 % MFMA utilisation inside the loop
 // (conv_gemm2_kernel: ~74 us); the kernel's remaining 36 us are its HBM-bound epilogue.
 #pragma once
+#include <type_traits>
 #include "conv_gemm2_impl.h"
 
 namespace st {
@@ -49,14 +50,13 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
     constexpr int WPW = 4, APW = 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                    // 2 buffers
-    unsigned char* Ws = smem + 2 * A_BYTES;      // 3 buffers
+    // LDS: 2 activation buffers (As = smem), then 3 weight buffers (Ws = smem + 2 * A_BYTES)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wc = wave % WC, wf = wave / WC;
-    const int grp = wave >> 2;
+    const int grp = wave >> 2, ngrp = grp ^ 1;
     const int cin = g.c0 + g.c1 + g.c2;
     const int nch = cin >> 6;
     const int T = g.T;
@@ -74,6 +74,26 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
     const int n = rest / g.tiles_f;
     const int cbase = tc * BC, t0 = tf * BFV;
     if (g.t_lim && t0 >= g.t_lim[n % g.t_lim_mod]) return;      // ragged batch: this tile lies past the item's last needed frame
+
+    // Accumulators.  The bias-initialised variants (EPI_ACT16 / EPI_GELU16: "start from the bias", g2_init_acc) keep the bias
+    // as four 16-register tuples that enter as the C operand of the very first MFMAs (D = A B + bias: the same operation
+    // as accumulating into a bias-initialised register, bit for bit) -- no 2 x 64 register copies next to the loop's
+    // invariant address registers.
+    constexpr bool BIAS_C = (EPI == EPI_ACT16 || EPI == EPI_GELU16);
+    f32x16_t acc[FC][FF];
+    f32x16_t bt[BIAS_C ? FC : 1];
+    if constexpr (BIAS_C) {
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.bias) bv = *(const float4*)(g.bias + cbase + wc * TC + a * 32 + 8 * q4 + 4 * hi);
+                bt[a][4 * q4 + 0] = bv.x; bt[a][4 * q4 + 1] = bv.y; bt[a][4 * q4 + 2] = bv.z; bt[a][4 * q4 + 3] = bv.w;
+            }
+    } else {
+        g2_init_acc<EPI, FC, FF>(acc, g, cbase + wc * TC, hi);
+    }
 
     const unsigned char* a0 = (const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * g.c0 * 2;
     const unsigned char* a1 = TWO_SRC ? (const unsigned char*)g.a1 + (size_t)(n % g.a1_mod) * T * g.c1 * 2 : nullptr;
@@ -95,71 +115,89 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
         voffA0[k] = (unsigned)(t * g.c0 * 2) + segb;
         if constexpr (TWO_SRC) voffA1[k] = (unsigned)(t * g.c1 * 2) + segb;
     }
+    // Everything wave-uniform in the loop lives in SGPRs and every per-lane address is computed ONCE, before the loop: on a
+    // SIMD a VALU instruction is issued INSTEAD of an MFMA (rocprofv3 SQ counters, profiles/r03_attention_sq_counters_and_
+    // ablation.txt), and the ~16 VALU per phase of per-phase address arithmetic cost a fifth of the loop.
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)smem);
+    const unsigned ldsA = lds0, ldsW = lds0 + 2 * A_BYTES;
+    const unsigned char* wsrc_s = sgpr_ptr64(wsrc);
+    const unsigned char* a0_s = sgpr_ptr64(a0);
+    const unsigned char* a1_s = TWO_SRC ? sgpr_ptr64(a1) : nullptr;
     auto issueW = [&](int c, int j, int buf, int k0, int k1) {
-        // (the stage base is wave-uniform; said explicitly, hipcc otherwise keeps it in VGPRs in this kernel and the
-        // SGPR operand of the asm statement does not assemble)
-        const uintptr_t sbv = (uintptr_t)(wsrc + (size_t)(j * cin + (c << 6)) * 2);
-        const unsigned char* sb = (const unsigned char*)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(sbv >> 32)) << 32) |
-                                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbv));
+        const unsigned char* sb = wsrc_s + (size_t)(j * cin + (c << 6)) * 2;
 #pragma unroll
         for (int k = 0; k < WPW; ++k)
-            if (k >= k0 && k < k1) glds16s(sb, voffW[k], Ws + buf * W_BYTES + (wave * WPW + k) * 1024);
+            if (k >= k0 && k < k1) glds16o(sb, voffW[k], ldsW + buf * W_BYTES + (wave * WPW + k) * 1024);
     };
     auto issueA = [&](int c, int buf, int k0, int k1) {
         int ch0 = c << 6;
         if (ch0 >= g.c0 + g.c1) ch0 -= g.c0 + g.c1;
         if (!TWO_SRC || ch0 < g.c0) {
-            const unsigned char* sb = a0 + (size_t)ch0 * 2;
+            const unsigned char* sb = a0_s + (size_t)ch0 * 2;
 #pragma unroll
             for (int k = 0; k < APW; ++k)
-                if (k >= k0 && k < k1) glds16b(validA[k] ? sb + voffA0[k] : zeros, As + buf * A_BYTES + (wave * APW + k) * 1024);
+                if (k >= k0 && k < k1) glds16bo(validA[k] ? sb + voffA0[k] : zeros, ldsA + buf * A_BYTES + (wave * APW + k) * 1024);
         } else if constexpr (TWO_SRC) {
-            const unsigned char* sb = a1 + (size_t)(ch0 - g.c0) * 2;
+            const unsigned char* sb = a1_s + (size_t)(ch0 - g.c0) * 2;
 #pragma unroll
             for (int k = 0; k < APW; ++k)
-                if (k >= k0 && k < k1) glds16b(validA[k] ? sb + voffA1[k] : zeros, As + buf * A_BYTES + (wave * APW + k) * 1024);
+                if (k >= k0 && k < k1) glds16bo(validA[k] ? sb + voffA1[k] : zeros, ldsA + buf * A_BYTES + (wave * APW + k) * 1024);
         }
     };
 
-    f32x16_t acc[FC][FF];
-    g2_init_acc<EPI, FC, FF>(acc, g, cbase + wc * TC, hi);
 
     // Fragment addresses: rows 32 apart share the swizzle term ((row >> 1) & 7), so the four channel fragments (and the
-    // two frame fragments) of a wave are ONE per-lane address per k-slice plus a 4096-byte immediate.
+    // two frame fragments) of a wave are ONE per-lane address per k-slice plus a 4096-byte immediate.  The 4 weight addresses
+    // (one per k-slice; a second set 64 KiB up for weight buffer 2, whose offset does not fit ds_read's 16-bit immediate) and
+    // the 12 activation addresses (tap x k-slice: the swizzle term moves with the tap's row shift) are loop invariant: 20
+    // registers, made opaque so that hipcc neither recomputes them per phase nor hoists anything else next to them.
+    unsigned wadr[4], wadr2[4], aadr[3][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        wadr[ks] = ldsW + (unsigned)(wrow * 128 + (((ks * 2 + hi) ^ ((wrow >> 1) & 7)) << 4));
+        wadr2[ks] = wadr[ks] + 2 * W_BYTES;
+        asm volatile("" : "+v"(wadr[ks]), "+v"(wadr2[ks]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int arow = arow0 + j;          // rows 256, 257 (last two frame columns at j = 2) fall into the next buffer
+            aadr[j][ks] = ldsA + (unsigned)(arow * 128 + (((ks * 2 + hi) ^ ((arow >> 1) & 7)) << 4));
+            asm volatile("" : "+v"(aadr[j][ks]));
+        }
+    }
     vec8 wfr[FC], afr[FF];
-    auto load_frags = [&](const unsigned char* Wb, const unsigned char* Ab, int j, int ks) {
-        // (the row indices pass through an empty asm statement: hipcc otherwise hoists all 24 per-(tap, k-slice)
-        // addresses out of the chunk loop and holds them in VGPRs next to the 128 accumulators -- the kernel spills)
-        int wr = wrow, ar0 = arow0;
-        asm volatile("" : "+v"(wr), "+v"(ar0));
-        const unsigned wad = (unsigned)(wr * 128 + (((ks * 2 + hi) ^ ((wr >> 1) & 7)) << 4));
-        const int arow = ar0 + j;          // rows 256, 257 (last two frame columns at j = 2) fall into the next buffer
-        const unsigned aad = (unsigned)(arow * 128 + (((ks * 2 + hi) ^ ((arow >> 1) & 7)) << 4));
+    auto load_frags = [&](int wbuf, unsigned abuf_off, int j, int ks) {      // wbuf, j, ks: compile-time after unrolling
+        const unsigned wad = wbuf == 2 ? wadr2[ks] : wadr[ks];
+        const unsigned woff = wbuf == 1 ? W_BYTES : 0;
+        const unsigned aad = aadr[j][ks] + abuf_off;      // the one VALU instruction of a phase (chunk parity is a run-time value)
 #pragma unroll
-        for (int a = 0; a < FC; ++a) wfr[a] = as_vec8<P>(*(const uint4*)(Wb + wad + a * 4096));
+        for (int a = 0; a < FC; ++a) wfr[a] = as_vec8<P>(lds_read16(wad + woff + a * 4096));
 #pragma unroll
-        for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(*(const uint4*)(Ab + aad + b * 4096));
+        for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(lds_read16(aad + b * 4096));
     };
-    auto mma = [&]() {
+    auto mma = [&](bool first) {      // first: compile-time after unrolling (the first phase of the first chunk)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < FC; ++a)
 #pragma unroll
-            for (int b = 0; b < FF; ++b) acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+            for (int b = 0; b < FF; ++b) {
+                if constexpr (BIAS_C) acc[a][b] = P::mfma(wfr[a], afr[b], first ? bt[a] : acc[a][b]);
+                else acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
+            }
         __builtin_amdgcn_s_setprio(0);
     };
     // One phase = fragment reads (+ this phase's LDS-DMA issues), reads retired, 8 MFMAs, with ONE barrier: group 0 takes
     // it between its reads and its MFMAs, group 1 before its reads -- so between two barriers group 0 runs [M(p-1) R(p)]
     // while group 1 runs [R(p-1) M(p-1)]: on every SIMD one wave is in its MFMAs while the other reads / issues.
+#define ST_BARRIER_IF(cond) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lnb_%=\n\ts_barrier\n.Lnb_%=:" :: "s"(cond) : "memory", "scc")
 #define ST_PHASE(ks, ISSUE)                                      \
     __builtin_amdgcn_sched_barrier(0);                           \
-    if (grp) ST_RAW_BARRIER();                                   \
-    load_frags(Wb, Ab, j, ks);                                   \
+    ST_BARRIER_IF(grp);                                          \
+    load_frags(j, abuf_off, j, ks);                              \
     ISSUE;                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
     __builtin_amdgcn_sched_barrier(0);                           \
-    if (!grp) ST_RAW_BARRIER();                                  \
-    mma();                                                       \
+    ST_BARRIER_IF(ngrp);                                         \
+    mma(FIRST && j == 0 && ks == 0);                             \
     __builtin_amdgcn_sched_barrier(0);
 
     // prologue: A(0), W(0) resident; W(1) in flight (retired by stage 0's wait)
@@ -168,15 +206,15 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
     ST_DMA_WAIT(4);
     __syncthreads();
 
-    for (int c = 0; c < nch; ++c) {
+    auto chunk = [&](int c, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const bool lastc = (c == nch - 1);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             // stage s + 2 = (c, j + 2) or (c + 1, j - 1); its buffer is (j + 2) % 3
             const int c2 = (j == 0) ? c : c + 1, j2 = (j + 2) % 3;
             const bool w2 = (j == 0) || !lastc;
-            const unsigned char* Ab = As + (c & 1) * A_BYTES;
-            const unsigned char* Wb = Ws + j * W_BYTES;
+            const unsigned abuf_off = (unsigned)(c & 1) * A_BYTES;
             ST_PHASE(0, if (j == 1 && !lastc) issueA(c + 1, (c + 1) & 1, 2, 3))
             ST_PHASE(1, if (w2) issueW(c2, j2, j2, 0, 2))
             ST_PHASE(2, {
@@ -192,8 +230,12 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
                 if (j == 1 && !lastc) issueA(c + 1, (c + 1) & 1, 3, 4);
             })
         }
-    }
+    };
+    // the first chunk is peeled when its first MFMAs take the bias as their C operand
+    chunk(0, std::integral_constant<bool, BIAS_C>{});
+    for (int c = 1; c < nch; ++c) chunk(c, std::false_type{});
 #undef ST_PHASE
+#undef ST_BARRIER_IF
     __syncthreads();
 
     if constexpr (EPI == EPI_ACT16 || EPI == EPI_GELU16)
