@@ -41,11 +41,6 @@ constexpr bool kAblNoSum = true;
 #else
 constexpr bool kAblNoSum = false;
 #endif
-#ifdef ST_ABL_NOMAX
-constexpr bool kAblNoMax = true;
-#else
-constexpr bool kAblNoMax = false;
-#endif
 #ifndef ST_ATTN_WAVES
 #define ST_ATTN_WAVES 8      // waves (x 32 queries) per block sharing one K/V tile stream: 4, 8 or 16
 #endif
@@ -157,10 +152,11 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     // and whose slot 1 is 1 for masked keys, Q by (-m_ref, -BIG) -- so the QK^T accumulator comes out as
     // s' = s - m_ref + key bias and p = exp2(s') needs no subtraction and no bias add (a per-row constant cancels
     // exactly between P and l, so the 16-bit rounding of m_ref is harmless; the product 1 x (-m_ref) is exact).
-    // m_ref is raised (O, l rescaled, s' corrected) only when a tile's maximum exceeds it by more than kLazy: p <= 2^kLazy
-    // stays inside f16's range, and since m_ref >= the first tile's exact maximum, smaller terms only underflow when
-    // they are negligible.  The first tile always takes the correction path (m_ref starts at 0).
-    constexpr float kLazy = 8.0f, kFloor = -20000.0f;
+    // m_ref is raised (O, l rescaled, s' recomputed) only when a lane's partial row sum of a tile exceeds kBig = 2^13: every
+    // p then fits f16 (and bf16) with room to spare, and since m_ref >= the first tile's exact maximum, smaller terms only
+    // underflow when they are negligible (2^-27 of the largest).  The first tile always takes the correction path (m_ref
+    // starts at 0).
+    constexpr float kBig = 8192.0f, kLazyTrain = 8.0f, kFloor = -20000.0f;
     unsigned drop_rh = 0;
     if constexpr (TRAIN) { if (a.drop.thresh16) drop_rh = a.drop.rowh[(size_t)nh * T + (query < T ? query : T - 1)]; }
     float m_ref = 0.f, l_run = 0.f;
@@ -208,57 +204,102 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
                     }
             }
         };
+        // ---- softmax numerators against the lazily raised reference
+        vec8 pf[4];
+        float psum[2];
         scores();
-        // ---- tile maximum relative to the reference, one query per lane (pair lane^32 shares the query)
-        float mx = s[0][0];
-        if constexpr (!(kAblNoMax && !TRAIN)) {
+        if constexpr (TRAIN) {
+            // Training variant (128 VGPRs with the dropout state; kept as straight-line code -- the lambda form of the
+            // inference branch below costs it two spilled registers): the per-tile maximum and its check sit in front of the exps.
+            float mx = s[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
             mx = xor32_max(mx);
-        }
-        if (kt == 0 || __any(mx > kLazy)) {
-            // Rare (and the first tile): raise the reference of the rows that need it, rescale their O and l, and
-            // RECOMPUTE the tile's scores with the new reference (subtracting the step from s' instead would keep the
-            // fp32 rounding of s - m_ref_old).  A fully masked tile (mx = -1e30) leaves the reference at kFloor: its
-            // probabilities are exactly 0 and the first tile with a valid key corrects from there.
-            const bool need = kt == 0 || mx > kLazy;
-            const float m_new = need ? (float)to16<P>(fmaxf(m_ref + mx, kFloor)) : m_ref;
-            const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
-            l_run *= alpha;
+            if (kt == 0 || __any(mx > kLazyTrain)) {
+                // Rare (and the first tile): raise the reference of the rows that need it, rescale their O and l, and
+                // RECOMPUTE the tile's scores with the new reference (subtracting the step from s' instead would keep the
+                // fp32 rounding of s - m_ref_old).  A fully masked tile (mx = -1e30) leaves the reference at kFloor: its
+                // probabilities are exactly 0 and the first tile with a valid key corrects from there.
+                const bool need = kt == 0 || mx > kLazyTrain;
+                const float m_new = need ? (float)to16<P>(fmaxf(m_ref + mx, kFloor)) : m_ref;
+                const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
+                l_run *= alpha;
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            m_ref = m_new;
-            if (hi == 0) qaug[0] = to16<P>(-m_ref);
-            scores();
-        }
-
-        vec8 pf[4];
-        float psum[2] = {0.f, 0.f};
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                m_ref = m_new;
+                if (hi == 0) qaug[0] = to16<P>(-m_ref);
+                scores();
+            }
+            psum[0] = 0.f; psum[1] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float p0, p1;
-                if constexpr (kAblNoExp && !TRAIN) { p0 = s[kb][r] * 0.001f; p1 = s[kb][r + 1] * 0.001f; }
-                else { p0 = __builtin_amdgcn_exp2f(s[kb][r]); p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]); }
-                if constexpr (!(kAblNoSum && !TRAIN)) {
+                for (int r = 0; r < 16; r += 2) {
+                    float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
                     psum[0] = add_f32_scalar(psum[0], p0);
                     psum[1] = add_f32_scalar(psum[1], p1);
-                }
-                if constexpr (TRAIN) {
                     if (a.drop.thresh16) {      // elements r, r+1 are keys 2j, 2j+1: one hash decides both (DropCfg, launch.h)
                         const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         const float2 f = drop_factors2(a.drop, drop_pair(drop_rh, a.drop.colh[key >> 1]));
                         p0 *= f.x; p1 *= f.y;
                     }
+                    pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p0);
+                    pf[kb * 2 + (r >> 3)][(r & 7) + 1] = to16<P>(p1);
                 }
-                pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p0);
-                pf[kb * 2 + (r >> 3)][(r & 7) + 1] = to16<P>(p1);
+        } else {
+            // Inference: NO per-element maximum in the common path.  p = exp2(s') is formed in fp32, and only when some lane's
+            // partial row sum of the tile exceeds kBig (a probability that would leave f16's comfortable range) are the maxima
+            // computed, the references of the rows above theirs raised, and the tile redone.  (On a SIMD a VALU instruction is
+            // issued instead of an MFMA; the 21 v_max3 / v_max per tile were 5 % of the kernel:
+            // profiles/r03_attention_sq_counters_and_ablation.txt.)
+            auto raise = [&](bool first) {      // same step as in the training branch, for every row above its reference
+                float mx = s[0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+                mx = xor32_max(mx);
+                const bool need = first || mx > 0.0f;
+                const float m_new = need ? (float)to16<P>(fmaxf(m_ref + mx, kFloor)) : m_ref;
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                m_ref = m_new;
+                if (hi == 0) qaug[0] = to16<P>(-m_ref);
+                scores();
+            };
+            auto numerators = [&]() {
+                psum[0] = 0.f; psum[1] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        float p0, p1;
+                        if constexpr (kAblNoExp) { p0 = s[kb][r] * 0.001f; p1 = s[kb][r + 1] * 0.001f; }
+                        else { p0 = __builtin_amdgcn_exp2f(s[kb][r]); p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]); }
+                        if constexpr (!kAblNoSum) {
+                            psum[0] = add_f32_scalar(psum[0], p0);
+                            psum[1] = add_f32_scalar(psum[1], p1);
+                        }
+                        pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p0);
+                        pf[kb * 2 + (r >> 3)][(r & 7) + 1] = to16<P>(p1);
+                    }
+            };
+            if (kt == 0) raise(true);        // the first tile starts from its exact maxima (m_ref starts at 0)
+            numerators();
+            if (kt != 0 && __any(!(psum[0] + psum[1] <= kBig))) {      // rare (the negated form also catches NaN sums: inf - inf)
+                scores();           // s' was consumed by the exps: recompute it against the old reference for the maxima
+                raise(false);
+                numerators();
             }
+        }
         l_run += psum[0] + psum[1];
 
         // ---- O^T += V^T . P^T
