@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
 #undef ST_TN_KSTEP
     };
 
-    // ---- K loop over this block's range of 64-frame chunks (item = chunk / chunks per item)
+    // ---- K loop over this block's range of 32-frame chunks (item = chunk / chunks per item)
     const int k0 = s * w.cps, nstage = min(kchunks, k0 + w.cps) - k0;
     auto issue_stage = [&](int st) { const int kx = k0 + st; issue(kx / nchunk, (kx % nchunk) * KF, st % NBUF); };
 #pragma unroll
