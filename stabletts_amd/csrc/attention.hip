@@ -115,8 +115,10 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     };
     auto issueKV = [&](int kt, int buf) {
         auto k_piece = [&](int piece) {
-            const int row = piece * 8 + (lane >> 3);
-            const int seg = (lane & 7) ^ ((row >> 1) & 7);
+            int ln = lane;
+            if constexpr (TRAIN) asm volatile("" : "+v"(ln));      // (recomputed per tile instead of held: the training variant has no spare register)
+            const int row = piece * 8 + (ln >> 3);
+            const int seg = (ln & 7) ^ ((row >> 1) & 7);
             const int key = min(kt * 64 + row, T - 1);
             glds16s(sgpr_ptr(kbase), (unsigned)(key * 128 + seg * 16), Ks + buf * TILE_BYTES + piece * 1024);
         };
@@ -238,17 +240,25 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                    psum[0] = add_f32_scalar(psum[0], p0);
-                    psum[1] = add_f32_scalar(psum[1], p1);
-                    if (a.drop.thresh16) {      // elements r, r+1 are keys 2j, 2j+1: one hash decides both (DropCfg, launch.h)
-                        const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const float2 f = drop_factors2(a.drop, drop_pair(drop_rh, a.drop.colh[key >> 1]));
-                        p0 *= f.x; p1 *= f.y;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    // elements 4 g4 .. 4 g4 + 3 are keys key0 .. key0 + 3 = two consecutive key pairs: one 8-byte table load, one
+                    // hash per pair decides both of its elements (DropCfg, launch.h)
+                    if (g4 == 2) __builtin_amdgcn_sched_barrier(0);      // (at most two table loads in flight: 128 VGPRs)
+                    uint2 ch = make_uint2(0u, 0u);
+                    if (a.drop.thresh16) ch = *(const uint2*)(a.drop.colh + ((kt * 64 + kb * 32 + 8 * g4 + 4 * hi) >> 1));
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = 4 * g4 + 2 * h2;
+                        float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                        psum[0] = add_f32_scalar(psum[0], p0);
+                        psum[1] = add_f32_scalar(psum[1], p1);
+                        if (a.drop.thresh16) {
+                            const float2 f = drop_factors2(a.drop, drop_pair(drop_rh, h2 ? ch.y : ch.x));
+                            p0 *= f.x; p1 *= f.y;
+                        }
+                        pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p0);
+                        pf[kb * 2 + (r >> 3)][(r & 7) + 1] = to16<P>(p1);
                     }
-                    pf[kb * 2 + (r >> 3)][r & 7] = to16<P>(p0);
-                    pf[kb * 2 + (r >> 3)][(r & 7) + 1] = to16<P>(p1);
                 }
         } else {
             // Inference: NO per-element maximum in the common path.  p = exp2(s') is formed in fp32, and only when some lane's
@@ -322,7 +332,12 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     const float l_tot = xor32_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if constexpr (TRAIN) {
-        if (hi == 0 && query < T) a.lse[(size_t)nh * T + query] = l_tot > 0.f ? m_run + log2f(l_tot) : 0.f;
+        // (the row index is re-derived here: hipcc otherwise carries its 64-bit form across the key loop -- two registers the
+        //  128-VGPR training variant does not have)
+        int lane_q = lane;
+        asm volatile("" : "+v"(lane_q));
+        const int query_e = qt * QB + wave * 32 + (lane_q & 31);
+        if ((lane_q >> 5) == 0 && query_e < T) a.lse[(size_t)nh * T + query_e] = l_tot > 0.f ? m_run + log2f(l_tot) : 0.f;
     }
     // Output through LDS: each wave parks its 32 x 64 tile as [query][d] (144-B pitch) in its own slice of the K/V
     // buffers (free after the loop's last barrier) and writes it out as 128-B rows, 16 B per lane -- 4 wide stores

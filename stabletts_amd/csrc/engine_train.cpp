@@ -83,8 +83,10 @@ int pack_T(st_engine* e, TrainState* ts, Conv& cv, const std::string& wname, int
            int ci_cnt, int cin_p, int ld, hipStream_t s) {
     cv.cout = cin_p; cv.cin = ld; cv.taps = taps; cv.split = false;
     const size_t bytes = (size_t)cin_p * taps * ld * 2;
-    if (!cv.w) { HIPCHK(e, hipMalloc(&cv.w, bytes)); ts->owned.push_back(cv.w); }
-    HIPCHK(e, hipMemsetAsync(cv.w, 0, bytes, s));
+    if (!cv.w) {        // the padding is zeroed once; a re-pack rewrites exactly the payload elements
+        HIPCHK(e, hipMalloc(&cv.w, bytes)); ts->owned.push_back(cv.w);
+        HIPCHK(e, hipMemsetAsync(cv.w, 0, bytes, s));
+    }
     HIPCHK(e, launch_pack_weight_t(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, cin_p, ld, 0, s));
     cv.bias = nullptr;
     return ST_OK;

@@ -405,10 +405,9 @@ def _mix32(h):
     return h ^ (h >> np.uint64(16))
 
 
-def _lowbias32(h):
-    h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x7feb352d)) & _M
-    h = h ^ (h >> np.uint64(15)); h = (h * np.uint64(0x846ca68b)) & _M
-    return h ^ (h >> np.uint64(16))
+def _pair32(x):                     # drop_pair (csrc/common.h): one odd multiply + xor-shift of rowh ^ colh
+    h = (x * np.uint64(0x9E3779B1)) & _M
+    return h ^ (h >> np.uint64(15))
 
 
 def _seed_words(seed, salt):
@@ -438,7 +437,7 @@ def _drop_attn(seed, salt, p, row, key):
     row = row.astype(np.uint64); key = key.astype(np.uint64)
     rh = _mix32(lo ^ ((row * np.uint64(0x9E3779B1)) & _M))
     ch = _mix32(hi ^ (((key >> np.uint64(1)) * np.uint64(0x85ebca77)) & _M))
-    return _keep16(_lowbias32(rh ^ ch), (key & np.uint64(1)) == 1, p)
+    return _keep16(_pair32(rh ^ ch), (key & np.uint64(1)) == 1, p)
 
 
 @pytest.mark.parametrize("dt,T,lengths,tiles", [("f16", 70, [70, 45], "policy"), ("f16", 250, [250, 181], "big")])
