@@ -44,7 +44,7 @@ namespace st {
 namespace {
 
 constexpr int kTile = 64 * 128;      // one 64 x 64 16-bit tile, dense 128-B rows, XOR-swizzled like attention.hip
-constexpr int kDkvLds = 8 * kTile + 4 * 2 * 64 * 4;      // dK/dV kernel: 4 tiles x 2 buffers + lse / D' / F / a rows
+constexpr int kDkvLds = 8 * kTile + 5 * 2 * 64 * 4;      // dK/dV kernel: 4 tiles x 2 buffers + lse / D' / F / a / dropout row-hash rows
 
 // natural-layout tile: 8 rows x 128 B per 1-KiB piece; rows >= T come from the zero page
 __device__ __forceinline__ void dma_rows(const unsigned char* base, size_t row_stride, int row0, int T, const unsigned char* zeros,
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
     float* D_t = lse_t + 2 * 64;
     float* F_t = D_t + 2 * 64;
     float* a_t = F_t + 2 * 64;
+    unsigned* rh_t = (unsigned*)(a_t + 2 * 64);     // dropout: rowh of the tile's queries (the same 64 values for every lane)
     constexpr bool dropping = DROP;
 
     const int T = a.T, Tp = a.Tp, H = a.H;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
     }
     const float bias_k = kok ? a.kbias[(size_t)mb * Tp + key] : -1e30f;
     const unsigned drop_ch = DROP ? a.drop.colh[(key < Tp ? key : Tp - 1) >> 1] : 0u;
+    const unsigned drop_shl = (key & 1) ? 0u : 16u, drop_thr = a.drop.thresh16 << 16;      // (odd key: high half of the pair hash)
 
     const int nq = ((kvend < T ? kvend : T) + 63) >> 6;      // queries past the last valid frame have d attn = 0: they add nothing
     auto issue = [&](int qt, int buf) {     // 4 tiles x 8 pieces over 4 waves: each wave moves pieces 2*wave, 2*wave+1 of every tile
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
             D_t[buf * 64 + lane] = qq < T ? a.Dq[(size_t)nh * T + qq] : 0.f;
             F_t[buf * 64 + lane] = qq < T ? a.Fq[(size_t)nh * T + qq] : 1.f;
             a_t[buf * 64 + lane] = qq < T ? a.aq[(size_t)nh * T + qq] : 0.f;
+            if (DROP) rh_t[buf * 64 + lane] = a.drop.rowh[(size_t)nh * T + (qq < T ? qq : T - 1)];
         }
     };
     int row_off[2], swz[2];
@@ -431,13 +434,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
                 const float fv[4] = {fz.x, fz.y, fz.z, fz.w}, av[4] = {az.x, az.y, az.z, az.w};
                 float fq4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (DROP) {     // this lane's key is one half of its pair: its own 16 bits of every query's pair hash (DropCfg, launch.h)
-                    const uint4 rh = *(const uint4*)(a.drop.rowh + (size_t)nh * T + qt * 64 + qb * 32 + 8 * g4 + 4 * hi);   // (table has a 64-entry tail)
+                    const uint4 rh = *(const uint4*)(rh_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                     const unsigned rhv[4] = {rh.x, rh.y, rh.z, rh.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float2 f2 = drop_factors2(a.drop, drop_pair(rhv[e], drop_ch));
-                        fq4[e] = (key & 1) ? f2.y : f2.x;
-                    }
+                    for (int e = 0; e < 4; ++e)      // the lane's half moved to the top 16 bits: one compare against thresh16 << 16
+                        fq4[e] = (drop_pair(rhv[e], drop_ch) << drop_shl) >= drop_thr ? a.drop.scale : 0.0f;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
