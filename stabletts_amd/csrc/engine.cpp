@@ -948,13 +948,12 @@ int pack_all(st_engine* e, hipStream_t s) {
         cv.cout = cout_p; cv.cin = split ? 3 * cin_p : cin_p; cv.taps = taps; cv.split = split;
         const size_t wbytes = (size_t)cout_p * taps * cv.cin * 2;
         int rc;
-        if (!cv.w && (rc = dev_alloc(e, &cv.w, wbytes))) return rc;
-        HIPCHK(e, hipMemsetAsync(cv.w, 0, wbytes, s));
+        // (the zero padding is written once, at allocation: a re-pack rewrites exactly the payload elements)
+        if (!cv.w) { if ((rc = dev_alloc(e, &cv.w, wbytes))) return rc; HIPCHK(e, hipMemsetAsync(cv.w, 0, wbytes, s)); }
         for (int part = 0; part < (split ? 3 : 1); ++part)
             HIPCHK(e, launch_pack_weight(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cv.cin,
                                          part * cin_p, cin_p, part == 2, s));
-        if (!cv.bias && (rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4))) return rc;
-        HIPCHK(e, hipMemsetAsync(cv.bias, 0, (size_t)cout_p * 4, s));
+        if (!cv.bias) { if ((rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4))) return rc; HIPCHK(e, hipMemsetAsync(cv.bias, 0, (size_t)cout_p * 4, s)); }
         if (bias_src) HIPCHK(e, hipMemcpyAsync(cv.bias, bias_src, (size_t)cout * 4, hipMemcpyDeviceToDevice, s));
         return ST_OK;
     };
