@@ -42,7 +42,9 @@ enum { ST_OPERAND_BF16 = 0, ST_OPERAND_F16 = 1 };
 enum { ST_SOLVER_EULER = 0, ST_SOLVER_MIDPOINT = 1, ST_SOLVER_RK4 = 2,
        ST_SOLVER_DOPRI5 = 3,  /* adaptive Dormand-Prince 5(4), rtol = atol = 1e-5: the reference default (solver=None) */
        /* the other explicit adaptive pairs of torchdiffeq offered by webui.py:110, same controller and tolerances */
-       ST_SOLVER_BOSH3 = 4, ST_SOLVER_FEHLBERG2 = 5, ST_SOLVER_ADAPTIVE_HEUN = 6 };
+       ST_SOLVER_BOSH3 = 4, ST_SOLVER_FEHLBERG2 = 5, ST_SOLVER_ADAPTIVE_HEUN = 6,
+       ST_SOLVER_IMPLICIT_ADAMS = 7 };  /* torchdiffeq 'implicit_adams' (webui.py:110): Adams-Bashforth-Moulton on the fixed grid of n_steps,
+                                           functional iteration of the corrector (<= 4 evaluations per step, rtol = atol = 1e-5) */
 
 /* Constructor arguments of reference CFMDecoder.__init__ (models/flow_matching.py:12). */
 typedef struct st_config {

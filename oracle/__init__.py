@@ -26,6 +26,6 @@ from .weights import (DecoderConfig, make_state_dict, make_cfg_params,  # noqa: 
 from .estimator_oracle import (  # noqa: F401
     decoder_forward, cfm_forward, cfg_wrapper, compute_loss, odeint_fixed,
     sinusoidal_pos_emb, rope, attention, ffn, dit_block, linspace_f32, odeint_dopri5,
-    dit_conv_block, text_encoder_forward, odeint_adaptive, ADAPTIVE_TABLEAUS,
+    dit_conv_block, text_encoder_forward, odeint_adaptive, ADAPTIVE_TABLEAUS, odeint_implicit_adams, adams_coefficients,
 )
 from .inputs import make_inputs  # noqa: F401

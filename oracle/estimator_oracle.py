@@ -278,6 +278,86 @@ def odeint_fixed(f, y0, t_span, method="euler"):
     return y
 
 
+def adams_coefficients(order):
+    """Exact Adams-Bashforth / Adams-Moulton weights for a uniform grid, newest sample first:
+    y1 - y0 = dt * sum_i bashforth[i] * f(t0 - i dt)            (order samples, explicit)
+    y1 - y0 = dt * (moulton[0] * f(t1) + sum_i moulton[i + 1] * f(t0 - i dt))   (order samples, implicit)
+    from the defining integrals of the Lagrange basis over [0, 1] (unit step), in rational arithmetic.  torchdiffeq's
+    fixed_adams.py stores the same numbers as integer tables over a divisor (e.g. [55, -59, 37, -9] / 24 and
+    [9, 19, -5, 1] / 24 for four samples)."""
+    from fractions import Fraction
+
+    def weights(nodes):
+        out = []
+        for j, xj in enumerate(nodes):
+            poly = [Fraction(1)]                    # coefficients of prod_{i != j} (u - x_i), lowest degree first
+            den = Fraction(1)
+            for i, xi in enumerate(nodes):
+                if i == j:
+                    continue
+                poly = [Fraction(0)] + poly
+                for k in range(len(poly) - 1):
+                    poly[k] -= xi * poly[k + 1]
+                den *= (xj - xi)
+            out.append(sum(c / (k + 1) for k, c in enumerate(poly)) / den)      # integral over [0, 1]
+        return out
+
+    bashforth = weights([Fraction(-i) for i in range(order)])          # samples at u = 0, -1, -2, ...
+    moulton = weights([Fraction(1)] + [Fraction(-i) for i in range(order - 1)])
+    return [float(x) for x in bashforth], [float(x) for x in moulton]
+
+
+def odeint_implicit_adams(f, y0, t_span, rtol=1e-5, atol=1e-5, max_order=12, max_iters=4, stats=None):
+    """torchdiffeq's 'implicit_adams' (fixed_adams.py: AdamsBashforthMoulton on the fixed grid t_span, as offered by the
+    reference's webui.py:110 and called at models/flow_matching.py:54 with rtol = atol = 1e-5), restated from memory of the
+    published source -- torchdiffeq is absent offline: PARITY UNPINNED.  Per grid step:
+      f0 = f(t0, y0) joins the history (newest first, at most max_order - 1 entries); with fewer than 3 entries the step
+      is the 3/8-rule Runge-Kutta step reusing f0 (rk4_alt_step_func); otherwise an Adams-Bashforth predictor of the
+      history's length followed by functional iteration of the Adams-Moulton corrector with one more sample,
+      dy <- dt * m0 * f(t1, y0 + dy) + delta, at most max_iters times, stopping when
+      max |dy_old - dy| / (atol + rtol * max(|dy_old|, |dy|)) < 1; if the iteration does not converge the OLDEST history
+      entry is dropped (and torchdiffeq warns).  y1 = y0 + dy."""
+    import collections
+    prev_f = collections.deque(maxlen=max_order - 1)
+    y = y0
+    nfe = 0
+    for i in range(len(t_span) - 1):
+        t0, t1 = t_span[i], t_span[i + 1]
+        dt = t1 - t0
+        f0 = f(t0, y)
+        nfe += 1
+        prev_f.appendleft(f0)
+        order = min(len(prev_f), max_order - 1)
+        if order < 3:
+            k1 = f0
+            k2 = f(t0 + dt / 3, y + dt * k1 / 3)
+            k3 = f(t0 + dt * 2 / 3, y + dt * (k2 - k1 / 3))
+            k4 = f(t1, y + dt * (k1 - k2 + k3))
+            nfe += 3
+            dy = (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        else:
+            bash, _ = adams_coefficients(order)
+            _, moul = adams_coefficients(order + 1)
+            dy = sum((dt * b) * fj for b, fj in zip(bash, prev_f))
+            delta = dt * sum(m * fj for m, fj in zip(moul[1:], prev_f))
+            converged = False
+            for _ in range(max_iters):
+                dy_old = dy
+                fn = f(t1, y + dy)
+                nfe += 1
+                dy = (dt * moul[0]) * fn + delta
+                tol = atol + rtol * torch.max(dy_old.abs(), dy.abs())
+                converged = bool(((dy_old - dy).abs() / tol).max() < 1)
+                if converged:
+                    break
+            if not converged:
+                prev_f.pop()
+        y = y + dy
+    if stats is not None:
+        stats.update(nfe=nfe)
+    return y
+
+
 # Dormand-Prince 5(4) tableau and controller constants of torchdiffeq 0.2.x (rk_common.py, dopri5.py,
 # misc.py), restated from the published algorithm -- torchdiffeq is not installable offline: PARITY UNPINNED.
 _DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
@@ -405,6 +485,8 @@ def cfm_forward(sd, mu, mask, n_timesteps, z, c, solver="euler", cfg_kwargs=None
         return odeint_dopri5(f, z, float(t_span[-1]))
     if solver in ADAPTIVE_TABLEAUS:
         return odeint_adaptive(f, z, solver, float(t_span[-1]))
+    if solver == "implicit_adams":
+        return odeint_implicit_adams(f, z, t_span)
     return odeint_fixed(f, z, t_span, solver)
 
 

@@ -13,12 +13,13 @@ ST_OK = 0
 ST_ERR_INVALID, ST_ERR_HIP, ST_ERR_STATE, ST_ERR_UNSUPPORTED = -1, -2, -3, -4
 ST_OPERAND_BF16, ST_OPERAND_F16 = 0, 1
 ST_SOLVER_EULER, ST_SOLVER_MIDPOINT, ST_SOLVER_RK4, ST_SOLVER_DOPRI5 = 0, 1, 2, 3
-ST_SOLVER_BOSH3, ST_SOLVER_FEHLBERG2, ST_SOLVER_ADAPTIVE_HEUN = 4, 5, 6
+ST_SOLVER_BOSH3, ST_SOLVER_FEHLBERG2, ST_SOLVER_ADAPTIVE_HEUN, ST_SOLVER_IMPLICIT_ADAMS = 4, 5, 6, 7
 OPERAND_DTYPES = {"bf16": ST_OPERAND_BF16, "f16": ST_OPERAND_F16, "fp16": ST_OPERAND_F16}
 # None is torchdiffeq's default method = dopri5 (models/flow_matching.py:54)
 SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_SOLVER_RK4,
            "dopri5": ST_SOLVER_DOPRI5, None: ST_SOLVER_DOPRI5, "bosh3": ST_SOLVER_BOSH3,
-           "fehlberg2": ST_SOLVER_FEHLBERG2, "adaptive_heun": ST_SOLVER_ADAPTIVE_HEUN}
+           "fehlberg2": ST_SOLVER_FEHLBERG2, "adaptive_heun": ST_SOLVER_ADAPTIVE_HEUN,
+           "implicit_adams": ST_SOLVER_IMPLICIT_ADAMS}      # = every method the reference's webui.py:110 offers
 
 # every symbol include/stabletts_hip.h declares
 EXPORTS = [

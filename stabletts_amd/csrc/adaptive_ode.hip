@@ -48,6 +48,16 @@ __global__ __launch_bounds__(256) void ode_norm_partial_kernel(const OdeNormArgs
                 const float q = dd[e] / (a.atol + a.rtol * fabsf(yy[e]));
                 s0 += q * q;
             }
+        } else if (a.mode == 3) {
+            // implicit Adams corrector: number of elements whose |a - b| / (atol + rtol max(|a|, |b|)) is not < 1
+            // (torchdiffeq's max-norm convergence test: converged iff the count is 0; NaN counts)
+            const float4 p0 = *(const float4*)(a.a + i), p1 = *(const float4*)(a.b + i);
+            const float av[4] = {p0.x, p0.y, p0.z, p0.w}, bv[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = fabsf(av[e] - bv[e]) / (a.atol + a.rtol * fmaxf(fabsf(av[e]), fabsf(bv[e])));
+                s0 += (q < 1.0f) ? 0.f : 1.f;
+            }
         } else {
             const float4 y1 = *(const float4*)(a.a + i);
             const float y1v[4] = {y1.x, y1.y, y1.z, y1.w};

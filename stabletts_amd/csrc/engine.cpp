@@ -11,6 +11,7 @@
 #include <iterator>
 #include <map>
 #include <string>
+#include <deque>
 #include <vector>
 
 using namespace st;
@@ -737,6 +738,135 @@ int solve_adaptive(st_engine* e, const Plan& p, const float* mask, int use_cfg, 
     return e->fail(ST_ERR_INVALID, std::string(tb.name) + ": too many steps");
 }
 
+std::vector<float> linspace01(int n);
+
+// Exact Adams-Bashforth / Adams-Moulton weights for `order` samples on a uniform grid, newest first (bashforth: samples at
+// t0, t0 - dt, ...; moulton: t1, t0, t0 - dt, ...), from the integrals of the Lagrange basis over one step.  Long double is
+// ample for order <= 12 (the integer tables torchdiffeq stores are these numbers over a common divisor).
+static void adams_weights(int order, bool implicit, double* w) {
+    std::vector<long double> nodes((size_t)order);
+    for (int i = 0; i < order; ++i) nodes[(size_t)i] = implicit ? (i == 0 ? 1.0L : -(long double)(i - 1)) : -(long double)i;
+    for (int j = 0; j < order; ++j) {
+        std::vector<long double> poly(1, 1.0L);     // prod_{i != j} (u - x_i), lowest degree first
+        long double den = 1.0L;
+        for (int i = 0; i < order; ++i) {
+            if (i == j) continue;
+            poly.insert(poly.begin(), 0.0L);
+            for (size_t k = 0; k + 1 < poly.size(); ++k) poly[k] -= nodes[(size_t)i] * poly[k + 1];
+            den *= nodes[(size_t)j] - nodes[(size_t)i];
+        }
+        long double integ = 0.0L;
+        for (size_t k = 0; k < poly.size(); ++k) integ += poly[k] / (long double)(k + 1);
+        w[j] = (double)(integ / den);
+    }
+}
+
+// torchdiffeq's 'implicit_adams' (fixed_adams.py: AdamsBashforthMoulton, max_order 12, max_iters 4) on the fixed grid of
+// models/flow_matching.py:46, rtol = atol = 1e-5 as at :54 -- the eighth solver the reference's web UI offers (webui.py:110).
+// Restated from the published source (oracle: odeint_implicit_adams, which says PARITY UNPINNED: torchdiffeq is absent offline).
+// Per step: f0 = f(t0, y0) joins the history (newest first, <= 11 entries); fewer than 3 entries -> 3/8-rule Runge-Kutta step
+// reusing f0; otherwise Adams-Bashforth predictor over the history, then functional iteration of the Adams-Moulton corrector
+// dy <- dt m0 f(t1, y0 + dy) + delta until max |dy_old - dy| / (atol + rtol max(|dy_old|, |dy|)) < 1 (one device reduction and
+// an 8-byte read-back per iteration), at most 4 times; no convergence -> the oldest history entry is dropped.
+int solve_implicit_adams(st_engine* e, const Plan& p, const float* mask, int use_cfg, float cfg_strength, int n_steps,
+                         hipStream_t s) {
+    constexpr int kMaxHist = 11, kMaxIters = 4, kExtra = 11;
+    const double rtol = 1e-5, atol = 1e-5;
+    const int B = p.B;
+    const int64_t per_item = (int64_t)p.T * e->Mp;
+    const int64_t nstate = (int64_t)B * per_item;
+    const size_t sbytes = (size_t)nstate * 4;
+    int rc;
+    // 19 state-sized fp32 buffers: 11 history + zero + dy x 2 + delta + f / Runge-Kutta stages x 3 + 1 spare; the plan has 8
+    if (e->adams_bytes < sbytes * kExtra) {
+        if (e->adams_buf) { HIPCHK(e, hipStreamSynchronize(s)); hipFree(e->adams_buf); e->adams_buf = nullptr; e->adams_bytes = 0; }
+        HIPCHK(e, hipMalloc(&e->adams_buf, sbytes * kExtra));
+        e->adams_bytes = sbytes * kExtra;
+    }
+    std::vector<float*> pool;
+    for (int j = 0; j < 7; ++j) pool.push_back(p.kbuf[j]);
+    pool.push_back(p.ynew);
+    for (int j = 0; j < kExtra; ++j) pool.push_back((float*)((char*)e->adams_buf + (size_t)j * sbytes));
+    float* zero = pool.back(); pool.pop_back();
+    float* dyA = pool.back(); pool.pop_back();
+    float* dyB = pool.back(); pool.pop_back();
+    float* delta = pool.back(); pool.pop_back();
+    float* tmp[3]; for (int j = 0; j < 3; ++j) { tmp[j] = pool.back(); pool.pop_back(); }
+    HIPCHK(e, hipMemsetAsync(zero, 0, sbytes, s));
+    std::deque<float*> hist;        // newest first; `pool` holds the free buffers (>= 12 left)
+    auto eval = [&](float t, float* kout) -> int {
+        HIPCHK(e, launch_set_scalar(p.tvals, t, s));
+        int r = run_time_tables(e, p, s); if (r) return r;
+        r = run_estimator(e, p, mask, 0, s); if (r) return r;
+        ProfScope ps(e, s, PC_ODE, 0);
+        HIPCHK(e, launch_cfg_combine(e->dt, p.v32, B, per_item, use_cfg, cfg_strength, kout, nullptr, nullptr, nullptr, 0.f, s));
+        e->last_nfe += 1;
+        return ST_OK;
+    };
+    // out = base + sum_j cf[j] * ks[j] for any number of terms (lincomb takes 7 at a time); optionally also the operand pair
+    auto combine = [&](const float* base, const std::vector<const float*>& ks, const std::vector<float>& cf, float* out32, bool operands) -> int {
+        size_t done = 0;
+        const float* cur = base;
+        do {
+            const int nk = (int)std::min<size_t>(7, ks.size() - done);
+            const bool last = done + (size_t)nk == ks.size();
+            ProfScope ps(e, s, PC_ODE, 0);
+            HIPCHK(e, launch_lincomb(e->dt, cur, ks.data() + done, cf.data() + done, nk, nstate, out32,
+                                     last && operands ? p.x16 : nullptr, last && operands ? p.x16lo : nullptr, s));
+            cur = out32; done += (size_t)nk;
+        } while (done < ks.size());
+        return ST_OK;
+    };
+    float* y = p.xstate;
+    const std::vector<float> grid = linspace01(n_steps);
+    float host2[2];
+    for (int i = 0; i < n_steps; ++i) {
+        const float t0 = grid[(size_t)i], t1 = grid[(size_t)i + 1], dt = t1 - t0;
+        // f0 = f(t0, y)  (x16 holds y); joins the history
+        if ((int)hist.size() == kMaxHist) { pool.push_back(hist.back()); hist.pop_back(); }
+        float* f0 = pool.back(); pool.pop_back();
+        if ((rc = eval(t0, f0))) return rc;
+        hist.push_front(f0);
+        const int order = (int)hist.size();
+        if (order < 3) {        // rk4_alt_step_func with k1 = f0
+            if ((rc = combine(y, {f0}, {dt / 3.0f}, nullptr, true))) return rc;
+            if ((rc = eval(t0 + dt / 3.0f, tmp[0]))) return rc;
+            if ((rc = combine(y, {tmp[0], f0}, {dt, -dt / 3.0f}, nullptr, true))) return rc;
+            if ((rc = eval(t0 + dt * 2.0f / 3.0f, tmp[1]))) return rc;
+            if ((rc = combine(y, {f0, tmp[0], tmp[1]}, {dt, -dt, dt}, nullptr, true))) return rc;
+            if ((rc = eval(t1, tmp[2]))) return rc;
+            if ((rc = combine(y, {f0, tmp[0], tmp[1], tmp[2]}, {dt * 0.125f, dt * 0.375f, dt * 0.375f, dt * 0.125f}, y, true))) return rc;
+            continue;
+        }
+        double wb[12], wm[13];
+        adams_weights(order, false, wb);
+        adams_weights(order + 1, true, wm);
+        std::vector<const float*> hs(hist.begin(), hist.end());
+        std::vector<float> cb((size_t)order), cm((size_t)order);
+        for (int j = 0; j < order; ++j) { cb[(size_t)j] = (float)((double)dt * wb[j]); cm[(size_t)j] = (float)((double)dt * wm[j + 1]); }
+        float* dy = dyA; float* dyn = dyB;
+        if ((rc = combine(zero, hs, cb, dy, false))) return rc;             // predictor
+        if ((rc = combine(zero, hs, cm, delta, false))) return rc;
+        bool converged = false;
+        for (int it = 0; it < kMaxIters && !converged; ++it) {
+            if ((rc = combine(y, {dy}, {1.0f}, nullptr, true))) return rc;      // operands of f(t1, y + dy)
+            if ((rc = eval(t1, tmp[0]))) return rc;
+            if ((rc = combine(delta, {tmp[0]}, {(float)((double)dt * wm[0])}, dyn, false))) return rc;
+            OdeNormArgs na; memset(&na, 0, sizeof(na));
+            na.mode = 3; na.y = dy; na.a = dy; na.b = dyn; na.rtol = (float)rtol; na.atol = (float)atol; na.n = nstate;
+            na.partial = p.ode_partial; na.out = p.ode_out;
+            HIPCHK(e, launch_ode_norm(na, s));
+            HIPCHK(e, hipMemcpyAsync(host2, p.ode_out, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(e, hipStreamSynchronize(s));
+            converged = host2[0] == 0.0f;
+            std::swap(dy, dyn);
+        }
+        if (!converged) { pool.push_back(hist.back()); hist.pop_back(); e->last_rejects += 1; }     // (torchdiffeq warns and drops the oldest sample)
+        if ((rc = combine(y, {dy}, {1.0f}, y, true))) return rc;            // y1 = y0 + dy, and its operands for the next f0
+    }
+    return ST_OK;
+}
+
 int check_ready(st_engine* e, int B, int T) {
     if (!e) return ST_ERR_INVALID;
     if (!e->finalized) return e->fail(ST_ERR_STATE, "st_finalize() has not been called after loading parameters");
@@ -840,6 +970,7 @@ void st_destroy(st_engine* e) {
     prof_collect(e);
     for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
     if (e->ws) hipFree(e->ws);
+    if (e->adams_buf) hipFree(e->adams_buf);
     if (e->rope_cos) hipFree(e->rope_cos);
     if (e->rope_sin) hipFree(e->rope_sin);
     if (e->zeros) hipFree(e->zeros);
@@ -1042,13 +1173,14 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     if (e->kind != 0) return e->fail(ST_ERR_STATE, "this handle is not a CFM decoder (st_create)");
     if (!mu || !mask || !z || !c || !out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     if (n_steps < 1 || n_steps > 4096) return e->fail(ST_ERR_INVALID, "n_steps out of range");
-    if (solver < ST_SOLVER_EULER || solver > ST_SOLVER_ADAPTIVE_HEUN)
+    if (solver < ST_SOLVER_EULER || solver > ST_SOLVER_IMPLICIT_ADAMS)
         return e->fail(ST_ERR_UNSUPPORTED, "solver not implemented natively (euler, midpoint, rk4, dopri5, bosh3, "
-                                           "fehlberg2, adaptive_heun are)");
+                                           "fehlberg2, adaptive_heun, implicit_adams are)");
     if (use_cfg && (!fake_speaker || !fake_content)) return e->fail(ST_ERR_INVALID, "CFG needs fake_speaker and fake_content");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    const bool adaptive = solver >= ST_SOLVER_DOPRI5;
+    const bool adams = solver == ST_SOLVER_IMPLICIT_ADAMS;
+    const bool adaptive = solver >= ST_SOLVER_DOPRI5;      // host-side controller: one part, eager, time tables per evaluation (incl. implicit Adams)
     const RkTableau& tableau = solver == ST_SOLVER_BOSH3 ? kBosh3 : solver == ST_SOLVER_FEHLBERG2 ? kFehlberg2
                              : solver == ST_SOLVER_ADAPTIVE_HEUN ? kAdaptiveHeun : kDopri5;
     const int stages = solver == ST_SOLVER_EULER ? 1 : (solver == ST_SOLVER_MIDPOINT ? 2 : 4);
@@ -1123,7 +1255,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
                                          (char*)p.mu16 + (size_t)pt.nb * per_item * 2, s));
         }
     }
-    e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive ? 0 : n_steps; e->last_rejects = 0;
+    e->last_nfe = adaptive ? 0 : (int64_t)n_t; e->last_steps = adaptive && !adams ? 0 : n_steps; e->last_rejects = 0;
 
     // One solver step of one part (fixed grid): estimator evaluation(s) + state update.
     auto step_fixed = [&](const Part& pt, int i, hipStream_t ps_) -> int {
@@ -1188,7 +1320,9 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
             if ((rc = run_adaln(e, pt.p, pt.s))) return rc;
             if (!adaptive && (rc = run_time_tables(e, pt.p, pt.s))) return rc;
         }
-        if (adaptive) {
+        if (adams) {
+            if ((rc = solve_implicit_adams(e, parts[0].p, parts[0].mask, use_cfg, cfg_strength, n_steps, cs))) return rc;
+        } else if (adaptive) {
             if ((rc = solve_adaptive(e, parts[0].p, parts[0].mask, use_cfg, cfg_strength, tableau, cs))) return rc;
         } else {
             for (int i = 0; i < n_steps; ++i)
@@ -1241,7 +1375,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
     if (!done) { brc = body(s); e->conc = 1; if (brc) return brc; }
     for (auto& pt : parts) {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_from_time_major(adaptive ? pt.p.ynew : pt.p.xstate, pt.nb, e->M, T, e->Mp, out + pt.b0 * bct, s));
+        HIPCHK(e, launch_from_time_major(adaptive && !adams ? pt.p.ynew : pt.p.xstate, pt.nb, e->M, T, e->Mp, out + pt.b0 * bct, s));
     }
     return ST_OK;
 }

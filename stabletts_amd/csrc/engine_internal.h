@@ -92,6 +92,7 @@ struct st_engine {
 
     // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
+    void* adams_buf = nullptr; size_t adams_bytes = 0;     // extra state buffers of the implicit Adams solver (allocated at its first use)
     int big_min_blocks = 192;
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)

@@ -165,6 +165,7 @@ hipError_t launch_set_scalar(float* dst, float v, hipStream_t s);
 //   mode 0: out[0] = sum (y/scale)^2, out[1] = sum (f/scale)^2            scale = atol + rtol*|y|      (a=y, b=f)
 //   mode 1: out[0] = sum ((b - a)/scale)^2                                scale = atol + rtol*|y|      (a=f0, b=f1)
 //   mode 2: out[0] = sum (err/tol)^2, err = sum_j coef[j]*k[j], tol = atol + rtol*max(|y|,|y1|)      (a = y1)
+//   mode 3: out[0] = number of elements with |a - b| / (atol + rtol*max(|a|,|b|)) not < 1   (implicit Adams corrector; y = any valid pointer)
 struct OdeNormArgs { const float* y; const float* a; const float* b; const float* k[7]; float coef[7]; int nk;
                      float rtol, atol; int64_t n; int mode; float* partial; float* out; };
 hipError_t launch_ode_norm(const OdeNormArgs& a, hipStream_t s);

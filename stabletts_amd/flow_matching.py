@@ -10,9 +10,10 @@ Differences from the reference, all additive:
     the shim multiplies by ``temperature`` exactly like :45) so parity tests can fix the noise.
   * ``solver``: 'euler', 'midpoint', 'rk4' (fixed grid), 'dopri5' / ``None`` (torchdiffeq's default: adaptive
     Dormand-Prince 5(4), rtol = atol = 1e-5 as at :54) and the other explicit adaptive pairs 'bosh3',
-    'fehlberg2', 'adaptive_heun' are native end to end; for the remaining torchdiffeq methods ('implicit_adams',
-    ...) torchdiffeq's controller runs around the native estimator when torchdiffeq is installed, else
-    NotImplementedError is raised (torchdiffeq is not a dependency of this package).
+    'fehlberg2', 'adaptive_heun' and the fixed-grid multistep 'implicit_adams' are native end to end -- every method the
+    reference's web UI offers (webui.py:110); for any other torchdiffeq method name torchdiffeq's controller runs around the
+    native estimator when torchdiffeq is installed, else NotImplementedError is raised (torchdiffeq is not a dependency of
+    this package).
   * ``operand_dtype``: MFMA operand type, 'f16' (default: the configuration that meets the 1e-3 parity bar against
     the fp32 reference on every metric) or 'bf16' (same speed, 8 mantissa bits: ~4e-3; for checkpoints whose
     activations exceed f16's range); accumulation / residual stream / LayerNorm / softmax statistics / ODE state
@@ -76,8 +77,8 @@ class CFMDecoder(nn.Module):
         return out
 
     def _solve_with_torchdiffeq(self, mu, mask, n_timesteps, temperature, c, solver, cfg_kwargs, z):
-        """Solvers without a native controller (torchdiffeq's implicit_adams, ... offered by the reference's
-        webui.py:110): torchdiffeq drives the time stepping exactly as at
+        """Solvers without a native controller (torchdiffeq methods the reference's web UI does not list, e.g.
+        'explicit_adams', 'tsit5'): torchdiffeq drives the time stepping exactly as at
         models/flow_matching.py:49-55, and every vector-field evaluation it asks for is the NATIVE estimator
         (st_estimator_forward, both CFG branches) -- only the step controller runs in Python.  torchdiffeq is not
         a dependency of this package: without it these solvers raise NotImplementedError."""
@@ -86,7 +87,7 @@ class CFMDecoder(nn.Module):
         except ImportError as e:
             raise NotImplementedError(
                 f"solver={solver!r}: native solvers are euler, midpoint, rk4 (fixed grid), dopri5 (adaptive; also the "
-                "reference default solver=None), bosh3, fehlberg2, adaptive_heun; other torchdiffeq methods need torchdiffeq installed "
+                "reference default solver=None), bosh3, fehlberg2, adaptive_heun, implicit_adams; other torchdiffeq methods need torchdiffeq installed "
                 "(they then run its controller around the native estimator)") from e
         if c is None:
             raise ValueError("c (speaker embedding, (B, gin_channels)) is required")

@@ -75,8 +75,10 @@ def test_shim_mirrors_reference_interface():
     assert params[:7] == ["mu", "mask", "n_timesteps", "temperature", "c", "solver", "cfg_kwargs"]
     # adaLN-Zero init like the reference (estimator.py:98-101)
     assert float(sd["blocks.0.block.adaLN_modulation.2.weight"].abs().max()) == 0.0
-    with pytest.raises(NotImplementedError):
-        dec(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), "implicit_adams")
+    with pytest.raises(NotImplementedError):      # a torchdiffeq method without a native controller (every webui.py:110 method has one)
+        dec(torch.zeros(1, 128, 8), torch.ones(1, 1, 8), 2, 1.0, torch.zeros(1, 256), "explicit_adams")
+    from stabletts_amd import _lib
+    assert set(_lib.SOLVERS) >= {"euler", "midpoint", "dopri5", "rk4", "implicit_adams", "bosh3", "fehlberg2", "adaptive_heun", None}
     with pytest.raises(AssertionError):
         CFMDecoder(128, 128, 256, 128, 1024, 4, 5, 3, 0.1, 256)       # n_layers % 2 (estimator.py:92)
     with pytest.raises(RuntimeError, match="no CPU fallback"):        # training path is native too: no CPU fallback either

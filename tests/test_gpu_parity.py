@@ -345,6 +345,33 @@ def test_other_adaptive_solvers_vs_oracle(decoders, sd, cfg_params, solver, stag
     assert float((out - ref).abs().max() / (ref - inp["z"]).abs().max()) <= 8e-3
 
 
+@pytest.mark.parametrize("use_cfg,n", [(False, 10), (True, 6)])
+def test_implicit_adams_vs_oracle(decoders, sd, cfg_params, use_cfg, n):
+    """torchdiffeq's 'implicit_adams' (the last of the methods webui.py:110 offers), native: Runge-Kutta start-up steps,
+    Adams-Bashforth predictor, functional iteration of the Adams-Moulton corrector with the max-norm convergence test on the
+    device.  vs oracle.odeint_implicit_adams (restated, parity unpinned) on the same inputs; f16 operands.  The corrector's
+    iteration count is a discrete decision on a 16-bit-operand field: the evaluation counts may differ by a few."""
+    inp = make_inputs(2, 40, seed=37, lengths=[40, 29])
+    kw = _cfg(cfg_params, 2.0, False) if use_cfg else None
+    stats = {}
+    t_span = oracle.linspace_f32(n)
+    if use_cfg:
+        f = lambda t, x: oracle.cfg_wrapper(sd, t, x, inp["mask"], inp["mu"], inp["c"], kw["fake_speaker"], kw["fake_content"], kw["cfg_strength"])
+    else:
+        f = lambda t, x: oracle.decoder_forward(sd, t, x, inp["mask"], inp["mu"], inp["c"])
+    with torch.inference_mode():
+        ref = oracle.odeint_implicit_adams(f, inp["z"], t_span, stats=stats)
+        assert torch.equal(ref, oracle.cfm_forward(sd, inp["mu"], inp["mask"], n, inp["z"], inp["c"], "implicit_adams", kw))
+    out = _solve(decoders["f16"], inp, n, "implicit_adams", _cfg(cfg_params, 2.0, True) if use_cfg else None, inp["z"])
+    st = decoders["f16"].estimator.engine().last_solve_stats()
+    assert st["steps"] == n and abs(st["nfe"] - stats["nfe"]) <= n, (st, stats)
+    assert torch.isfinite(out).all()
+    assert _rel(out, ref) <= 1e-3
+    assert float((out - ref).abs().max() / (ref - inp["z"]).abs().max()) <= 8e-3
+    pad = ~inp["mask"].bool().expand_as(out)
+    assert torch.equal(out[pad], inp["z"][pad])
+
+
 def test_attention_rescale_branch_with_peaky_scores(sd):
     """Online-softmax rescale path: with q/k projections scaled 6x the row maxima keep growing across key tiles
     by more than the deferred-rescale threshold, so the (otherwise rare) rescale branch of attention.hip runs on

@@ -247,6 +247,47 @@ def test_fixed_grid_rules_have_their_classical_order():
         assert abs(float(y[0]) - taylor) < 1e-14, method
 
 
+def test_implicit_adams_oracle_coefficients_and_behaviour():
+    """oracle.odeint_implicit_adams (torchdiffeq's 'implicit_adams', restated: PARITY UNPINNED).  What CAN be pinned offline:
+    the Adams-Bashforth / Adams-Moulton weights equal the published integer tables over their divisors, integrate
+    polynomials of degree < order exactly, the start-up steps are the 3/8-rule Runge-Kutta steps of oracle.odeint_fixed, and
+    the scheme converges at high order on a smooth linear problem with the expected number of evaluations."""
+    import math
+    import numpy as np
+    import torch
+    import oracle
+    from oracle.estimator_oracle import adams_coefficients, odeint_implicit_adams
+    published = {     # (bashforth numerators, moulton numerators, divisor): the tables of any numerical-analysis text / fixed_adams.py
+        1: ([1], [1], 1), 2: ([3, -1], [1, 1], 2), 3: ([23, -16, 5], [5, 8, -1], 12),
+        4: ([55, -59, 37, -9], [9, 19, -5, 1], 24), 5: ([1901, -2774, 2616, -1274, 251], [251, 646, -264, 106, -19], 720),
+        6: ([4277, -7923, 9982, -7298, 2877, -475], [475, 1427, -798, 482, -173, 27], 1440)}
+    for k, (bn, mn, div) in published.items():
+        b, m = adams_coefficients(k)
+        assert np.allclose(np.array(b) * div, bn, atol=1e-9) and np.allclose(np.array(m) * div, mn, atol=1e-9), k
+    for k in range(1, 13):
+        b, m = adams_coefficients(k)
+        for deg in range(k):          # integral over [0, 1] of u^deg from its samples at 0, -1, ... (explicit) / 1, 0, -1, ... (implicit)
+            exact = 1.0 / (deg + 1)
+            eb = sum(w * (float(-i) ** deg if (i or deg) else 1.0) for i, w in enumerate(b))
+            nodes = [1.0] + [float(-i) for i in range(k - 1)]
+            em = sum(w * (x ** deg if (x or deg) else 1.0) for w, x in zip(m, nodes))
+            scale = float(k) ** deg                   # the sums cancel: tolerance relative to the terms' magnitude
+            assert abs(eb - exact) < 1e-13 * scale * sum(abs(w) for w in b) + 1e-14, (k, deg)
+            assert abs(em - exact) < 1e-13 * scale * sum(abs(w) for w in m) + 1e-14, (k, deg)
+    f = lambda t, y: -2 * y + torch.sin(3 * t)
+    y0 = torch.tensor([1.0], dtype=torch.float64)
+    exact = (1 + 3 / 13) * math.exp(-2.0) + (2 * math.sin(3.0) - 3 * math.cos(3.0)) / 13
+    ts = torch.linspace(0, 1, 3, dtype=torch.float64)            # two steps: both are Runge-Kutta start-up steps
+    assert torch.equal(odeint_implicit_adams(f, y0, ts), oracle.odeint_fixed(f, y0, ts, "rk4"))
+    errs = {}
+    for n in (10, 20, 40):
+        st = {}
+        y = odeint_implicit_adams(f, y0, torch.linspace(0, 1, n + 1, dtype=torch.float64), stats=st)
+        errs[n] = abs(float(y) - exact)
+        assert 8 + (n - 2) * 2 <= st["nfe"] <= 8 + (n - 2) * 5            # 2 x 4 start-up evaluations, then 1 + (1..4) per step
+    assert errs[10] < 1e-5 and errs[40] < errs[10] * 1e-3
+
+
 def test_alignment_oracle_matches_reference_fixture():
     """oracle.align_oracle (numpy restatement of models/model.py:17-27,85-95) vs outputs of the REAL generate_path /
     sequence_mask (tests/golden/align_outputs.npz, oracle/make_golden_align.py): integer results bit-exact."""
