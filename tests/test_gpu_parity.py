@@ -463,7 +463,7 @@ def test_error_behaviour(decoders):
     with pytest.raises(ValueError):
         d(inp["mu"].cuda(), inp["mask"][:1].cuda(), 2, 1.0, inp["c"].cuda(), "euler")
     with pytest.raises(NotImplementedError):
-        d(inp["mu"].cuda(), inp["mask"].cuda(), 2, 1.0, inp["c"].cuda(), "implicit_adams")
+        d(inp["mu"].cuda(), inp["mask"].cuda(), 2, 1.0, inp["c"].cuda(), "explicit_adams")
     from stabletts_amd._lib import NativeError
     with pytest.raises(NativeError):
         d(inp["mu"].cuda(), inp["mask"].cuda(), 0, 1.0, inp["c"].cuda(), "euler")
@@ -477,7 +477,7 @@ def test_error_behaviour(decoders):
 
 
 def test_non_native_solver_runs_torchdiffeq_controller_over_native_estimator(decoders, cfg_params, monkeypatch):
-    """solver names without a native controller (webui.py:110: implicit_adams) hand the time stepping to
+    """solver names without a native controller (torchdiffeq methods outside webui.py:110's list, e.g. explicit_adams) hand the time stepping to
     torchdiffeq while every vector-field evaluation stays native.  torchdiffeq is not installed here, so a
     stand-in module whose ``odeint`` is the fixed-grid Euler rule checks the plumbing (call signature of
     flow_matching.py:54, CFG wrapper, trajectory[-1]): the result must equal the fused native euler solve."""
@@ -503,8 +503,8 @@ def test_non_native_solver_runs_torchdiffeq_controller_over_native_estimator(dec
     inp = {k: v.cuda() for k, v in make_inputs(2, 60, seed=41, lengths=[60, 37]).items() if k != "lengths"}
     for cfg in (None, kw):
         ref = d(inp["mu"], inp["mask"], 4, 0.8, inp["c"], "euler", cfg, z=inp["z"])
-        out = d(inp["mu"], inp["mask"], 4, 0.8, inp["c"], "implicit_adams", cfg, z=inp["z"])
-        assert calls == dict(method="implicit_adams", rtol=1e-5, atol=1e-5, nfe=4)
+        out = d(inp["mu"], inp["mask"], 4, 0.8, inp["c"], "explicit_adams", cfg, z=inp["z"])
+        assert calls == dict(method="explicit_adams", rtol=1e-5, atol=1e-5, nfe=4)
         assert _rel(out.cpu(), ref.cpu()) <= 2e-4
 
 
