@@ -99,6 +99,12 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
                 v[u].z = (v[u].z + k.bias.z + xin[u].z) * mm; v[u].w = (v[u].w + k.bias.w + xin[u].w) * mm;
             }
         } else {   // EPI_RESGATE: x + gate * ((acc + b) * mask)
+            if (g.branch32) {
+#pragma unroll
+                for (int u = 0; u < R; ++u)
+                    if (ok[u]) store_row16(g.branch32 + grow[u] * g.cout + ch,
+                                           make_float4((v[u].x + k.bias.x) * m[u], (v[u].y + k.bias.y) * m[u], (v[u].z + k.bias.z) * m[u], (v[u].w + k.bias.w) * m[u]));
+            }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 v[u].x = xin[u].x + k.gate.x * ((v[u].x + k.bias.x) * m[u]); v[u].y = xin[u].y + k.gate.y * ((v[u].y + k.bias.y) * m[u]);
@@ -212,7 +218,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
             const int tl = t < T ? t : T - 1;            // loads of an invalid row are clamped, its stores dropped
             mk[u] = mrow ? mrow[tl] : 1.0f;
             xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)(g.out32 + ((size_t)n * T + tl) * g.cout + cbase + chl);
+            if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)((g.res32 ? g.res32 : g.out32) + ((size_t)n * T + tl) * g.cout + cbase + chl);
             if constexpr (EPI == EPI_F32) { if (g.add32) xin[u] = *(const float4*)(g.add32 + ((size_t)an * T + tl) * g.cout + cbase + chl); }
         }
         __syncthreads();
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmArgs g
     }
     const float m[1] = {g.mask ? g.mask[(size_t)(n % g.mask_mod) * g.T + t] : 1.0f};
     float4 xin[1]; xin[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (EPI == EPI_RESGATE) xin[0] = *(const float4*)(g.out32 + (size_t)row * 256 + ch);
+    if constexpr (EPI == EPI_RESGATE) xin[0] = *(const float4*)((g.res32 ? g.res32 : g.out32) + (size_t)row * 256 + ch);
     if constexpr (EPI == EPI_F32) {
         if (g.add32) xin[0] = *(const float4*)(g.add32 + ((size_t)(n < g.add_clamp ? n : g.add_clamp) * g.T + t) * 256 + ch);
     }

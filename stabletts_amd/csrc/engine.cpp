@@ -122,7 +122,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
             ConvGemmArgs pa = a;
             pa.t_lim = nullptr;
             pa.bias = nullptr; pa.flags = 0; pa.mask = nullptr; pa.add32 = nullptr; pa.out16 = nullptr; pa.out16_lo = nullptr;
-            pa.ln_h16 = nullptr; pa.gate = nullptr; pa.out32 = e->kpart; pa.ksplit = ks;
+            pa.ln_h16 = nullptr; pa.gate = nullptr; pa.res32 = nullptr; pa.branch32 = nullptr; pa.out32 = e->kpart; pa.ksplit = ks;
             const int pcfg = e->small_tiles ? G2_T64 : G2_T128;
             hipError_t he = bf ? launch_conv_gemm2_bf16(pcfg, taps, EPI_F32, pa, s) : launch_conv_gemm2_f16(pcfg, taps, EPI_F32, pa, s);
             if (he != hipSuccess) return he;

@@ -57,6 +57,7 @@ struct TrainState {
     float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *alphabuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
           *gin, *gsc;
     unsigned *gbits, *dsmax, *qbits;
+    bool fuse_ln = true;                        // ST_FUSE_TRAIN_LN=0: stand-alone residual / LayerNorm kernels after out-proj and FFN conv_2 (A/B)
     bool fuse_silu = true;                      // ST_FUSE_SILU=0: stand-alone silu_drop / silu_bwd kernels (A/B and the bit-identity test)
     unsigned *drop_rowh, *drop_colh;            // dropout hash tables of the attention site being processed (launch_drop_tables)
     float* skip_sc;                             // {scale, 1 / scale} each long-skip gradient was written at
@@ -104,6 +105,7 @@ int train_prepare(st_engine* e, hipStream_t s) {
     if (!e->train) {
         e->train = new TrainState();
         if (const char* v = getenv("ST_FUSE_SILU")) e->train->fuse_silu = atoi(v) != 0;
+        if (const char* v = getenv("ST_FUSE_TRAIN_LN")) e->train->fuse_ln = atoi(v) != 0;
     }
     TrainState* ts = e->train;
     if (ts->packed) return ST_OK;
@@ -343,18 +345,28 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
             }
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
-        {   // o = (Wo attn + b) * mask
+        if (ts->fuse_ln) {   // o = (Wo attn + b) * mask ; x2 = x1 + g_msa * o ; LN2 + modulate, masked -> h2: one GEMM with the
+            // inference epilogue (EPI_RESGATE + fused LayerNorm) that also stores the branch output o the gate's gradient needs
             ConvGemmArgs a = cargs(e, e->oproj[i], N, T, B);
-            a.a0 = A.attn16; a.c0 = C; a.mask = m; a.flags = GF_MASK; a.out32 = A.o32;
-            HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
-        }
-        {   // x2 = x1 + g_msa * o ; LN2 + modulate, masked -> h2
-            TrainLnArgs a; memset(&a, 0, sizeof(a));
-            a.xin = A.x1; a.xout = A.x2; a.h16 = A.h2;
-            a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.branch = A.o32;
-            a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
-            a.mask = m; a.mask_mod = B; a.mask_out = 1; a.T = T; a.rows = (int)R;
-            HIPCHK(e, launch_train_ln(e->dt, a, s));
+            a.a0 = A.attn16; a.c0 = C; a.mask = m; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C;
+            a.res32 = A.x1; a.out32 = A.x2; a.branch32 = A.o32;
+            a.ln_h16 = A.h2; a.ln_film = nullptr; a.ln_film_mod = 1;
+            a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
+            HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
+        } else {
+            {   // o = (Wo attn + b) * mask
+                ConvGemmArgs a = cargs(e, e->oproj[i], N, T, B);
+                a.a0 = A.attn16; a.c0 = C; a.mask = m; a.flags = GF_MASK; a.out32 = A.o32;
+                HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
+            }
+            {   // x2 = x1 + g_msa * o ; LN2 + modulate, masked -> h2
+                TrainLnArgs a; memset(&a, 0, sizeof(a));
+                a.xin = A.x1; a.xout = A.x2; a.h16 = A.h2;
+                a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.branch = A.o32;
+                a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 3 * C; a.scale_off = 4 * C;
+                a.mask = m; a.mask_mod = B; a.mask_out = 1; a.T = T; a.rows = (int)R;
+                HIPCHK(e, launch_train_ln(e->dt, a, s));
+            }
         }
         {   // FFN (diffusion_transformer.py:25-30)
             ConvGemmArgs a = cargs(e, e->ffn1[i], N, T, B); a.a0 = A.h2; a.c0 = C; a.out16 = A.a16;
@@ -366,10 +378,17 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
                 HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
                 HIPCHK(e, launch_silu_drop(e->dt, A.a16, A.u16, m, B, T, F, R, dc, s));
             }
-            a = cargs(e, e->ffn2[i], N, T, B); a.a0 = A.u16; a.c0 = F; a.mask = m; a.flags = GF_MASK; a.out32 = A.f32b;
-            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+            a = cargs(e, e->ffn2[i], N, T, B); a.a0 = A.u16; a.c0 = F; a.mask = m;
+            if (ts->fuse_ln) {      // f = (W2 u + b) * mask ; x3 = x2 + g_mlp * f (+ its 16-bit copies) in the GEMM's epilogue
+                a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.res32 = A.x2; a.out32 = A.x3; a.branch32 = A.f32b;
+                a.out16 = A.x3_16; a.out16_lo = i + 1 == L ? ts->x3lo : nullptr;
+                HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
+            } else {
+                a.flags = GF_MASK; a.out32 = A.f32b;
+                HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+            }
         }
-        {   // x3 = x2 + g_mlp * f  (+ 16-bit copies: long-skip / final_proj operands)
+        if (!ts->fuse_ln) {   // x3 = x2 + g_mlp * f  (+ 16-bit copies: long-skip / final_proj operands)
             TrainLnArgs a; memset(&a, 0, sizeof(a));
             a.xin = A.x2; a.xout = A.x3; a.x16 = A.x3_16; a.x16lo = i + 1 == L ? ts->x3lo : nullptr;
             a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.branch = A.f32b;

@@ -34,6 +34,8 @@ struct ConvGemmArgs {
     void* out16_lo;                   // optional (with out16, fp32-staged epilogues): 16-bit residual x - float(out16)
     const float* add32; int add_clamp;  // EPI_F32: + add32[min(n, add_clamp)][t][ch]
     const float* gate; int gate_stride; // EPI_RESGATE: out32 += gate[n*gate_stride + ch]*((acc+b)*mask)
+    const float* res32;               // EPI_RESGATE: the residual is read from res32 instead of out32 (nullptr: in place) -- training keeps x1 / x2 apart
+    float* branch32;                  // EPI_RESGATE: also stores the branch output (acc+b)*mask in fp32 (training: the gate's gradient needs it)
     // EPI_QKV (cout = 3*C, head_dim 64): q,k -> [item][H][T][64], vT -> [item][H][64][Tp]
     void* q; void* k; void* vt;
     const float* rope_cos; const float* rope_sin;   // [T][16]
