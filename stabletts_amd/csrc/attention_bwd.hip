@@ -67,6 +67,21 @@ __device__ __forceinline__ typename P::vec8 frag(const unsigned char* tile, int 
     return as_vec8<P>(*(const uint4*)(tile + row_off + ((slot ^ swz) << 4)));
 }
 
+// max |value| of the block's output tile into one cell (non-negative floats order like their bit patterns; NaN / inf do not
+// set a scale, as in absmax_kernel): one atomic per wave -- replaces three 65-MB reading passes over dq, dk, dv per layer
+__device__ __forceinline__ void publish_absmax(const f32x16_t (&o)[2], bool valid, unsigned* cell) {
+    float m = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = fabsf(o[d][r]); if (v == v && v < 3.0e38f) m = fmaxf(m, v); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(cell, __float_as_uint(m));
+}
+
 __device__ __forceinline__ void store_acc_rows(float* dst_row, const f32x16_t (&o)[2], int hi) {
     // lane = one position; o[d2][r] = value for head dim d2*32 + (r&3) + 8*(r>>2) + 4*hi
 #pragma unroll
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
             for (int r = 0; r < 16; ++r) o[d2][r] = o[d2][r] * inv_alpha + km[d2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] * rs;
     }
     if (qok) store_acc_rows(a.dq + ((size_t)nh * T + query) * 64, o, hi);
+    if (a.gmax) publish_absmax(o, qok, a.gmax);
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
@@ -475,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
         store_acc_rows(a.dk + ((size_t)nh * T + key) * 64, dk, hi);
         store_acc_rows(a.dv + ((size_t)nh * T + key) * 64, dv, hi);
     }
+    if (a.gmax) { publish_absmax(dk, kok, a.gmax + 1); publish_absmax(dv, kok, a.gmax + 2); }
 }
 
 hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s) {

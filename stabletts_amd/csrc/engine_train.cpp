@@ -602,11 +602,13 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
                 HIPCHK(e, launch_drop_tables(a.drop, N * H * T + 64, Tp / 2, ts->drop_rowh, ts->drop_colh, s));
                 a.drop.rowh = ts->drop_rowh; a.drop.colh = ts->drop_colh;
             }
+            HIPCHK(e, hipMemsetAsync(ts->qbits, 0, 12, s));
+            a.gmax = ts->qbits;          // the kernels publish max |dq|, |dk|, |dv| themselves
             HIPCHK(e, launch_attn_bwd_dq(e->dt, a, s));
             HIPCHK(e, launch_attn_bwd_dkv(e->dt, a, s));
             // d q, d k are ~1/T of d v: each gets its own power-of-two factor before the rounding to 16 bits (f16's normal
             // range ends at 6e-5); the fused dgrad GEMM takes the copy with one common factor
-            HIPCHK(e, launch_qkv_grad_scales(ts->dq, ts->dk, ts->dv, R * C, ts->gsc, ts->qbits, ts->qs, s));
+            HIPCHK(e, launch_qkv_grad_scales(ts->dq, ts->dk, ts->dv, R * C, ts->gsc, ts->qbits, ts->qs, s, true));
             HIPCHK(e, launch_qkv_grad_pack(e->dt, ts->dq, ts->dk, ts->dv, e->rope_cos, e->rope_sin, N, H, T, ts->qs, ts->g16b, ts->g16w, s));
         }
         if (cap) { capture(e, "g.dq_" + std::to_string(i), ts->dq, R * C, false, s); capture(e, "g.dk_" + std::to_string(i), ts->dk, R * C, false, s);

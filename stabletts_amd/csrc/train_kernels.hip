@@ -387,13 +387,15 @@ __global__ void qkv_scales_kernel(const unsigned* bits3, const float* gsc, float
     for (int i = 0; i < 3; ++i) { qs[2 + 2 * i] = f[i] * gsc[0]; qs[3 + 2 * i] = 1.0f / (f[i] * gsc[0]); qs[8 + i] = f[i]; }
 }
 hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float* dv, int64_t n, const float* gsc,
-                                  unsigned* bits3, float* qs, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(bits3, 0, 12, s);
-    if (e != hipSuccess) return e;
-    int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dq, n, bits3);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dk, n, bits3 + 1);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dv, n, bits3 + 2);
+                                  unsigned* bits3, float* qs, hipStream_t s, bool have_max) {
+    if (!have_max) {
+        hipError_t e = hipMemsetAsync(bits3, 0, 12, s);
+        if (e != hipSuccess) return e;
+        int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dq, n, bits3);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dk, n, bits3 + 1);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, dv, n, bits3 + 2);
+    }
     hipLaunchKernelGGL(qkv_scales_kernel, dim3(1), dim3(1), 0, s, bits3, gsc, qs);
     return hipGetLastError();
 }

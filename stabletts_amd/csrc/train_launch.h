@@ -136,6 +136,7 @@ struct AttnBwdArgs {
     const float* qmean; const float* kmean;            // [item][H][64]: what was subtracted from qT / kT
     const void* dO; int dO_row_stride;                 // time-major [item][T][H*64] (row stride H*64)
     const float* lse;                                  // [item][H][T]: log2-sum-exp of the forward
+    unsigned* gmax;                                    // [3] bit patterns of max |dq|, max |dk|, max |dv| (atomicMax by the kernels; zeroed by the caller; may be null)
     float* alphaq;                                     // [item][H][T]: power-of-two operand scale of each query's dS column (first pass -> second pass)
     float* Dq; float* Fq; float* aq;                   // [item][H][T]: sum_k P f dP', sum_k P f, dO . vmean -- written by the dQ
                                                        // kernel (first pass), read by the dK/dV kernel
@@ -156,7 +157,7 @@ hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s);
 //   qs[2..3], [4..5], [6..7]          {f_x gsc[0], 1 / (f_x gsc[0])} for x = q, k, v: unscale pairs of the three WGRAD outputs
 //   qs[8..10]                         f_q, f_k, f_v (each tensor's own maximum -> ~2^8): operand of the WGRAD GEMM
 hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float* dv, int64_t n, const float* gsc,
-                                  unsigned* bits3, float* qs, hipStream_t s);
+                                  unsigned* bits3, float* qs, hipStream_t s, bool have_max = false);   // have_max: bits3 already holds the three maxima (attention backward kernels)
 // RoPE^T on dq, dk, the 1/8 and ln2 factors, and packing into the time-major 16-bit operands [item][T][3*H*64]:
 // d16 (common factor qs[0], dgrad) and w16 (per-tensor factors qs[8..10], wgrad)
 hipError_t launch_qkv_grad_pack(int dtype, const float* dq, const float* dk, const float* dv, const float* rope_cos,
