@@ -366,15 +366,17 @@ int run_prenet(st_engine* e, const Plan& p, hipStream_t s) {
 int run_adaln(st_engine* e, const Plan& p, hipStream_t s) {
     const int C = e->C;
     ProfScope ps(e, s, PC_PREP, 0);
+    if (e->G == C) HIPCHK(e, launch_silu_rows(p.cvec, (int64_t)p.N * C, p.ada_tmp, s));      // SiLU(c): the same input for every block
     for (int i = 0; i < e->L; ++i) {
         const std::string pre = e->blk(i) + "adaLN_modulation.";
-        const float* in = p.cvec; int k = e->G;
         if (e->G != C) {
             HIPCHK(e, launch_linear(p.cvec, p.N, e->G, P(e, pre + "0.weight"), P(e, pre + "0.bias"), C, p.ada_tmp, 0, 0, s));
-            in = p.ada_tmp; k = C;
+            HIPCHK(e, launch_linear(p.ada_tmp, p.N, C, P(e, pre + "2.weight"), P(e, pre + "2.bias"), 6 * C,
+                                    p.ada + (size_t)i * p.N * 6 * C, 1, 0, s));
+        } else {
+            HIPCHK(e, launch_linear(p.ada_tmp, p.N, C, P(e, pre + "2.weight"), P(e, pre + "2.bias"), 6 * C,
+                                    p.ada + (size_t)i * p.N * 6 * C, 0, 0, s));
         }
-        HIPCHK(e, launch_linear(in, p.N, k, P(e, pre + "2.weight"), P(e, pre + "2.bias"), 6 * C,
-                                p.ada + (size_t)i * p.N * 6 * C, 1, 0, s));
     }
     return ST_OK;
 }

@@ -94,6 +94,17 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* in, int n, int
     }
 }
 
+__global__ __launch_bounds__(256) void silu_rows_kernel(const float* in, int64_t n, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = silu_f(in[i]);
+}
+// out = SiLU(in): the activation in front of the six adaLN modulation linears is the same vector for all of them; computed
+// once instead of once per output element inside linear_kernel (its expf chain was most of those launches' 14 us)
+hipError_t launch_silu_rows(const float* in, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(silu_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
                          float* out, int silu_in, int silu_out, hipStream_t s) {
     const long long waves = (long long)n * o;
