@@ -3,6 +3,7 @@
 // include/stabletts_hip.h.  Reference path: models/flow_matching.py:25-67 (CFMDecoder.forward,
 // cfg_wrapper), models/estimator.py:103-138 (Decoder.forward), torchdiffeq fixed-grid solvers.
 #include "engine_internal.h"
+#include "train_launch.h"
 
 #include <algorithm>
 #include <cmath>
@@ -973,6 +974,8 @@ void st_destroy(st_engine* e) {
     for (hipEvent_t ev : e->ev_pool) hipEventDestroy(ev);
     if (e->ws) hipFree(e->ws);
     if (e->adams_buf) hipFree(e->adams_buf);
+    if (e->pk_fwd.dev) hipFree(e->pk_fwd.dev);
+    if (e->pk_T.dev) hipFree(e->pk_T.dev);
     if (e->rope_cos) hipFree(e->rope_cos);
     if (e->rope_sin) hipFree(e->rope_sin);
     if (e->zeros) hipFree(e->zeros);
@@ -1004,7 +1007,7 @@ int st_load_param(st_engine* e, const char* name, const float* data, const int64
     if (!ok) return e->fail(ST_ERR_INVALID, std::string("shape mismatch for ") + name);
     HIPCHK(e, hipSetDevice(e->device));
     if (p.borrowed) { p.dev = nullptr; p.borrowed = false; }
-    if (!p.dev) HIPCHK(e, hipMalloc((void**)&p.dev, (size_t)p.numel() * 4));
+    if (!p.dev) { HIPCHK(e, hipMalloc((void**)&p.dev, (size_t)p.numel() * 4)); pk_drop(e); }       // (new pointer: the recorded re-pack jobs are stale)
     HIPCHK(e, hipMemcpy(p.dev, data, (size_t)p.numel() * 4, hipMemcpyDefault));
     p.loaded = true;
     e->finalized = false;
@@ -1030,6 +1033,7 @@ int st_bind_param(st_engine* e, const char* name, const float* data, const int64
     p.borrowed = true;
     p.loaded = true;
     e->finalized = false;
+    pk_drop(e);             // the recorded re-pack jobs hold the old pointer
     return ST_OK;
 }
 
@@ -1059,6 +1063,7 @@ int st_finalize(st_engine* e) {
         return vocos_finalize(e);
     }
     e->drop_graphs();          // instantiated graphs hold fp32 parameter pointers that a re-bind may have changed
+    pk_drop(e);                // ... and so do the recorded re-pack jobs
     int rc = pack_all(e, nullptr); if (rc) return rc;
     HIPCHK(e, hipDeviceSynchronize());
     train_invalidate(e);
@@ -1069,11 +1074,60 @@ int st_finalize(st_engine* e) {
 }  // extern "C"
 
 namespace sthost {
+static void pk_push(st_engine::PackList& L, const PackJob& j0, size_t elems) {
+    if (!L.recording) return;
+    PackJob j = j0;
+    j.blk0 = L.nblocks;
+    L.jobs.push_back(j);
+    L.nblocks += (unsigned)((elems + 255) / 256);
+}
+void pk_begin(st_engine::PackList& L) { L.jobs.clear(); L.nblocks = 0; L.ready = false; L.recording = true; }
+int pk_end(st_engine* e, st_engine::PackList& L, hipStream_t s) {
+    L.recording = false;
+    if (L.jobs.empty()) return ST_OK;
+    if (L.dev) { HIPCHK(e, hipStreamSynchronize(s)); hipFree(L.dev); L.dev = nullptr; }
+    HIPCHK(e, hipMalloc((void**)&L.dev, L.jobs.size() * sizeof(PackJob)));
+    HIPCHK(e, hipMemcpyAsync(L.dev, L.jobs.data(), L.jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));        // (pageable source; once per parameter binding)
+    L.ready = true;
+    return ST_OK;
+}
+bool pk_replay(st_engine* e, st_engine::PackList& L, hipStream_t s, int* rc) {
+    if (!L.ready) return false;
+    *rc = ST_OK;
+    if (launch_pack_jobs(e->dt, L.dev, (int)L.jobs.size(), L.nblocks, s) != hipSuccess) *rc = e->fail(ST_ERR_HIP, "launch_pack_jobs");
+    return true;
+}
+void pk_drop(st_engine* e) { e->pk_fwd.ready = false; e->pk_T.ready = false; }
+int pk_weight(st_engine* e, st_engine::PackList& L, const float* src, int cout, int cin_total, int K, int ci_off, int ci_cnt, void* dst,
+              int row_off, int cin_p, int col_off, int slice_w, int lo, hipStream_t s) {
+    HIPCHK(e, launch_pack_weight(e->dt, src, cout, cin_total, K, ci_off, ci_cnt, dst, row_off, cin_p, col_off, slice_w, lo, s));
+    pk_push(L, PackJob{src, dst, 0, cout, cin_total, K, ci_off, ci_cnt, row_off, cin_p, col_off, slice_w, lo, 0u}, (size_t)cout * K * slice_w);
+    return ST_OK;
+}
+int pk_weight_t(st_engine* e, st_engine::PackList& L, const float* src, int cout, int cin_total, int taps, int ci_off, int ci_cnt, void* dst,
+                int cin_p, int ld, int col_off, hipStream_t s) {
+    HIPCHK(e, launch_pack_weight_t(e->dt, src, cout, cin_total, taps, ci_off, ci_cnt, dst, cin_p, ld, col_off, s));
+    pk_push(L, PackJob{src, dst, 1, cout, cin_total, taps, ci_off, ci_cnt, 0, ld, col_off, 0, 0, 0u}, (size_t)ci_cnt * taps * cout);
+    return ST_OK;
+}
+int pk_copy(st_engine* e, st_engine::PackList& L, float* dst, const float* src, int n, hipStream_t s) {
+    HIPCHK(e, hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    pk_push(L, PackJob{src, dst, 2, n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u}, (size_t)n);
+    return ST_OK;
+}
+
 // Packs every convolution's weights into the 16-bit MFMA operand layouts on stream `s`.  The packed buffers are
 // allocated by the first call and re-used by every later one (shapes are fixed by the configuration), so instantiated
 // HIP graphs and in-flight launch sequences keep valid pointers and a re-pack is pure stream work.
 int pack_all(st_engine* e, hipStream_t s) {
     const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
+    {   // every later re-pack of the same tensors is one launch (the list was recorded by the first one)
+        int prc;
+        if (e->packed_once && pk_replay(e, e->pk_fwd, s, &prc)) return prc;
+    }
+    st_engine::PackList& PL = e->pk_fwd;
+    pk_begin(PL);
     // generic packer: (cout, cin_total, taps) source slice -> Conv with padded dims.  split: the packed K dimension
     // is [W_hi | W_hi | W_lo] (W_lo = W - float(W_hi)), the weight side of a split-precision operand
     auto pack = [&](Conv& cv, const std::string& wname, const float* bias_src, int cout, int cout_p, int cin_total,
@@ -1084,10 +1138,9 @@ int pack_all(st_engine* e, hipStream_t s) {
         // (the zero padding is written once, at allocation: a re-pack rewrites exactly the payload elements)
         if (!cv.w) { if ((rc = dev_alloc(e, &cv.w, wbytes))) return rc; HIPCHK(e, hipMemsetAsync(cv.w, 0, wbytes, s)); }
         for (int part = 0; part < (split ? 3 : 1); ++part)
-            HIPCHK(e, launch_pack_weight(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cv.cin,
-                                         part * cin_p, cin_p, part == 2, s));
+            if ((rc = pk_weight(e, PL, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, 0, cv.cin, part * cin_p, cin_p, part == 2, s))) return rc;
         if (!cv.bias) { if ((rc = dev_alloc(e, (void**)&cv.bias, (size_t)cout_p * 4))) return rc; HIPCHK(e, hipMemsetAsync(cv.bias, 0, (size_t)cout_p * 4, s)); }
-        if (bias_src) HIPCHK(e, hipMemcpyAsync(cv.bias, bias_src, (size_t)cout * 4, hipMemcpyDeviceToDevice, s));
+        if (bias_src && (rc = pk_copy(e, PL, cv.bias, bias_src, cout, s))) return rc;
         return ST_OK;
     };
     int rc;
@@ -1119,8 +1172,8 @@ int pack_all(st_engine* e, hipStream_t s) {
         int r = 0;
         for (const char* nm : {"q", "k", "v"}) {
             const std::string n = b + "attn.conv_" + nm;
-            HIPCHK(e, launch_pack_weight(e->dt, P(e, n + ".weight"), C, C, 1, 0, C, q.w, r * C, C, 0, C, false, s));
-            HIPCHK(e, hipMemcpyAsync(q.bias + (size_t)r * C, P(e, n + ".bias"), (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+            if ((rc = pk_weight(e, PL, P(e, n + ".weight"), C, C, 1, 0, C, q.w, r * C, C, 0, C, 0, s))) return rc;
+            if ((rc = pk_copy(e, PL, q.bias + (size_t)r * C, P(e, n + ".bias"), C, s))) return rc;
             ++r;
         }
         if ((rc = pack(e->oproj[i], b + "attn.conv_o.weight", P(e, b + "attn.conv_o.bias"), C, C, C, 1, 0, C, C, false))) return rc;
@@ -1128,7 +1181,7 @@ int pack_all(st_engine* e, hipStream_t s) {
         if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F, false))) return rc;
     }
     e->packed_once = true;
-    return ST_OK;
+    return pk_end(e, PL, s);
 }
 }  // namespace sthost
 

@@ -58,6 +58,10 @@ struct st_engine {
     }
     std::map<std::string, sthost::Param> params;
     bool finalized = false;
+    // Re-pack job lists (launch.h: PackJob): the first pack runs its individual launches and records them; later re-packs of
+    // the same parameter tensors are ONE launch per list.  Dropped whenever a parameter pointer may have changed.
+    struct PackList { std::vector<st::PackJob> jobs; st::PackJob* dev = nullptr; unsigned nblocks = 0; bool ready = false; bool recording = false; };
+    PackList pk_fwd, pk_T;
     bool packed_once = false;          // pack_all has allocated the packed-weight buffers (st_repack re-uses them)
     std::string err;
     int64_t weight_bytes = 0;
@@ -151,7 +155,17 @@ int ensure_rope(st_engine* e, int T, hipStream_t s);
 int check_ready(st_engine* e, int B, int T);
 extern std::string g_create_error;
 int vocos_finalize(st_engine* e);
-int pack_all(st_engine* e, hipStream_t s);            // (re)packs every 16-bit weight; allocates on the first call only
+int pack_all(st_engine* e, hipStream_t s);
+// recorder / replayer of a PackList: begin -> the pk_* calls (individual launch + record) -> end (upload); replay = one launch
+bool pk_replay(st_engine* e, st_engine::PackList& L, hipStream_t s, int* rc);      // true: the list was replayed (or failed: *rc)
+void pk_begin(st_engine::PackList& L);
+int pk_end(st_engine* e, st_engine::PackList& L, hipStream_t s);
+void pk_drop(st_engine* e);                                                          // parameter pointers may have changed
+int pk_weight(st_engine* e, st_engine::PackList& L, const float* src, int cout, int cin_total, int K, int ci_off, int ci_cnt, void* dst,
+              int row_off, int cin_p, int col_off, int slice_w, int lo, hipStream_t s);
+int pk_weight_t(st_engine* e, st_engine::PackList& L, const float* src, int cout, int cin_total, int taps, int ci_off, int ci_cnt, void* dst,
+                int cin_p, int ld, int col_off, hipStream_t s);
+int pk_copy(st_engine* e, st_engine::PackList& L, float* dst, const float* src, int n, hipStream_t s);            // (re)packs every 16-bit weight; allocates on the first call only
 void vocos_destroy(st_engine* e);
 
 // HIP-event bracket around the launches of one kernel class (st_profile_*)

@@ -88,7 +88,8 @@ int pack_T(st_engine* e, TrainState* ts, Conv& cv, const std::string& wname, int
         HIPCHK(e, hipMalloc(&cv.w, bytes)); ts->owned.push_back(cv.w);
         HIPCHK(e, hipMemsetAsync(cv.w, 0, bytes, s));
     }
-    HIPCHK(e, launch_pack_weight_t(e->dt, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, cin_p, ld, 0, s));
+    int rc = pk_weight_t(e, e->pk_T, P(e, wname), cout, cin_total, taps, ci_off, ci_cnt, cv.w, cin_p, ld, 0, s);
+    if (rc) return rc;
     cv.bias = nullptr;
     return ST_OK;
 }
@@ -112,6 +113,12 @@ int train_prepare(st_engine* e, hipStream_t s) {
     ts->have_fwd = false;
     const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, K = e->K, L = e->L;
     int rc;
+    if (ts->grad_flat && pk_replay(e, e->pk_T, s, &rc)) {      // the usual case after an optimizer step: one launch
+        if (rc) return rc;
+        ts->packed = true;
+        return ST_OK;
+    }
+    pk_begin(e->pk_T);
     if ((rc = pack_T(e, ts, ts->finT, "final_proj.weight", M, C, 1, 0, C, C, Mp, s))) return rc;
     if ((rc = pack_T(e, ts, ts->inxT, "in_proj.weight", C, C + M, 1, 0, M, Mp, C, s))) return rc;
     if ((rc = pack_T(e, ts, ts->incT, "in_proj.weight", C, C + M, 1, M, C, C, C, s))) return rc;
@@ -131,7 +138,7 @@ int train_prepare(st_engine* e, hipStream_t s) {
         if (!q.w) { HIPCHK(e, hipMalloc(&q.w, (size_t)C * 3 * C * 2)); ts->owned.push_back(q.w); }
         int r = 0;
         for (const char* nm : {"q", "k", "v"}) {
-            HIPCHK(e, launch_pack_weight_t(e->dt, P(e, b + "attn.conv_" + nm + ".weight"), C, C, 1, 0, C, q.w, C, 3 * C, r * C, s));
+            if ((rc = pk_weight_t(e, e->pk_T, P(e, b + "attn.conv_" + nm + ".weight"), C, C, 1, 0, C, q.w, C, 3 * C, r * C, s))) return rc;
             ++r;
         }
     }
@@ -148,6 +155,7 @@ int train_prepare(st_engine* e, hipStream_t s) {
         int64_t off = 0;
         for (auto& kv : e->params) { ts->grads[kv.first] = ts->grad_flat + off; off += kv.second.numel(); }
     }
+    if ((rc = pk_end(e, e->pk_T, s))) return rc;
     ts->packed = true;
     return ST_OK;
 }

@@ -153,6 +153,12 @@ hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_tot
                               int ci_cnt, void* dst, int row_off, int cin_p, int col_off, int slice_w, int lo,
                               hipStream_t s);
 hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);
+// One launch for a whole list of packing jobs (the ~100 launch_pack_weight / launch_pack_weight_t calls and ~60 bias copies of a
+// re-pack after an optimizer step are each a few microseconds of launch latency: 0.75 ms per training step as separate launches).
+// kind 0: launch_pack_weight's mapping, kind 1: launch_pack_weight_t's (train_launch.h), kind 2: fp32 copy of `cout` elements.
+// blk0 = first 256-thread block of the job in the merged grid (jobs sorted by blk0).
+struct PackJob { const float* src; void* dst; int kind, cout, cin_total, K, ci_off, ci_cnt, row_off, cin_p, col_off, slice_w, lo; unsigned blk0; };
+hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t s);
 
 // ---------------------------------------------------------------- duration -> alignment -> mu_y (align_kernels.hip; models/model.py:17-27,82-96)
 hipError_t launch_durations(const float* logw, const float* x_mask, float length_scale, int B, int Tx, float* w_ceil,

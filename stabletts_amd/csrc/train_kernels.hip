@@ -635,6 +635,46 @@ hipError_t launch_pack_weight_t(int dtype, const float* src, int cout, int cin_t
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ merged re-pack (launch.h: PackJob)
+template <class P>
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                 // block-uniform binary search: the job whose block range holds blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const size_t idx = (size_t)(blockIdx.x - j.blk0) * 256 + threadIdx.x;
+    if (j.kind == 0) {              // pack_weight_kernel (misc_kernels.hip)
+        const size_t total = (size_t)j.cout * j.K * j.slice_w;
+        if (idx >= total) return;
+        const int ci = (int)(idx % j.slice_w);
+        const int t = (int)((idx / j.slice_w) % j.K);
+        const int co = (int)(idx / ((size_t)j.slice_w * j.K));
+        float v = 0.f;
+        if (ci < j.ci_cnt) v = j.src[((size_t)co * j.cin_total + j.ci_off + ci) * j.K + t];
+        if (j.lo) v -= (float)to16<P>(v);
+        ((typename P::elem*)j.dst)[((size_t)(j.row_off + co) * j.K + t) * j.cin_p + j.col_off + ci] = to16<P>(v);
+    } else if (j.kind == 1) {       // pack_weight_t_kernel (above); cin_p carries its `ld`
+        const size_t total = (size_t)j.ci_cnt * j.K * j.cout;
+        if (idx >= total) return;
+        const int co = (int)(idx % j.cout);
+        const int t = (int)((idx / j.cout) % j.K);
+        const int ci = (int)(idx / ((size_t)j.cout * j.K));
+        const float v = j.src[((size_t)co * j.cin_total + j.ci_off + ci) * j.K + (j.K - 1 - t)];
+        ((typename P::elem*)j.dst)[((size_t)ci * j.K + t) * j.cin_p + j.col_off + co] = to16<P>(v);
+    } else {                        // fp32 copy (biases)
+        if (idx < (size_t)j.cout) ((float*)j.dst)[idx] = j.src[idx];
+    }
+}
+
+hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t s) {
+    if (njobs < 1 || nblocks < 1) return hipSuccess;
+    if (dtype == DT_BF16) hipLaunchKernelGGL((pack_jobs_kernel<OpBF16>), dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs);
+    else                  hipLaunchKernelGGL((pack_jobs_kernel<OpF16>), dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ small fp32 linears: backward
 // (adaLN / FiLM / time-MLP linears on per-item vectors: n = batch items, a few hundred inputs and outputs.  Register-blocked so
 //  that every loaded value feeds 8 multiply-adds -- one output per thread cost 2 loads and, with SiLU on the input, one expf per
