@@ -213,6 +213,12 @@ int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, voi
  * the sum of all parameter sizes.  What loss.backward() of the autograd binding uses (one 81 MB copy instead of 116). */
 int st_param_grads_flat(st_engine* e, float* dst, int64_t numel, void* stream);
 
+/* Non-finite guard (no reference analogue: the reference is fp32).  The kernel that writes the output of st_estimator_forward /
+ * st_cfm_solve raises a flag when a value is NaN / Inf -- f16 MFMA operands overflow at 65504 (a checkpoint whose activations
+ * exceed that needs operand_dtype = bf16), or the inputs were bad.  Synchronises `stream`, stores the flag of the calls completed
+ * since the last query in *nonfinite (0 / 1) and clears it; after a flagged call the engine re-zeroes its workspace by itself. */
+int st_output_status(st_engine* e, void* stream, int* nonfinite);
+
 /* Function evaluations, attempted steps and rejected steps of the last st_cfm_solve (adaptive solvers vary). */
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects);
 

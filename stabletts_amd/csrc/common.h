@@ -202,4 +202,19 @@ __device__ __forceinline__ unsigned drop_ffn_hash(const D& d, unsigned long long
     return drop_mix32(((unsigned)d.seed ^ ((unsigned)(i >> 1) * 0x9E3779B1u)) + (unsigned)(d.seed >> 32));
 }
 
+// Fused-FFN weight stream (launch.h: launch_pack_ffn_stream; ffn_fused.h consumes it): element idx of one stage's F*256*3 values ->
+// source offset in the fp32 conv weight and destination offset in the stream (16-bit elements).  hidden = 256 hard-wired.
+//   idx = ((c*24 + sl)*16 + f)*512 + lane*8 + e;  sl = (ci, tap, kp) = ci*6 + tap*2 + kp;  f = ksl*8 + a8
+//   stage 0, conv_1 (F, 256, 3): row = c*256 + a8*32 + (lane&31), cin = ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e
+//   stage 1, conv_2 (256, F, 3): row = a8*32 + (lane&31),         cin = c*256 + ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e
+__host__ __device__ __forceinline__ void ffn_stream_index(size_t idx, int stage, int F, size_t* src_off, size_t* dst_off) {
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), f = (int)((idx >> 9) & 15);
+    const int sl = (int)((idx >> 13) % 24), c = (int)(idx / (24u * 8192u));
+    const int ksl = f >> 3, a8 = f & 7, ci = sl / 6, tap = (sl % 6) >> 1, kp = sl & 1;
+    const int kk = ci * 64 + (2 * kp + ksl) * 16 + (lane >> 5) * 8 + e;
+    if (stage == 0) *src_off = ((size_t)(c * 256 + a8 * 32 + (lane & 31)) * 256 + kk) * 3 + tap;
+    else            *src_off = ((size_t)(a8 * 32 + (lane & 31)) * F + c * 256 + kk) * 3 + tap;
+    *dst_off = (size_t)c * (48u * 8192u) + (size_t)(stage * 24 + sl) * 8192u + (idx & 8191);
+}
+
 }  // namespace st

@@ -471,7 +471,11 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
         if (cap) { capture(e, bn + "x2", p.X, rowsC, false, s); capture(e, bn + "h2", p.h16, rowsC, true, s); }
-        {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
+        // Big grids: the whole FFN as ONE kernel, u never leaves the CU (ffn_fused.h; bit-identical to the two launches below).
+        // Debug capture keeps the two-kernel path (it taps u).
+        const bool fused = e->fused_ffn && !cap && (int)e->ffn_stream.size() == L && e->ffn_stream[i] &&
+                           (int64_t)e->conc * N * ((T + kFfnFusedFrames - 1) / kFfnFusedFrames) >= e->big_min_blocks;
+        if (!fused) {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
             ConvGemmArgs a = base_args(e, p, e->ffn1[i], N);
             a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
             ProfScope ps(e, s, PC_FFN1, conv_flops(p, e->ffn1[i], N));
@@ -482,14 +486,16 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         {   // FFN conv_2, mask, gate, residual (diffusion_transformer.py:29-30,112) [+ FiLM/LN1 of block i+1]
             ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
+            if (fused) { a.a0 = p.h16; a.c0 = C; a.w = e->ffn_stream[i]; a.bias1 = e->ffn1[i].bias; a.cmid = F; a.flags = GF_SILU | GF_MASK; }
             a.out16 = copy16;
             if (i + 1 == L) a.out16_lo = p.cur16lo;        // operand pair of final_proj
             if (i + 1 < L / 2) fuse_ln1(a, i + 1);         // blocks >= L/2 start with the long-skip conv instead
             // ... which rebuilds the residual stream from the 16-bit operands (and final_proj reads only those): from
             // block L/2 - 1 on the fp32 copy of x3 is dead, so it is not written (40 % of this epilogue's HBM bytes)
             else if (!cap) a.out32_readonly = 1;
-            ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N));
-            HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
+            ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N) + (fused ? conv_flops(p, e->ffn1[i], N) : 0.0));
+            if (fused) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused_bf16(a, s) : launch_ffn_fused_f16(a, s));
+            else HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }
         if (cap) {
             if (i + 1 < L / 2) capture(e, bn + "x3", copy16, rowsC, true, s);   // X already holds the FiLM'd value
@@ -929,6 +935,7 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     e->kind = kind; e->n_vocab = n_vocab;
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
+    if (const char* v = getenv("ST_FUSED_FFN")) e->fused_ffn = atoi(v);
     if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);
     if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)
     if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
@@ -944,6 +951,9 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
         delete e;
         return ST_ERR_HIP;
     }
+    if (hipHostMalloc((void**)&e->status_host, sizeof(int), hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer((void**)&e->status_dev, e->status_host, 0) == hipSuccess) *e->status_host = 0;
+    else { (void)hipGetLastError(); e->status_host = nullptr; e->status_dev = nullptr; }      // (guard unavailable: st_output_status says so)
     *out = e;
     return ST_OK;
 }
@@ -980,6 +990,7 @@ void st_destroy(st_engine* e) {
     if (e->rope_sin) hipFree(e->rope_sin);
     if (e->zeros) hipFree(e->zeros);
     if (e->kpart) hipFree(e->kpart);
+    if (e->status_host) hipHostFree(e->status_host);
     delete e;
 }
 
@@ -1007,7 +1018,9 @@ int st_load_param(st_engine* e, const char* name, const float* data, const int64
     if (!ok) return e->fail(ST_ERR_INVALID, std::string("shape mismatch for ") + name);
     HIPCHK(e, hipSetDevice(e->device));
     if (p.borrowed) { p.dev = nullptr; p.borrowed = false; }
-    if (!p.dev) { HIPCHK(e, hipMalloc((void**)&p.dev, (size_t)p.numel() * 4)); pk_drop(e); }       // (new pointer: the recorded re-pack jobs are stale)
+    if (!p.dev) {       // new pointer: the recorded re-pack jobs are stale, and so are instantiated graphs (they bake the fp32
+        HIPCHK(e, hipMalloc((void**)&p.dev, (size_t)p.numel() * 4)); pk_drop(e); e->drop_graphs();      // pointers of the adaLN / FiLM / time-MLP linears)
+    }
     HIPCHK(e, hipMemcpy(p.dev, data, (size_t)p.numel() * 4, hipMemcpyDefault));
     p.loaded = true;
     e->finalized = false;
@@ -1033,7 +1046,8 @@ int st_bind_param(st_engine* e, const char* name, const float* data, const int64
     p.borrowed = true;
     p.loaded = true;
     e->finalized = false;
-    pk_drop(e);             // the recorded re-pack jobs hold the old pointer
+    pk_drop(e);             // the recorded re-pack jobs hold the old pointer ...
+    e->drop_graphs();       // ... and instantiated solve graphs read the fp32 linears (adaLN, FiLM, time MLP) through it
     return ST_OK;
 }
 
@@ -1041,6 +1055,9 @@ int st_repack(st_engine* e, void* stream) {
     if (!e) return ST_ERR_INVALID;
     if (e->kind == 2) return e->fail(ST_ERR_UNSUPPORTED, "st_repack: vocoder handles re-pack through st_finalize");
     if (!e->packed_once) return e->fail(ST_ERR_STATE, "st_repack needs one earlier st_finalize (it allocates the packed buffers)");
+    // A re-bind / re-load since the last st_finalize may have moved fp32 tensors: st_repack is for in-place updates only.
+    if (!e->finalized && !e->pk_fwd.ready)
+        return e->fail(ST_ERR_STATE, "st_repack after st_bind_param / st_load_param of a new pointer: call st_finalize");
     for (auto& kv : e->params)
         if (!kv.second.loaded) return e->fail(ST_ERR_STATE, "parameter not loaded: " + kv.first);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1179,6 +1196,15 @@ int pack_all(st_engine* e, hipStream_t s) {
         if ((rc = pack(e->oproj[i], b + "attn.conv_o.weight", P(e, b + "attn.conv_o.bias"), C, C, C, 1, 0, C, C, false))) return rc;
         if ((rc = pack(e->ffn1[i], b + "mlp.conv_1.weight", P(e, b + "mlp.conv_1.bias"), F, F, C, K, 0, C, C, false))) return rc;
         if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F, false))) return rc;
+        if (e->kind == 0 && C == 256 && K == 3 && F % 256 == 0 && F <= 2048) {      // the fused FFN kernel's weight stream (ffn_fused.h)
+            if ((int)e->ffn_stream.size() != L) e->ffn_stream.assign(L, nullptr);
+            if (!e->ffn_stream[i] && (rc = dev_alloc(e, &e->ffn_stream[i], (size_t)2 * F * C * K * 2))) return rc;
+            for (int st = 0; st < 2; ++st) {
+                const float* src = P(e, b + (st ? "mlp.conv_2.weight" : "mlp.conv_1.weight"));
+                HIPCHK(e, launch_pack_ffn_stream(e->dt, src, st, F, e->ffn_stream[i], s));
+                pk_push(PL, PackJob{src, e->ffn_stream[i], 3, F, 0, 0, 0, 0, 0, 0, 0, 0, st, 0u}, (size_t)F * C * K);
+            }
+        }
     }
     e->packed_once = true;
     return pk_end(e, PL, s);
@@ -1197,6 +1223,7 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
     hipStream_t s = (hipStream_t)stream;
     Plan p;
     if ((rc = make_plan(e, B, T, false, t_len, &p))) return rc;
+    e->arena_poisoned();      // an earlier call produced NaN / Inf: its stale frames must not be trusted (re-zero below)
     if ((rc = arena_fresh(e, layout_sig(1, B, T, 0, t_len, 1), layout_plan(e, B, T, false, t_len, 0, &p), s))) return rc;
     bind_plan(e, &p);
     if ((rc = ensure_rope(e, T, s))) return rc;
@@ -1215,7 +1242,7 @@ int st_estimator_forward(st_engine* e, const float* t, int t_len, const float* x
     if ((rc = run_estimator(e, p, mask, t_len == 1 ? 0 : -1, s))) return rc;
     {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_from_time_major(p.v32, B, e->M, T, e->Mp, out, s));
+        HIPCHK(e, launch_from_time_major(p.v32, B, e->M, T, e->Mp, out, s, e->status_dev));
     }
     return ST_OK;
 }
@@ -1270,6 +1297,7 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
             off = layout_plan(e, parts[k].nb, T, use_cfg != 0, n_t, off, &parts[k].p);
         }
         if ((rc = ensure_ws(e, off))) return rc;
+        e->arena_poisoned();
         if ((rc = arena_fresh(e, layout_sig(2, B, T, use_cfg != 0, n_t, nparts), off, s))) return rc;
         for (auto& pt : parts) bind_plan(e, &pt.p);
     }
@@ -1427,10 +1455,10 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         g->seen += 1;
         if (g->exec) { HIPCHK(e, hipGraphLaunch(g->exec, s)); done = true; }
     }
-    if (!done) { brc = body(s); e->conc = 1; if (brc) return brc; }
+    if (!done) { brc = body(s); e->conc = 1; if (brc) { e->ws_sig = 0; return brc; } }      // (a half-enqueued body: re-zero the arena next time)
     for (auto& pt : parts) {
         ProfScope ps(e, s, PC_PREP, 0);
-        HIPCHK(e, launch_from_time_major(adaptive && !adams ? pt.p.ynew : pt.p.xstate, pt.nb, e->M, T, e->Mp, out + pt.b0 * bct, s));
+        HIPCHK(e, launch_from_time_major(adaptive && !adams ? pt.p.ynew : pt.p.xstate, pt.nb, e->M, T, e->Mp, out + pt.b0 * bct, s, e->status_dev));
     }
     return ST_OK;
 }
@@ -1491,6 +1519,17 @@ int st_align(const float* cum, const float* x_mask, const int64_t* y_lengths, co
     if (B < 1 || M < 1 || Tx < 1 || Ty < 1 || B > 65535) return align_fail(ST_ERR_INVALID, "shape out of range");
     if (launch_align(cum, x_mask, (const long long*)y_lengths, mu_x, B, M, Tx, Ty, attn, mu_y, y_mask, (hipStream_t)stream) != hipSuccess)
         return align_fail(ST_ERR_HIP, "align kernel launch failed");
+    return ST_OK;
+}
+
+int st_output_status(st_engine* e, void* stream, int* nonfinite) {
+    if (!e) return ST_ERR_INVALID;
+    if (!nonfinite) return e->fail(ST_ERR_INVALID, "null argument");
+    if (!e->status_host) return e->fail(ST_ERR_UNSUPPORTED, "host-mapped status word unavailable on this device");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    *nonfinite = *e->status_host != 0;
+    e->arena_poisoned();      // clears the word; the next call re-zeroes the arena
     return ST_OK;
 }
 

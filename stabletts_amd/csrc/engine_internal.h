@@ -70,6 +70,7 @@ struct st_engine {
     std::vector<sthost::Conv> pre;              // 3 prenet convs
     sthost::Conv inx, inc, fin;                 // in_proj x-part / cond-part, final_proj
     std::vector<sthost::Conv> lsc, qkv, oproj, ffn1, ffn2;
+    std::vector<void*> ffn_stream;      // per block: conv_1 + conv_2 weights as the fused FFN kernel's stream (ffn_fused.h); empty if unsupported
     std::vector<void*> owned;           // device allocations to free
 
     float* rope_cos = nullptr; float* rope_sin = nullptr; int rope_T = 0;
@@ -93,6 +94,12 @@ struct st_engine {
     double prof_flops[sthost::PC_COUNT] = {0};
 
     int64_t last_nfe = 0, last_steps = 0, last_rejects = 0;   // statistics of the last solve
+    // Non-finite guard: the boundary kernel that writes a call's output sets *status_host (host-mapped, no synchronisation) when a
+    // value is NaN / Inf -- an f16 operand beyond 65504, a bad input.  st_output_status reads it after a stream sync; the next call
+    // reads it without one and, if set, re-zeroes the arena (ragged tile skipping leaves stale frames that are only ever read by
+    // don't-care positions, but 0 x NaN would leak: arena_fresh).
+    int* status_host = nullptr; int* status_dev = nullptr;
+    bool arena_poisoned() { if (status_host && *status_host) { *status_host = 0; ws_sig = 0; return true; } return false; }
 
     // tile policy: 256x256 tiles only when the launch has at least this many of them (~3/4 block per CU); read once
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
@@ -100,6 +107,7 @@ struct st_engine {
     int big_min_blocks = 192;
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
+    int fused_ffn = 1;                  // FFN of big grids as ONE kernel, the intermediate kept in LDS (ffn_fused.h); ST_FUSED_FFN=0: A/B runs
     int phased = 1;                     // k = 3 convs on 256-wide tiles use the phased K loop (conv_gemm_phased.h); ST_PHASED=0: A/B runs
     int splitk_max = kSplitKMax, splitk_min_stages = 4;
     int small_tiles = 256;              // conv launches of <= this many 128x128 tiles use the 64-frame tile variants (0: never)

@@ -58,6 +58,9 @@ struct ConvGemmArgs {
     void* act16; const void* dact16;
     unsigned long long drop_seed; unsigned drop_thresh16; float drop_scale;
     int ksplit;                       // > 1: split-K launch (EPI_F32 only): out32 = partial planes [ksplit][items][T][cout], raw sums
+    // fused FFN (ffn_fused.h): w = the fused weight stream (launch_pack_ffn_stream), bias1 = conv_1's bias [cmid], cmid = the
+    // intermediate width (filter_channels); every other field describes conv_2's EPI_RESGATE epilogue, a0 = the FFN input
+    const float* bias1; int cmid;
     unsigned long long* dbg;          // diagnostics (ST_STAGE_TIMING builds of tools/gemm2_bench only), else nullptr
 };
 
@@ -73,6 +76,17 @@ hipError_t launch_conv_gemm2_f16(int cfg, int taps, int epi, const ConvGemmArgs&
 // epilogue `epi` (EPI_F32 / EPI_RESGATE, cout == 256) of the sum of the S partial planes a split-K launch left in `part`
 hipError_t launch_splitk_finish_bf16(int epi, const ConvGemmArgs& a, const float* part, int S, hipStream_t s);
 hipError_t launch_splitk_finish_f16(int epi, const ConvGemmArgs& a, const float* part, int S, hipStream_t s);
+// Fused FFN (diffusion_transformer.py:20-30 as ONE kernel, the 1024-wide intermediate never leaves the CU): conv_1 + SiLU + mask
+// -> 16-bit u chunk in LDS -> conv_2 accumulating over the chunks -> conv_2's EPI_RESGATE(+LN) epilogue.  a.w = fused weight
+// stream, a.bias1 / a.cmid = conv_1 bias / width, everything else as for conv_2 (a0 = the FFN input h2, c0 = cout = 256).
+constexpr int kFfnFusedFrames = 126;      // output frames per block (128 u rows = the tile + conv_2's halo)
+hipError_t launch_ffn_fused_bf16(const ConvGemmArgs& a, hipStream_t s);
+hipError_t launch_ffn_fused_f16(const ConvGemmArgs& a, hipStream_t s);
+// Weight stream of the fused FFN kernel, in the order the kernel consumes it: for each 256-channel chunk c of the intermediate
+// width, 24 conv_1 slabs (cin chunk, tap, k-step pair) then 24 conv_2 slabs (u sub-chunk, tap, k-step pair); a slab = 16 MFMA
+// A-fragments of 1 KiB stored lane-linear (fragment (ksl, a8): rows a8*32.., k-step 2*kp+ksl).  stage 0: src = conv_1 weight
+// (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).
+hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F, void* dst, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 
@@ -130,7 +144,7 @@ hipError_t launch_mask_prep(const float* mask, int B, int T, int Tp, int* n_full
 hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T, int Cp,
                                 float* out32, void* out16, void* out16lo, hipStream_t s);
 // time-major (B, T, Cp) fp32 -> (B, C, T) fp32
-hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s);
+hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s, int* nonfinite = nullptr);
 // dst16[t][c] = vec[c] for all t (uncond prenet input: fake_content broadcast, flow_matching.py:60)
 hipError_t launch_embed_tokens(const long long* tokens, const long long* lengths, const float* emb, int n_vocab,
                                int C, float scale, int B, int T, float* X, float* mask_out, hipStream_t s);
@@ -155,7 +169,8 @@ hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_tot
 hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);
 // One launch for a whole list of packing jobs (the ~100 launch_pack_weight / launch_pack_weight_t calls and ~60 bias copies of a
 // re-pack after an optimizer step are each a few microseconds of launch latency: 0.75 ms per training step as separate launches).
-// kind 0: launch_pack_weight's mapping, kind 1: launch_pack_weight_t's (train_launch.h), kind 2: fp32 copy of `cout` elements.
+// kind 0: launch_pack_weight's mapping, kind 1: launch_pack_weight_t's (train_launch.h), kind 2: fp32 copy of `cout` elements,
+// kind 3: launch_pack_ffn_stream's (lo = stage, cout = F).
 // blk0 = first 256-thread block of the job in the merged grid (jobs sorted by blk0).
 struct PackJob { const float* src; void* dst; int kind, cout, cin_total, K, ci_off, ci_cnt, row_off, cin_p, col_off, slice_w, lo; unsigned blk0; };
 hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t s);

@@ -188,7 +188,9 @@ hipError_t launch_to_time_major(int dtype, const float* in, int B, int C, int T,
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void from_time_major_kernel(const float* in, int C, int T, int Cp, float* out) {
+// nonfinite (optional, host-mapped): set to 1 when a value that leaves through this boundary is NaN / Inf (an f16 operand that
+// overflowed, a bad input) -- read by st_output_status and by the next call's arena check, never waited for here
+__global__ __launch_bounds__(256) void from_time_major_kernel(const float* in, int C, int T, int Cp, float* out, int* nonfinite) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -203,13 +205,17 @@ __global__ __launch_bounds__(256) void from_time_major_kernel(const float* in, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + i * 8, t = t0 + tx;
-        if (c < C && t < T) out[((size_t)b * C + c) * T + t] = tile[tx][ty + i * 8];
+        if (c < C && t < T) {
+            const float v = tile[tx][ty + i * 8];
+            out[((size_t)b * C + c) * T + t] = v;
+            if (nonfinite && !(fabsf(v) <= 3.4028234664e38f)) *nonfinite = 1;
+        }
     }
 }
 
-hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s) {
+hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, float* out, hipStream_t s, int* nonfinite) {
     dim3 grid((T + 31) / 32, (C + 31) / 32, B);
-    hipLaunchKernelGGL(from_time_major_kernel, grid, dim3(256), 0, s, in, C, T, Cp, out);
+    hipLaunchKernelGGL(from_time_major_kernel, grid, dim3(256), 0, s, in, C, T, Cp, out, nonfinite);
     return hipGetLastError();
 }
 
@@ -389,6 +395,24 @@ hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_tot
         hipLaunchKernelGGL((pack_weight_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (__bf16*)dst, row_off, cin_p, col_off, slice_w, lo);
     else
         hipLaunchKernelGGL((pack_weight_kernel<OpF16>), dim3(grid), dim3(256), 0, s, src, cout, cin_total, K, ci_off, ci_cnt, (_Float16*)dst, row_off, cin_p, col_off, slice_w, lo);
+    return hipGetLastError();
+}
+
+// fused-FFN weight stream (common.h: ffn_stream_index)
+template <class P>
+__global__ void pack_ffn_stream_kernel(const float* src, int stage, int F, typename P::elem* dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)F * 256 * 3) return;
+    size_t so, dof;
+    ffn_stream_index(idx, stage, F, &so, &dof);
+    dst[dof] = to16<P>(src[so]);
+}
+
+hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F, void* dst, hipStream_t s) {
+    const size_t total = (size_t)F * 256 * 3;
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((pack_ffn_stream_kernel<OpBF16>), dim3(grid), dim3(256), 0, s, src, stage, F, (__bf16*)dst);
+    else                  hipLaunchKernelGGL((pack_ffn_stream_kernel<OpF16>), dim3(grid), dim3(256), 0, s, src, stage, F, (_Float16*)dst);
     return hipGetLastError();
 }
 

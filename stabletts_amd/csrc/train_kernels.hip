@@ -663,6 +663,11 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int
         const int ci = (int)(idx / ((size_t)j.cout * j.K));
         const float v = j.src[((size_t)co * j.cin_total + j.ci_off + ci) * j.K + (j.K - 1 - t)];
         ((typename P::elem*)j.dst)[((size_t)ci * j.K + t) * j.cin_p + j.col_off + co] = to16<P>(v);
+    } else if (j.kind == 3) {       // pack_ffn_stream_kernel (misc_kernels.hip): lo = stage, cout = F
+        if (idx >= (size_t)j.cout * 256 * 3) return;
+        size_t so, dof;
+        ffn_stream_index(idx, j.lo, j.cout, &so, &dof);
+        ((typename P::elem*)j.dst)[dof] = to16<P>(j.src[so]);
     } else {                        // fp32 copy (biases)
         if (idx < (size_t)j.cout) ((float*)j.dst)[idx] = j.src[idx];
     }

@@ -93,6 +93,30 @@ def test_phased_k_loop_is_bit_identical_to_the_two_buffer_kernel(sd, cfg_params,
             assert torch.equal(_solve(new, inp, 2, "euler", kw), ref), (B, T)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fused_ffn_is_bit_identical_to_the_two_kernel_path(sd, cfg_params, monkeypatch, dtype):
+    """ffn_fused_kernel (conv_1 -> SiLU / mask / 16-bit rounding in LDS -> conv_2 -> RESGATE(+LN) epilogue in ONE launch,
+    126-frame tiles, 256-channel chunks of the intermediate, operand areas shared by h and u, a 5-slab weight ring with
+    counted LDS-DMA waits) contracts in the two-kernel path's K order with the same SiLU / rounding instructions: whole
+    solves must agree bit for bit -- at tile-edge lengths (126 | 127 | 252 | 253 frames), ragged masks with tile skipping,
+    a length-1 row, and repeated (a race in the barrier / vmcnt protocol would show up as run-to-run differences)."""
+    kw = _kw(cfg_params, 3.0)
+    old = _fresh(sd, monkeypatch, dtype, ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN="0", ST_SMALL_GRID="0")
+    new = _fresh(sd, monkeypatch, dtype, ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN="1", ST_SMALL_GRID="0")
+    for B, T, lengths in ((2, 126, [126, 100]), (1, 127, [127]), (3, 253, [253, 252, 1]), (2, 700, [700, 255]), (4, 1000, [1000, 873, 640, 377])):
+        inp = make_inputs(B, T, seed=60 + T, lengths=lengths)
+        ref = _solve(old, inp, 2, "euler", kw)
+        for _ in range(3):
+            out = _solve(new, inp, 2, "euler", kw)
+            assert torch.equal(out, ref), (B, T, float((out - ref).abs().max()))
+    # one evaluation with a per-item t (the training-shaped entry point) through the same launches
+    inp = make_inputs(3, 400, seed=61, lengths=[400, 399, 17])
+    t = torch.tensor([0.1, 0.5, 0.9])
+    args = (t.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+    with torch.no_grad():
+        assert torch.equal(new.estimator(*args), old.estimator(*args))
+
+
 def test_small_grid_variants_match_the_plain_kernels(sd, cfg_params, monkeypatch):
     """Split-K convolutions (+ row-wise finish kernel), 64-frame tiles and the key-split attention kernel change only
     the fp32 summation order: a small solve with them (default) and without (ST_SMALL_GRID=0) must agree to fp32
