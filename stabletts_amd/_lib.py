@@ -24,7 +24,7 @@ SOLVERS = {"euler": ST_SOLVER_EULER, "midpoint": ST_SOLVER_MIDPOINT, "rk4": ST_S
 # every symbol include/stabletts_hip.h declares
 EXPORTS = [
     "st_abi_version", "st_create", "st_destroy", "st_last_error", "st_load_param", "st_num_params",
-    "st_finalize", "st_bind_param", "st_repack", "st_train_serial", "st_estimator_forward", "st_cfm_solve", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
+    "st_finalize", "st_bind_param", "st_repack", "st_train_serial", "st_estimator_forward", "st_cfm_solve", "st_output_status", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
     "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad", "st_param_grads_flat",
@@ -96,6 +96,8 @@ def load():
     lib.st_cfm_solve.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.st_cfm_solve.restype = c_int
+    lib.st_output_status.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_int)]
+    lib.st_output_status.restype = c_int
     lib.st_last_solve_stats.argtypes = [c_void_p] + [ctypes.POINTER(ctypes.c_int64)] * 3
     lib.st_last_solve_stats.restype = c_int
     lib.st_debug_capture.argtypes = [c_void_p, c_int]
@@ -288,6 +290,12 @@ class Engine:
             lay[None] = off
             self._grad_layout = lay
         return lay
+
+    def output_nonfinite(self, stream):
+        """True when a call completed since the last query wrote NaN / Inf to its output (synchronises ``stream``)."""
+        flag = ctypes.c_int(0)
+        self._check(self.lib.st_output_status(self.handle, ctypes.c_void_p(stream), ctypes.byref(flag)))
+        return bool(flag.value)
 
     def last_solve_stats(self):
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()

@@ -28,8 +28,12 @@ from .estimator import Decoder
 
 class CFMDecoder(nn.Module):
     def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels, n_heads,
-                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="f16"):
+                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="f16", check_finite=False):
         super().__init__()
+        # check_finite=True: every forward() asks the engine whether its output contains NaN / Inf (one stream
+        # synchronisation per call) and raises -- f16 operands overflow at 65504, which an fp32 checkpoint may exceed; the
+        # remedy is operand_dtype="bf16" (INTEGRATION.md section 2).  Off by default: serving loops enqueue solves back to back.
+        self.check_finite = check_finite
         self.noise_channels = noise_channels
         self.cond_channels = cond_channels
         self.hidden_channels = hidden_channels
@@ -72,8 +76,13 @@ class CFMDecoder(nn.Module):
                 raise ValueError("fake_speaker must be (1, gin) and fake_content (1, n_feats, 1)")
         out = torch.empty_like(mu)
         with torch.cuda.device(dev):
-            eng.cfm_solve(mu, mask, z, c, int(n_timesteps), _lib.SOLVERS[solver], use_cfg, strength, fs, fc, out,
-                          torch.cuda.current_stream(dev).cuda_stream)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            eng.cfm_solve(mu, mask, z, c, int(n_timesteps), _lib.SOLVERS[solver], use_cfg, strength, fs, fc, out, stream)
+            if self.check_finite and eng.output_nonfinite(stream):
+                raise FloatingPointError(
+                    "stabletts_amd: the solve produced NaN / Inf.  With operand_dtype='f16' an activation beyond 65504 "
+                    "overflows its MFMA operand: construct the decoder with operand_dtype='bf16' (same range as fp32), or "
+                    "check the inputs.")
         return out
 
     def _solve_with_torchdiffeq(self, mu, mask, n_timesteps, temperature, c, solver, cfg_kwargs, z):
