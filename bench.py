@@ -137,14 +137,20 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
             opt.step()
         torch.cuda.synchronize(dev)
         whole = (time.perf_counter() - t0) / steps
-    fwd_flops = 2.0 * (12320768 + 3072 * T + 4325376) * B * T           # one evaluation incl. the prenet, padded frames
+    # one evaluation incl. the prenet over the VALID frames (SURVEY 8(d)'s ragged rule: linear terms on sum(len), the attention
+    # term on sum(len^2)) -- the kernels skip the work past each utterance's end, so padded frames are not algorithmic work
+    lens = raw["lengths"].double()
+    fwd_flops = float(2.0 * ((12320768 + 4325376) * lens.sum() + 3072 * (lens * lens).sum()))
+    fwd_flops_padded = 2.0 * (12320768 + 3072 * T + 4325376) * B * T
     fb = (times["fwd"] + times["bwd"]) / steps
     res = {"workload": f"BASELINE config 5 on one GPU: compute_loss forward + backward + AdamW, B={B} x T={T} ragged "
                        f"({valid} valid frames), per-item t, dropout {'0.1' if dropout else 'off (eval mode)'}, {dtype} operands",
            "ms_forward": times["fwd"] / steps * 1e3, "ms_backward": times["bwd"] / steps * 1e3,
            "ms_optimizer_incl_repack": times["opt"] / steps * 1e3, "ms_step_back_to_back": whole * 1e3,
            "mel_frames_per_sec_step": valid / whole, "tflops_fwd_bwd_3x_forward": 3 * fwd_flops / fb / 1e12,
-           "frac_of_mfma_peak": 3 * fwd_flops / fb / 1e12 / MFMA_PEAK_TFLOPS, "loss_first_last": [losses[0], losses[-1]],
+           "frac_of_mfma_peak": 3 * fwd_flops / fb / 1e12 / MFMA_PEAK_TFLOPS,
+           "flops_basis": "valid frames: sum(len), sum(len^2)", "tflops_if_padded_frames_counted": 3 * fwd_flops_padded / fb / 1e12,
+           "loss_first_last": [losses[0], losses[-1]],
            "torch_GB": torch.cuda.max_memory_allocated(dev) / 1e9, "engine_GB": dec.estimator.engine().device_bytes() / 1e9}
     del dec, opt
     return res
@@ -153,7 +159,7 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
 # kernel that implements each profiled class on the default path (for the PMC traffic lookup)
 CLASS_KERNEL = {
     "ffn_conv1": "conv_gemm_phased3_kernel<st::Op{DT}, 0, false>",
-    "ffn_conv2": "conv_gemm_phased3_kernel<st::Op{DT}, 2, false>",
+    "ffn_conv2": "ffn_fused_kernel<st::Op{DT}, 0, 0>",        # the whole FFN since round 4 (conv_1 + SiLU + conv_2 in one launch)
     "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
     "attention": "attention_kernel<st::Op{DT}, false>",
     "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 128, 4, 2, 1>",
@@ -163,7 +169,7 @@ CLASS_KERNEL = {
 
 def _pmc_table():
     """Committed rocprofv3 PMC passes of this same command (newest round first)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", name))), name
         except Exception:

@@ -43,10 +43,46 @@ constexpr int kFfnArea = 136 * 128, kFfnSlab = 16384, kFfnRing = 5;
 constexpr int kFfnOffRing = 4 * kFfnArea, kFfnOffBias = kFfnOffRing + kFfnRing * kFfnSlab, kFfnOffSink = kFfnOffBias + 8192;
 constexpr int kFfnLds = kFfnOffSink + 1024;      // 160,768 B
 
-// ABL (developer ablations, tools only; results are garbage): 1 = no epilogue, 2 = no SiLU arithmetic, 4 = no weight DMA
-template <class P, int ABL>
+// LDS-DMA pieces a wave issues in local phase lp of a chunk (lp < 0: the previous, non-last chunk): 2 weight pieces unless the
+// stream has ended, + 1 h piece in phases 1..3 (this chunk's h cin chunk 3 -> area 3) and, unless this is the last chunk, in
+// phases 1..3 of S2's sub-chunks 1..3 (the next chunk's h cin chunks 0..2 -> the areas S2 has finished with)
+constexpr bool ffn_w_issued(int lp, bool last, int depth) { return !last || lp + depth < 48; }
+constexpr bool ffn_h_issued(int lp, bool last) { return (lp >= 1 && lp <= 3) || (!last && lp >= 30 && (lp - 24) % 6 >= 1 && (lp - 24) % 6 <= 3); }
+constexpr int ffn_n_issued(int lp, bool last, int depth) {
+    return lp < 0 ? ffn_n_issued(lp + 48, false, depth) : 2 * (int)ffn_w_issued(lp, last, depth) + (int)ffn_h_issued(lp, last);
+}
+// pieces that may stay outstanding at the top of phase lp: slab lp + 1 was issued in phase lp + 1 - depth, everything younger may fly
+constexpr int ffn_allowed(int lp, bool last, int depth) {
+    int n = 0;
+    for (int k = 1; k <= depth - 2; ++k) n += ffn_n_issued(lp - k, last, depth);
+    return n;
+}
+template <int N> __device__ __forceinline__ void ffn_dma_wait() {
+    static_assert(N >= 0 && N <= 9, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+}
+
+// VAR: bit 0 = the phase's LDS-DMA issues sit between the two halves of its MFMAs (after the barrier) instead of in the read
+//      segment; bit 1 = slab p + 4 instead of p + 3 is issued in phase p (legal only with bit 0: the slot it overwrites was last
+//      read in the interval that ends with barrier #p).
+// ABL (developer ablations, tools only; results are garbage): 1 = no epilogue, 2 = no SiLU arithmetic, 4 = the weight stream
+//      re-reads its first slabs (cache-hot source), 8 = no top-of-phase waits, 16 = no LDS-DMA inside the loop, 32 = no MFMAs,
+//      64 = s_memtime stamps per phase segment (g.dbg).  VAR bit 2 = no s_setprio around the MFMAs, bit 3 = software-pipelined
+//      phases without the group stagger (FF_PHASE_P).
+template <class P, int ABL, int VAR>
 __global__ __launch_bounds__(512, 1)
 void ffn_fused_kernel(const ConvGemmArgs g) {
+    constexpr int PLACE = VAR & 1, DEPTH = (VAR & 2) ? 4 : 3;
+    static_assert(DEPTH == 3 || PLACE == 1 || (VAR & 8), "depth 4 needs the issue after the barrier");
     using vec8 = typename P::vec8;
     constexpr int FV = kFfnFusedFrames, AREA = kFfnArea, SLAB = kFfnSlab, RING = kFfnRing;
     constexpr int OFF_RING = kFfnOffRing, OFF_BIAS = kFfnOffBias, OFF_SINK = kFfnOffSink;
@@ -117,15 +153,16 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
 
     // ---- LDS-DMA issue ---------------------------------------------------------------------------------------------------
     auto issueH = [&](int ci, int k) {      // k: compile-time after unrolling
+        if constexpr (ABL & 16) return;
         const unsigned char* sb = h_s + ci * 128;
         const unsigned dst = (k < 2) ? lds0 + (unsigned)(ci * AREA + (wave + 8 * k) * 1024)
                                      : (wave == 0 ? lds0 + (unsigned)(ci * AREA + 16 * 1024) : lds0 + (unsigned)OFF_SINK);
         glds16bo(validH[k] ? sb + voffH[k] : zeros, dst);
     };
-    unsigned roff = 0, woff = 3 * SLAB, sig = 3;      // ring offsets of the slab being read / issued, index of the slab being issued
+    unsigned roff = 0, woff = DEPTH * SLAB, sig = DEPTH;      // ring offsets of the slab being read / issued, index of the slab being issued
     auto issueW = [&]() {
-        if constexpr (ABL & 4) return;
-        const unsigned char* sb = w_s + (size_t)sig * SLAB + (size_t)wave * 2048;
+        if constexpr (ABL & 16) return;
+        const unsigned char* sb = w_s + (size_t)((ABL & 4) ? sig % 5 : sig) * SLAB + (size_t)wave * 2048;
         const unsigned d = lds0 + (unsigned)OFF_RING + woff + (unsigned)wave * 2048u;
         glds16o(sb, voffL, d);
         glds16o(sb + 1024, voffL, d + 1024);
@@ -135,9 +172,13 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) issueH(ci, k);
+        for (int k = 0; k < 3; ++k) {
+            const unsigned dst = (k < 2) ? lds0 + (unsigned)(ci * AREA + (wave + 8 * k) * 1024)
+                                         : (wave == 0 ? lds0 + (unsigned)(ci * AREA + 16 * 1024) : lds0 + (unsigned)OFF_SINK);
+            glds16bo(validH[k] ? h_s + ci * 128 + voffH[k] : zeros, dst);
+        }
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
+    for (int sl = 0; sl < DEPTH; ++sl) {
         const unsigned char* sb = w_s + (size_t)sl * SLAB + (size_t)wave * 2048;
         const unsigned d = lds0 + (unsigned)(OFF_RING + sl * SLAB) + (unsigned)wave * 2048u;
         glds16o(sb, voffL, d);
@@ -158,24 +199,35 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
             for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.0f;
 
     vec8 wfr[2][2], bfr[2][2];
+    // ABL & 64: s_memtime stamps per phase segment -> g.dbg[block][wave 0 / 4][8] = top wait, barrier (group 1), reads + issue,
+    // barrier (group 0), MFMA issue (to the next phase's top), SiLU step, -, total loop ticks
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tstart = 0;
+    if constexpr (ABL & 64) { tlast = tstart = __builtin_amdgcn_s_memtime(); }
 #define ST_BARRIER_IF(cond) asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lnb_%=\n\ts_barrier\n.Lnb_%=:" :: "s"(cond) : "memory", "scc")
-    // top-of-phase wait: everything but the pieces of the previous phase (2 weight pieces, + 1 where it carried an h piece; the
-    // last chunk issues no h pieces and, in its last three phases, no weights)
+    // top-of-phase wait: everything but the pieces of the last DEPTH - 2 phases (ffn_allowed)
 #define FF_TOPWAIT(LP)                                                                           \
-    if constexpr ((LP) >= 2 && (LP) <= 4) { ST_DMA_WAIT(3); }                                    \
-    else if constexpr ((LP) >= 32 && ((LP) - 24) % 6 >= 2 && ((LP) - 24) % 6 <= 4) {             \
-        if (!lastc) { ST_DMA_WAIT(3); } else if ((LP) >= 46) { ST_DMA_WAIT(0); } else { ST_DMA_WAIT(2); } \
-    } else if constexpr ((LP) >= 46) { if (lastc) { ST_DMA_WAIT(0); } else { ST_DMA_WAIT(2); } } \
-    else { ST_DMA_WAIT(2); }
+    if constexpr (!(ABL & 8)) {                                                                  \
+        if (lastc) ffn_dma_wait<ffn_allowed((LP), true, DEPTH)>(); else ffn_dma_wait<ffn_allowed((LP), false, DEPTH)>(); \
+    }
 #define FF_ISSUE(LP)                                                                             \
-    if ((LP) < 45 || !lastc) issueW();                                                           \
+    if ((LP) + DEPTH < 48 || !lastc) issueW();                                                   \
     if constexpr ((LP) >= 1 && (LP) <= 3) issueH(3, (LP) - 1);                                   \
     if constexpr ((LP) >= 30 && ((LP) - 24) % 6 >= 1 && ((LP) - 24) % 6 <= 3) { if (!lastc) issueH(((LP) - 24) / 6 - 1, ((LP) - 24) % 6 - 1); }
-#define FF_PHASE(ACC, AR, J, KP, LP)                                                             \
+#define FF_MMA(ACC, KSL)                                                                         \
+    if constexpr (ABL & 32) { asm volatile("" :: "v"(wfr[KSL][0]), "v"(wfr[KSL][1]), "v"(bfr[KSL][0]), "v"(bfr[KSL][1])); } \
+    else {                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                            \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b) ACC[a][b] = P::mfma(wfr[KSL][a], bfr[KSL][b], ACC[a][b]); \
+    }
+#define FF_STAMP(K) if constexpr (ABL & 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tm[K] += t_ - tlast; tlast = t_; }
+#define FF_PHASE_S(ACC, AR, J, KP, LP)                                                           \
     {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        FF_STAMP(4)                                                                              \
         FF_TOPWAIT(LP)                                                                           \
+        FF_STAMP(0)                                                                              \
         ST_BARRIER_IF(grp);                                                                      \
+        FF_STAMP(1)                                                                              \
         {                                                                                        \
             const unsigned wad = wbase + roff;                                                   \
             _Pragma("unroll") for (int ksl = 0; ksl < 2; ++ksl) {                                \
@@ -183,20 +235,60 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
                 _Pragma("unroll") for (int b = 0; b < 2; ++b) bfr[ksl][b] = as_vec8<P>(lds_read16(aadr[J][2 * (KP) + ksl] + (AR) * AREA + b * 4096)); \
             }                                                                                    \
         }                                                                                        \
-        FF_ISSUE(LP)                                                                             \
+        if constexpr (!PLACE) { FF_ISSUE(LP) }                                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        FF_STAMP(2)                                                                              \
         ST_BARRIER_IF(ngrp);                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                           \
-        _Pragma("unroll") for (int ksl = 0; ksl < 2; ++ksl)                                      \
-            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                        \
-                _Pragma("unroll") for (int b = 0; b < 2; ++b) ACC[a][b] = P::mfma(wfr[ksl][a], bfr[ksl][b], ACC[a][b]); \
-        __builtin_amdgcn_s_setprio(0);                                                           \
+        FF_STAMP(3)                                                                              \
+        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);                                 \
+        FF_MMA(ACC, 0)                                                                           \
+        if constexpr (PLACE) {                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            FF_ISSUE(LP)                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+        FF_MMA(ACC, 1)                                                                           \
+        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         roff += SLAB; if (roff == RING * SLAB) roff = 0;                                         \
         woff += SLAB; if (woff == RING * SLAB) woff = 0;                                         \
         sig += 1;                                                                                \
     }
+    // VAR & 8: software-pipelined phase, no group stagger.  Every wave: barrier, reads of the phase's second k-step, LDS-DMA issues,
+    // MFMAs of the first k-step (its fragments were read during the previous phase), reads of the NEXT phase's first k-step, MFMAs of
+    // the second k-step -- a wave's LDS latency hides under its own MFMAs.  The next slab is read one phase early: the top-of-phase
+    // wait + barrier that cover slab p + 1 precede it; a slab's last read is finished before the barrier of the next phase, so the
+    // ring's WAR distance is one barrier (DEPTH <= RING - 1).  Stage starts (phases 0 and 24) load both halves.
+#define FF_LOAD_HALF(KSL, ROFF, AR, J, KP)                                                       \
+    {                                                                                            \
+        const unsigned wad_ = wbase + (ROFF);                                                    \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) wfr[KSL][a] = as_vec8<P>(lds_read16(wad_ + (KSL) * 8192 + a * 1024)); \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) bfr[KSL][b] = as_vec8<P>(lds_read16(aadr[J][2 * (KP) + (KSL)] + (AR) * AREA + b * 4096)); \
+    }
+#define FF_PHASE_P(ACC, AR, J, KP, LP)                                                           \
+    {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        FF_TOPWAIT(LP)                                                                           \
+        ST_RAW_BARRIER();                                                                        \
+        if constexpr ((LP) == 0 || (LP) == 24) FF_LOAD_HALF(0, roff, AR, J, KP)                  \
+        FF_LOAD_HALF(1, roff, AR, J, KP)                                                         \
+        FF_ISSUE(LP)                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);                                 \
+        FF_MMA(ACC, 0)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        roff += SLAB; if (roff == RING * SLAB) roff = 0;                                         \
+        woff += SLAB; if (woff == RING * SLAB) woff = 0;                                         \
+        sig += 1;                                                                                \
+        if constexpr ((LP) != 23 && (LP) != 47) FF_LOAD_HALF(0, roff, (((LP) + 1) % 24) / 6, (((LP) + 1) % 6) / 2, ((LP) + 1) & 1) \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        FF_MMA(ACC, 1)                                                                           \
+        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+#define FF_PHASE(ACC, AR, J, KP, LP)                                                             \
+    if constexpr (VAR & 8) FF_PHASE_P(ACC, AR, J, KP, LP) else FF_PHASE_S(ACC, AR, J, KP, LP)
 #define FF_STAGE6(ACC, AR, BASE)                                                                 \
     FF_PHASE(ACC, AR, 0, 0, (BASE) + 0) FF_PHASE(ACC, AR, 0, 1, (BASE) + 1)                      \
     FF_PHASE(ACC, AR, 1, 0, (BASE) + 2) FF_PHASE(ACC, AR, 1, 1, (BASE) + 3)                      \
@@ -251,11 +343,24 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         ST_RAW_BARRIER();
+        FF_STAMP(5)
         // ---- S2: conv_2, K = (u sub-chunk, tap, k-step); areas it has finished with are refilled with h for the next chunk
         FF_STAGE6(acc2, 0, 24) FF_STAGE6(acc2, 1, 30) FF_STAGE6(acc2, 2, 36) FF_STAGE6(acc2, 3, 42)
     }
+    if constexpr (ABL & 64) {
+        if (g.dbg && lane == 0 && (wave & 3) == 0 && lin < 64) {
+            unsigned long long* d = g.dbg + (size_t)(lin * 2 + (wave >> 2)) * 8;
+            for (int k = 0; k < 6; ++k) d[k] = tm[k];
+            d[6] = 0; d[7] = __builtin_amdgcn_s_memtime() - tstart;
+        }
+    }
+#undef FF_STAMP
 #undef FF_STAGE6
 #undef FF_PHASE
+#undef FF_PHASE_S
+#undef FF_PHASE_P
+#undef FF_LOAD_HALF
+#undef FF_MMA
 #undef FF_ISSUE
 #undef FF_TOPWAIT
 #undef ST_BARRIER_IF
@@ -271,6 +376,9 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
 #ifndef ST_FFN_ABL
 #define ST_FFN_ABL 0
 #endif
+#ifndef ST_FFN_VAR
+#define ST_FFN_VAR 0
+#endif
 
 template <class P>
 static hipError_t launch_ffn_fused_t(const ConvGemmArgs& a, hipStream_t s) {
@@ -278,7 +386,7 @@ static hipError_t launch_ffn_fused_t(const ConvGemmArgs& a, hipStream_t s) {
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_done_dev[dev_]) {
-        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<P, ST_FFN_ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds);
+        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<P, ST_FFN_ABL, ST_FFN_VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds);
         if (e != hipSuccess) return e;
         attr_done_dev[dev_] = true;
     }
@@ -289,7 +397,7 @@ static hipError_t launch_ffn_fused_t(const ConvGemmArgs& a, hipStream_t s) {
     b.tiles_c = 1;
     const int total = b.n_items * b.tiles_f;
     const int grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL((ffn_fused_kernel<P, ST_FFN_ABL>), dim3(grid), dim3(512), kFfnLds, s, b);
+    hipLaunchKernelGGL((ffn_fused_kernel<P, ST_FFN_ABL, ST_FFN_VAR>), dim3(grid), dim3(512), kFfnLds, s, b);
     return hipGetLastError();
 }
 

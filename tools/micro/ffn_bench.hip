@@ -1,0 +1,102 @@
+// Stand-alone benchmark of the fused FFN kernel (stabletts_amd/csrc/ffn_fused.h) at the headline launch shape: 64 CFG-doubled
+// items x 1000 frames, F = 1024, f16 operands, the heaviest epilogue (RESGATE + fused FiLM / LayerNorm / modulate, fp32 row
+// written).  Every (ABL, VAR) variant listed below is timed interleaved; variants with ABL = 0 must reproduce variant (0, 0)'s
+// output bit for bit (checked).  Developer tool: build + run with tools/micro/run_ffn_bench.sh on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../stabletts_amd/csrc/ffn_fused.h"
+
+using namespace st;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static unsigned rng_state = 12345u;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
+
+template <int ABL, int VAR>
+static float run(const ConvGemmArgs& a0, int reps, hipStream_t s) {
+    CK(hipFuncSetAttribute((const void*)ffn_fused_kernel<OpF16, ABL, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds));
+    ConvGemmArgs b = a0;
+    b.tiles_f = (b.T + kFfnFusedFrames - 1) / kFfnFusedFrames;
+    b.tiles_c = 1;
+    const int total = b.n_items * b.tiles_f, grid = ((total + 7) / 8) * 8;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((ffn_fused_kernel<OpF16, ABL, VAR>), dim3(grid), dim3(512), kFfnLds, s, b);      // warm-up
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ffn_fused_kernel<OpF16, ABL, VAR>), dim3(grid), dim3(512), kFfnLds, s, b);
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    return ms * 1000.0f / reps;
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 1000, F = 1024, C = 256, reps = 20, rounds = 3;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const size_t rows = (size_t)N * T;
+    std::vector<_Float16> h(rows * C), w((size_t)2 * F * C * 3);
+    for (auto& v : h) v = (_Float16)(frand() * 2.0f);
+    for (auto& v : w) v = (_Float16)(frand() * 0.08f);
+    std::vector<float> b1(F), b2(C), gate((size_t)N * C), mask((size_t)(N / 2) * T, 1.0f), x(rows * C), film(2 * C), ada((size_t)N * 2 * C);
+    for (auto& v : b1) v = frand() * 0.1f;
+    for (auto& v : b2) v = frand() * 0.1f;
+    for (auto& v : gate) v = frand();
+    for (auto& v : x) v = frand() * 2.0f;
+    for (auto& v : film) v = 1.0f + frand() * 0.1f;
+    for (auto& v : ada) v = frand() * 0.1f;
+    void *dh, *dw, *db1, *db2, *dgate, *dmask, *dx, *dxo, *do16, *dln, *dfilm, *dada, *dz;
+    CK(hipMalloc(&dh, h.size() * 2)); CK(hipMalloc(&dw, w.size() * 2)); CK(hipMalloc(&db1, F * 4)); CK(hipMalloc(&db2, C * 4));
+    CK(hipMalloc(&dgate, gate.size() * 4)); CK(hipMalloc(&dmask, mask.size() * 4)); CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&dxo, x.size() * 4));
+    CK(hipMalloc(&do16, rows * C * 2)); CK(hipMalloc(&dln, rows * C * 2)); CK(hipMalloc(&dfilm, film.size() * 4)); CK(hipMalloc(&dada, ada.size() * 4));
+    CK(hipMalloc(&dz, 256)); CK(hipMemset(dz, 0, 256));
+    CK(hipMemcpy(dh, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db1, b1.data(), F * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db2, b2.data(), C * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dgate, gate.data(), gate.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dmask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dfilm, film.data(), film.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dada, ada.data(), ada.size() * 4, hipMemcpyHostToDevice));
+
+    ConvGemmArgs a; memset(&a, 0, sizeof(a));
+    a.a0 = dh; a.c0 = C; a.a0_mod = N; a.a1_mod = N; a.w = dw; a.bias = (const float*)db2; a.bias1 = (const float*)db1; a.cmid = F;
+    a.cout = C; a.T = T; a.n_items = N; a.mask = (const float*)dmask; a.mask_mod = N / 2; a.flags = GF_SILU | GF_MASK;
+    a.gate = (const float*)dgate; a.gate_stride = C; a.res32 = (const float*)dx; a.out32 = (float*)dxo; a.out16 = do16; a.zeros = dz;
+    a.ln_h16 = dln; a.ln_film = (const float*)dfilm; a.ln_film_stride = 0; a.ln_film_mod = 1;
+    a.ln_ada = (const float*)dada; a.ln_ada_stride = 2 * C; a.ln_shift_off = 0; a.ln_scale_off = C; a.ln_mask_out = 0;
+
+    const double gflop = 2.0 * 2.0 * rows * (double)F * C * 3 * 1e-9;
+    std::vector<unsigned short> ref(rows * C), out(rows * C);
+    auto check = [&](const char* name, bool is_ref) {
+        CK(hipMemcpy(out.data(), dln, out.size() * 2, hipMemcpyDeviceToHost));
+        if (is_ref) { ref = out; return; }
+        size_t bad = 0; for (size_t i = 0; i < out.size(); ++i) bad += out[i] != ref[i];
+        printf("   check %-10s: %zu of %zu outputs differ from variant (0,0)%s\n", name, bad, out.size(), bad ? "  <-- MISMATCH" : "");
+    };
+#define RUNV(ABL, VAR) { const float us = run<ABL, VAR>(a, reps, s); printf("round %d  ABL %2d VAR %d : %7.1f us  %6.0f TF/s\n", r, ABL, VAR, us, gflop / us * 1e-3); fflush(stdout); }
+    for (int r = 0; r < rounds; ++r) {
+        RUNV(0, 0) if (r == 0) check("(0,0)", true);
+        RUNV(0, 1) if (r == 0) check("(0,1)", false);
+        RUNV(0, 3) if (r == 0) check("(0,3)", false);
+        RUNV(0, 8) if (r == 0) check("(0,8)", false);
+        RUNV(0, 10) if (r == 0) check("(0,10)", false);
+        RUNV(0, 12) RUNV(0, 14) RUNV(3, 8) RUNV(3, 10) RUNV(3, 14) RUNV(19, 10) RUNV(35, 10)
+        RUNV(1, 0) RUNV(3, 0)
+    }
+    {   // phase anatomy (ABL 64: s_memtime stamps; ticks of the constant-rate counter)
+        unsigned long long* dd; CK(hipMalloc(&dd, 64 * 2 * 8 * 8)); CK(hipMemset(dd, 0, 64 * 2 * 8 * 8));
+        ConvGemmArgs ad = a; ad.dbg = dd;
+        const float us = run<65, 0>(ad, 1, s);
+        std::vector<unsigned long long> hd(64 * 2 * 8); CK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
+        const char* nm[8] = {"top wait", "barrier(g1)", "reads+issue", "barrier(g0)", "mfma issue", "silu step", "-", "total"};
+        printf("anatomy (ABL 65, %.1f us per launch; ticks per phase, block 0/1/2 group 0 | group 1):\n", us);
+        for (int k = 0; k < 8; ++k) {
+            printf("  %-12s", nm[k]);
+            for (int blk = 0; blk < 3; ++blk) printf("  %8.1f | %8.1f", hd[(blk * 2 + 0) * 8 + k] / 192.0, hd[(blk * 2 + 1) * 8 + k] / 192.0);
+            printf("\n");
+        }
+    }
+    // run-to-run determinism of the shipped candidate (a race in the barrier / vmcnt protocol shows up here)
+    { run<0, 10>(a, 1, s); CK(hipDeviceSynchronize()); check("(0,10) rerun", false); }
+    return 0;
+}
