@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ST_ABI_VERSION 2
+#define ST_ABI_VERSION 3
 
 enum {
     ST_OK = 0,
@@ -206,11 +206,26 @@ int64_t st_train_serial(const st_engine* e);
 int st_train_backward(st_engine* e, int64_t serial, int B, int T, const float* grad_out, float* grad_x, float* grad_mu,
                       float* grad_c, void* stream);
 
+/* The same backward in three PARTS, so that a data-parallel wrapper (DDP, train.py:49-51) can reduce the gradients of finished
+ * layers while the remaining ones are still being computed -- torch's autograd delivers them layer by layer, a single native call
+ * would deliver all 116 at once:
+ *     part 0: final_proj, blocks L-1 .. L/2, the long-skip convs      part 1: blocks L/2-1 .. 0
+ *     part 2: in_proj, the cond prenet, the time MLP; writes d x, d mu, d c (grad_x / grad_mu / grad_c, each may be NULL)
+ * st_train_param_part(name) says which part finishes a parameter's gradient.  Parts run in order 0, 1, 2 (ST_ERR_STATE otherwise);
+ * grad_out is read by part 0 only.  grad_flat (part 0; may be NULL = the engine's own buffers, fetch with st_param_grad): a
+ * caller-owned device buffer of st_train_grad_numel() floats that receives EVERY parameter gradient of this backward directly
+ * -- no staging copy -- at st_train_grad_offset(name) (reference shape, 64-byte aligned slices, st_param_info's order); it must stay
+ * valid until part 2 has run.  The legacy call above = the three parts with the engine's own buffers. */
+int st_train_backward_part(st_engine* e, int64_t serial, int B, int T, int part, const float* grad_out, float* grad_flat,
+                           int64_t grad_numel, float* grad_x, float* grad_mu, float* grad_c, void* stream);
+int st_train_param_part(const st_engine* e, const char* name);        /* 0, 1, 2; < 0: unknown name */
+int64_t st_train_grad_offset(const st_engine* e, const char* name);   /* element offset in the flat gradient layout; < 0: unknown */
+int64_t st_train_grad_numel(const st_engine* e);                      /* floats of the flat layout (alignment gaps included) */
+
 /* Copies the gradient of one parameter (reference state_dict name, `numel` fp32 values) to the device pointer dst. */
 int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, void* stream);
 
-/* All parameter gradients in ONE copy: dst receives them back to back in st_param_info's order (index 0 first), `numel` =
- * the sum of all parameter sizes.  What loss.backward() of the autograd binding uses (one 81 MB copy instead of 116). */
+/* All parameter gradients in ONE copy: dst receives the flat layout described above (`numel` = st_train_grad_numel()). */
 int st_param_grads_flat(st_engine* e, float* dst, int64_t numel, void* stream);
 
 /* Non-finite guard (no reference analogue: the reference is fp32).  The kernel that writes the output of st_estimator_forward /

@@ -27,7 +27,8 @@ EXPORTS = [
     "st_finalize", "st_bind_param", "st_repack", "st_train_serial", "st_estimator_forward", "st_cfm_solve", "st_output_status", "st_last_solve_stats", "st_debug_capture", "st_debug_fetch",
     "st_create_text_encoder", "st_text_encoder_forward", "st_param_info",
     "st_profile_enable", "st_profile_select", "st_profile_stride", "st_profile_num_classes", "st_profile_class_name", "st_profile_read",
-    "st_device_bytes", "st_train_forward", "st_train_backward", "st_param_grad", "st_param_grads_flat",
+    "st_device_bytes", "st_train_forward", "st_train_backward", "st_train_backward_part", "st_train_param_part", "st_train_grad_offset",
+    "st_train_grad_numel", "st_param_grad", "st_param_grads_flat",
     "st_durations", "st_generate_path", "st_align", "st_create_vocoder", "st_vocos_forward",
 ]
 
@@ -128,6 +129,14 @@ def load():
     lib.st_train_forward.restype = c_int
     lib.st_train_backward.argtypes = [c_void_p, ctypes.c_int64, c_int, c_int] + [c_void_p] * 4 + [c_void_p]
     lib.st_train_backward.restype = c_int
+    lib.st_train_backward_part.argtypes = [c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_int64] + [c_void_p] * 3 + [c_void_p]
+    lib.st_train_backward_part.restype = c_int
+    lib.st_train_param_part.argtypes = [c_void_p, ctypes.c_char_p]
+    lib.st_train_param_part.restype = c_int
+    lib.st_train_grad_offset.argtypes = [c_void_p, ctypes.c_char_p]
+    lib.st_train_grad_offset.restype = ctypes.c_int64
+    lib.st_train_grad_numel.argtypes = [c_void_p]
+    lib.st_train_grad_numel.restype = ctypes.c_int64
     lib.st_param_grad.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_int64, c_void_p]
     lib.st_param_grad.restype = c_int
     lib.st_param_grads_flat.argtypes = [c_void_p, c_void_p, ctypes.c_int64, c_void_p]
@@ -142,7 +151,7 @@ def load():
     lib.st_create_vocoder.restype = c_int
     lib.st_vocos_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.st_vocos_forward.restype = c_int
-    if lib.st_abi_version() != 2:
+    if lib.st_abi_version() != 3:
         raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -269,25 +278,41 @@ class Engine:
         self._check(self.lib.st_train_backward(self.handle, int(serial), B, T, grad_out.data_ptr(), ptr(grad_x), ptr(grad_mu),
                                                ptr(grad_c), ctypes.c_void_p(stream)))
 
+    def train_backward_part(self, serial, part, B, T, grad_out, grad_flat, grad_x, grad_mu, grad_c, stream):
+        """One of the three parts of a backward (0: final_proj + upper blocks + long-skip convs, 1: lower blocks, 2: in_proj /
+        prenet / time MLP + input gradients); grad_flat (part 0) receives every parameter gradient directly (grad_layout())."""
+        ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+        self._check(self.lib.st_train_backward_part(self.handle, int(serial), B, T, int(part), ptr(grad_out), ptr(grad_flat),
+                                                    grad_flat.numel() if grad_flat is not None else 0, ptr(grad_x), ptr(grad_mu),
+                                                    ptr(grad_c), ctypes.c_void_p(stream)))
+
+    def param_part(self, name):
+        r = self.lib.st_train_param_part(self.handle, name.encode())
+        if r < 0:
+            raise NativeError(r, f"st_train_param_part({name})")
+        return r
+
     def param_grad(self, name, dst, stream):
         self._check(self.lib.st_param_grad(self.handle, name.encode(), dst.data_ptr(), dst.numel(), ctypes.c_void_p(stream)))
 
     def param_grads_flat(self, dst, stream):
-        """Every parameter gradient in one copy: dst (fp32, sum of all parameter sizes) in param_info() order."""
+        """Every parameter gradient in one copy: dst (fp32, grad_layout()[None] elements) in the flat layout."""
         self._check(self.lib.st_param_grads_flat(self.handle, dst.data_ptr(), dst.numel(), ctypes.c_void_p(stream)))
 
     def grad_layout(self):
         """{reference name: (offset, numel, shape)} of param_grads_flat's layout (cached)."""
         lay = getattr(self, "_grad_layout", None)
         if lay is None:
-            lay, off = {}, 0
+            lay = {}
             for name, shape in self.param_info():
                 n = 1
                 for d in shape:
                     n *= d
-                lay[name] = (off, n, shape)
-                off += n
-            lay[None] = off
+                off = self.lib.st_train_grad_offset(self.handle, name.encode())
+                if off < 0:
+                    raise NativeError(int(off), f"st_train_grad_offset({name})")
+                lay[name] = (int(off), n, shape)       # slices start on 64-byte boundaries
+            lay[None] = int(self.lib.st_train_grad_numel(self.handle))
             self._grad_layout = lay
         return lay
 

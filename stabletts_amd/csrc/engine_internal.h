@@ -188,5 +188,6 @@ int train_prepare(st_engine* e, hipStream_t s);       // packs the transposed (d
 void train_invalidate(st_engine* e);                  // called by st_finalize
 void train_destroy(st_engine* e);
 int64_t train_bytes(const st_engine* e);              // device bytes held by the training state
+int64_t train_grad_layout(const st_engine* e, std::map<std::string, int64_t>* offs);   // flat parameter-gradient layout (64-byte aligned slices); returns the total
 
 }  // namespace sthost

@@ -38,8 +38,14 @@ struct TrainState {
     Conv finT, inxT, incT, preT[3];
     std::vector<Conv> ffn1T, ffn2T, oprojT, qkvT, lscTa, lscTb;
     std::vector<void*> owned;
-    std::map<std::string, float*> grads;       // fp32 gradient buffers, reference shapes: slices of grad_flat in parameter-name order
+    // fp32 parameter gradients, reference shapes, in ONE flat buffer: parameter-name order (st_param_info's), every slice starting
+    // on a 64-byte boundary (goff; st_train_grad_offset).  gbase = where the running backward writes them: the engine's own
+    // grad_flat (st_train_backward + st_param_grad) or a buffer of the caller (st_train_backward_part: no staging copy).
+    std::map<std::string, float*> grads;       // slices of grad_flat
+    std::map<std::string, int64_t> goff;
     float* grad_flat = nullptr; int64_t grad_numel = 0;
+    float* gbase = nullptr;
+    int next_part = 0; int64_t part_serial = 0;   // st_train_backward_part: the part expected next of the backward of forward #part_serial
     // activation + scratch arena of the last train_forward
     char* ws = nullptr; size_t ws_cap = 0;
     int B = 0, T = 0, Tp = 0;
@@ -96,6 +102,16 @@ int pack_T(st_engine* e, TrainState* ts, Conv& cv, const std::string& wname, int
 
 }  // namespace
 
+// Flat layout of the parameter gradients: name order, each slice aligned to 16 floats (vectorised optimizers, 64-byte rows).
+int64_t train_grad_layout(const st_engine* e, std::map<std::string, int64_t>* offs) {
+    int64_t off = 0;
+    for (auto& kv : e->params) {
+        if (offs) (*offs)[kv.first] = off;
+        off += (kv.second.numel() + 15) / 16 * 16;
+    }
+    return off;
+}
+
 void train_invalidate(st_engine* e) {
     if (e->train) { e->train->packed = false; e->train->have_fwd = false; }
 }
@@ -148,12 +164,12 @@ int train_prepare(st_engine* e, hipStream_t s) {
         if ((rc = pack_T(e, ts, ts->lscTb[j], n, C, 2 * C, K, C, C, C, C, s))) return rc;
     }
     if (!ts->grad_flat) {      // one allocation, parameter-name order (st_param_info's order): st_param_grads_flat copies it in one piece
-        int64_t total = 0;
-        for (auto& kv : e->params) total += kv.second.numel();
+        const int64_t total = train_grad_layout(e, &ts->goff);
         HIPCHK(e, hipMalloc((void**)&ts->grad_flat, (size_t)total * 4)); ts->owned.push_back(ts->grad_flat);
+        HIPCHK(e, hipMemsetAsync(ts->grad_flat, 0, (size_t)total * 4, s));      // (the alignment gaps are never written)
         ts->grad_numel = total;
-        int64_t off = 0;
-        for (auto& kv : e->params) { ts->grads[kv.first] = ts->grad_flat + off; off += kv.second.numel(); }
+        for (auto& kv : ts->goff) ts->grads[kv.first] = ts->grad_flat + kv.second;
+        ts->gbase = ts->grad_flat;
     }
     if ((rc = pk_end(e, e->pk_T, s))) return rc;
     ts->packed = true;
@@ -500,37 +516,51 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     return ST_OK;
 }
 
-float* G(TrainState* ts, const std::string& name) { return ts->grads.at(name); }
+float* G(TrainState* ts, const std::string& name) { return ts->gbase + ts->goff.at(name); }
 
 }  // namespace
 }  // namespace sthost
 
-extern "C" {
+// The backward runs in three PARTS so that a data-parallel wrapper can start reducing the gradients of the layers that are done
+// while the rest is still computing (train.py:49-51,78-81 under DDP: buckets become ready part by part):
+//   part 0: d out -> final_proj, blocks L-1 .. L/2 with their long-skip convs        (parameters: final_proj, lsc_layers, blocks >= L/2)
+//   part 1: blocks L/2-1 .. 0                                                        (parameters: blocks < L/2)
+//   part 2: in_proj, the cond prenet, the time MLP; d x, d mu, d c                   (parameters: in_proj, cond_proj, time_mlp)
+// Each block finishes its own per-item linears (adaLN modulation, FiLM) as soon as its d ada / d film rows are complete.
+namespace sthost {
+namespace {
 
-int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float* grad_out, float* grad_x, float* grad_mu,
-                      float* grad_c, void* stream) {
-    if (!e) return ST_ERR_INVALID;
-    if (e->kind != 0 || !e->train || !e->train->have_fwd)
-        return e->fail(ST_ERR_STATE, "st_train_backward needs a preceding st_train_forward (none held: never run, or invalidated by a parameter update)");
-    if (serial != e->train->serial || B_ != e->train->B || T_ != e->train->T)
-        return e->fail(ST_ERR_STATE, "st_train_backward: the engine holds the activations of forward #" + std::to_string(e->train->serial) +
-                       " (B=" + std::to_string(e->train->B) + ", T=" + std::to_string(e->train->T) + "), not of #" + std::to_string(serial) +
-                       " (B=" + std::to_string(B_) + ", T=" + std::to_string(T_) + "): one backward per forward, before the next grad-enabled forward");
-    if (!grad_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
-    HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t s = (hipStream_t)stream;
-    TrainState* ts = e->train;
-    ProfScope prof(e, s, PC_TRAIN_BWD, 0);
-    const int C = e->C, F = e->F, M = e->M, Mp = e->Mp, L = e->L, H = e->H, K = e->K, N = ts->B, B = ts->B, T = ts->T, Tp = ts->Tp;
-    const int64_t R = (int64_t)N * T;
+struct BwdDims { int C, F, M, Mp, L, H, K, N, B, T, Tp; int64_t R; int chunks; };
+BwdDims bwd_dims(const st_engine* e, const TrainState* ts) {
+    BwdDims d{e->C, e->F, e->M, e->Mp, e->L, e->H, e->K, ts->B, ts->B, ts->T, ts->Tp, (int64_t)ts->B * ts->T, red_chunks(ts->T)};
+    return d;
+}
+
+// Re-centres the pass-wide power-of-two gradient scale on the running gradient dX (device side, no host sync): whenever its
+// maximum has left [2^1, 2^9) it is brought to [2^5, 2^6), dX is multiplied by the same factor (the kernel returns at once
+// when it is 1) and every later fp32 result is un-scaled by the new pair.  Called at every point where the NEXT kernels round
+// gradients to 16 bits: block boundaries and, inside a block, after each LayerNorm backward -- with trained-like weights (adaLN
+// gates of O(1), peaky attention) the gradient grows by more than two orders of magnitude INSIDE a block and overflowed f16
+// (65504) when the scale was only re-centred per block (profiles/r04_nan_trace.txt).
+int recentre(st_engine* e, TrainState* ts, const BwdDims& d, hipStream_t s) {
+    HIPCHK(e, launch_grad_rescale(ts->dX, d.R * d.C, ts->gbits, ts->gsc, s));
+    HIPCHK(e, launch_scale_by(ts->dX, d.R * d.C, ts->gsc, s));
+    return ST_OK;
+}
+
+int bwd_head(st_engine* e, TrainState* ts, const float* grad_out, hipStream_t s) {
+    const BwdDims d = bwd_dims(e, ts);
+    const int C = d.C, M = d.M, Mp = d.Mp, L = d.L, N = d.N, B = d.B, T = d.T;
+    const int64_t R = d.R;
     const float* m = ts->maskbuf;
-    const int chunks = red_chunks(T);
     int rc;
     const bool cap = e->capture;
     HIPCHK(e, hipMemsetAsync(ts->dada, 0, (size_t)L * N * 6 * C * 4, s));
     HIPCHK(e, hipMemsetAsync(ts->dfilm, 0, (size_t)L * N * 2 * C * 4, s));
     for (const char* nm : {"time_mlp.layer.0.weight", "time_mlp.layer.0.bias", "time_mlp.layer.2.weight", "time_mlp.layer.2.bias"})
         HIPCHK(e, hipMemsetAsync(G(ts, nm), 0, (size_t)e->params.at(nm).numel() * 4, s));
+    HIPCHK(e, hipMemsetAsync(ts->dcvec, 0, (size_t)N * e->G * 4, s));
+    HIPCHK(e, hipMemsetAsync(ts->dtau, 0, (size_t)N * C * 4, s));
     // d v (time-major, masked: out = (W x + b) * mask), as the 16-bit operand of the first GEMMs
     HIPCHK(e, launch_grad_scale(grad_out, (int64_t)B * M * T, ts->gbits, ts->gsc, s));
     HIPCHK(e, launch_to_time_major(e->dt, grad_out, B, M, T, Mp, ts->gin, nullptr, nullptr, s));
@@ -542,21 +572,27 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
     if (cap) { capture(e, "g.scale", ts->gsc, 2, false, s); capture(e, "g.x3_" + std::to_string(L - 1), ts->dX, R * C, false, s); }
-    for (int i = L - 1; i >= 0; --i) {
+    return ST_OK;
+}
+
+int bwd_block(st_engine* e, TrainState* ts, int i, hipStream_t s) {
+    const BwdDims d = bwd_dims(e, ts);
+    const int C = d.C, F = d.F, L = d.L, H = d.H, K = d.K, N = d.N, B = d.B, T = d.T, Tp = d.Tp, chunks = d.chunks;
+    const int64_t R = d.R;
+    const float* m = ts->maskbuf;
+    int rc;
+    const bool cap = e->capture;
+    {
         LayerAct& A = ts->L[i];
         const std::string b = e->blk(i);
         const float* ada_i = ts->ada + (size_t)i * N * 6 * C;
         float* dada_i = ts->dada + (size_t)i * N * 6 * C;
         // The gradient's magnitude changes by orders of magnitude from block to block (FiLM's gamma multiplies the whole residual
-        // stream: ~0.05 at initialisation): re-centre the pass-wide power-of-two scale on the running gradient whenever its
-        // maximum has left [2^4, 2^12), so that every 16-bit operand derived from it inside this block sits in f16's normal range.
-        // dX, which lives in scaled units, is multiplied by the same factor (the kernel returns at once when it is 1); every fp32
-        // result is un-scaled by the pair current at the time it is written; a long-skip gradient remembers the scale it was
-        // written at (skip_sc) and is converted when it is added.
-        if (i < L - 1) {
-            HIPCHK(e, launch_grad_rescale(ts->dX, R * C, ts->gbits, ts->gsc, s));
-            HIPCHK(e, launch_scale_by(ts->dX, R * C, ts->gsc, s));
-        }
+        // stream: ~0.05 at initialisation) and, with trained-like weights, inside a block: the pass-wide power-of-two scale is
+        // re-centred on the running gradient here and after each LayerNorm backward (recentre), so that every 16-bit operand
+        // derived from it sits in f16's range.  Every fp32 result is un-scaled by the pair current at the time it is written; a
+        // long-skip gradient remembers the scale it was written at (skip_sc) and is converted when it is added.
+        if (i < L - 1 && (rc = recentre(e, ts, d, s))) return rc;
         if (cap) capture(e, "g.scale_" + std::to_string(i), ts->gsc, 2, false, s);      // the scale block i's captured tensors carry
         // ---- x3 = x2 + g_mlp * f
         HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.f32b, ada_i + 5 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
@@ -584,6 +620,8 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         HIPCHK(e, launch_ln_bwd(A.x2, ts->tmpC, ada_i, 6 * C, 4 * C, m, B, 1, T, N, ts->dX, ts->red, nullptr, s));
         { const int off[2] = {4 * C, 3 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
         if (cap) capture(e, "g.x2_" + std::to_string(i), ts->dX, R * C, false, s);
+        if ((rc = recentre(e, ts, d, s))) return rc;
+        if (cap) capture(e, "g.scale_a" + std::to_string(i), ts->gsc, 2, false, s);      // the scale of this block's attention-part tensors
         // ---- x2 = x1 + g_msa * o
         HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.o32, ada_i + 2 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
         { const int off[1] = {2 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 1, dada_i, 6 * C, off, 0, ts->gsc, s)); }
@@ -635,6 +673,8 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         HIPCHK(e, launch_ln_bwd(A.x1, ts->tmpC, ada_i, 6 * C, C, m, B, 0, T, N, ts->dX, ts->red, ts->qs, s));
         { const int off[2] = {C, 0}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
         if (cap) capture(e, "g.x1_" + std::to_string(i), ts->dX, R * C, false, s);
+        if ((rc = recentre(e, ts, d, s))) return rc;
+        if (cap) capture(e, "g.scale_b" + std::to_string(i), ts->gsc, 2, false, s);      // ... and of what follows (g.xin_i)
         // ---- x1 = (gamma * xpre + beta) * mask
         HIPCHK(e, launch_film_bwd(e->dt, xpre_of(ts, i, L), ts->film + (size_t)i * N * 2 * C, 2 * C, N, m, B, T, N, ts->dX,
                                   i >= L / 2 ? ts->g16b : nullptr, ts->red, s));
@@ -655,6 +695,39 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         if (i < L / 2) HIPCHK(e, launch_add_rescaled(ts->dX, ts->dskip[i], R * C, ts->gsc, ts->skip_sc + 2 * i, s));
         if (cap) capture(e, "g.xin_" + std::to_string(i), ts->dX, R * C, false, s);
     }
+    {   // this block's per-item linears: adaLN modulation (-> d c), FiLM (-> d tau); its d ada / d film rows are complete now
+        const std::string pa = e->blk(i) + "adaLN_modulation.2.";
+        float* gw = G(ts, pa + "weight"); float* gb = G(ts, pa + "bias");
+        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)6 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)6 * C * 4, s));
+        const float* dout = ts->dada + (size_t)i * N * 6 * C;
+        if (e->G == C) {
+            HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, s));
+            HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, 1, s));
+        } else {        // through SiLU into adaLN_modulation.0, then into c
+            const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
+            const float* pre = ts->ada_pre + (size_t)i * N * C;
+            float* g0w = G(ts, p0 + "weight"); float* g0b = G(ts, p0 + "bias");
+            HIPCHK(e, hipMemsetAsync(g0w, 0, (size_t)C * e->G * 4, s)); HIPCHK(e, hipMemsetAsync(g0b, 0, (size_t)C * 4, s));
+            HIPCHK(e, launch_linear_bwd_w(pre, dout, N, C, 6 * C, 1, gw, gb, s));
+            HIPCHK(e, launch_linear_bwd_in(pre, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dada_pre, 0, s));
+            HIPCHK(e, launch_linear_bwd_w(ts->cvec, ts->dada_pre, N, e->G, C, 0, g0w, g0b, s));
+            HIPCHK(e, launch_linear_bwd_in(ts->cvec, ts->dada_pre, P(e, p0 + "weight"), N, e->G, C, 0, ts->dcvec, 1, s));
+        }
+        const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
+        gw = G(ts, pf + "weight"); gb = G(ts, pf + "bias");
+        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)2 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)2 * C * 4, s));
+        const float* dfo = ts->dfilm + (size_t)i * N * 2 * C;
+        HIPCHK(e, launch_linear_bwd_w(ts->tau, dfo, N, C, 2 * C, 0, gw, gb, s));
+        HIPCHK(e, launch_linear_bwd_in(ts->tau, dfo, P(e, pf + "weight"), N, C, 2 * C, 0, ts->dtau, 1, s));
+    }
+    return ST_OK;
+}
+
+int bwd_tail(st_engine* e, TrainState* ts, float* grad_x, float* grad_mu, float* grad_c, hipStream_t s) {
+    const BwdDims d = bwd_dims(e, ts);
+    const int C = d.C, F = d.F, M = d.M, Mp = d.Mp, K = d.K, N = d.N, B = d.B, T = d.T;
+    const int64_t R = d.R;
+    int rc;
     // ---- in_proj: h0 = Wx x + Wc cond + b
     HIPCHK(e, launch_cast16(e->dt, ts->dX, nullptr, 1, T, C, R, nullptr, ts->g16b, s));
     {
@@ -693,39 +766,97 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
         }
     }
     // ---- per-item vectors: adaLN (-> d c), FiLM (-> d tau), time MLP
-    HIPCHK(e, hipMemsetAsync(ts->dcvec, 0, (size_t)N * e->G * 4, s));
-    HIPCHK(e, hipMemsetAsync(ts->dtau, 0, (size_t)N * C * 4, s));
-    for (int i = 0; i < L; ++i) {
-        const std::string pa = e->blk(i) + "adaLN_modulation.2.";
-        float* gw = G(ts, pa + "weight"); float* gb = G(ts, pa + "bias");
-        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)6 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)6 * C * 4, s));
-        const float* dout = ts->dada + (size_t)i * N * 6 * C;
-        if (e->G == C) {
-            HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, s));
-            HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, 1, s));
-        } else {        // through SiLU into adaLN_modulation.0, then into c
-            const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
-            const float* pre = ts->ada_pre + (size_t)i * N * C;
-            float* g0w = G(ts, p0 + "weight"); float* g0b = G(ts, p0 + "bias");
-            HIPCHK(e, hipMemsetAsync(g0w, 0, (size_t)C * e->G * 4, s)); HIPCHK(e, hipMemsetAsync(g0b, 0, (size_t)C * 4, s));
-            HIPCHK(e, launch_linear_bwd_w(pre, dout, N, C, 6 * C, 1, gw, gb, s));
-            HIPCHK(e, launch_linear_bwd_in(pre, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dada_pre, 0, s));
-            HIPCHK(e, launch_linear_bwd_w(ts->cvec, ts->dada_pre, N, e->G, C, 0, g0w, g0b, s));
-            HIPCHK(e, launch_linear_bwd_in(ts->cvec, ts->dada_pre, P(e, p0 + "weight"), N, e->G, C, 0, ts->dcvec, 1, s));
-        }
-        const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
-        gw = G(ts, pf + "weight"); gb = G(ts, pf + "bias");
-        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)2 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)2 * C * 4, s));
-        const float* dfo = ts->dfilm + (size_t)i * N * 2 * C;
-        HIPCHK(e, launch_linear_bwd_w(ts->tau, dfo, N, C, 2 * C, 0, gw, gb, s));
-        HIPCHK(e, launch_linear_bwd_in(ts->tau, dfo, P(e, pf + "weight"), N, C, 2 * C, 0, ts->dtau, 1, s));
-    }
     HIPCHK(e, launch_linear_bwd_w(ts->th_pre, ts->dtau, N, F, C, 1, G(ts, "time_mlp.layer.2.weight"), G(ts, "time_mlp.layer.2.bias"), s));
     HIPCHK(e, launch_linear_bwd_in(ts->th_pre, ts->dtau, P(e, "time_mlp.layer.2.weight"), N, F, C, 1, ts->dth, 0, s));
     HIPCHK(e, launch_linear_bwd_w(ts->emb, ts->dth, N, C, F, 0, G(ts, "time_mlp.layer.0.weight"), G(ts, "time_mlp.layer.0.bias"), s));
     if (grad_c) HIPCHK(e, hipMemcpyAsync(grad_c, ts->dcvec, (size_t)N * e->G * 4, hipMemcpyDeviceToDevice, s));
     return ST_OK;
 }
+
+int bwd_check(st_engine* e, int64_t serial, int B_, int T_, const char* who) {
+    if (e->kind != 0 || !e->train || !e->train->have_fwd)
+        return e->fail(ST_ERR_STATE, std::string(who) + " needs a preceding st_train_forward (none held: never run, or invalidated by a parameter update)");
+    if (serial != e->train->serial || B_ != e->train->B || T_ != e->train->T)
+        return e->fail(ST_ERR_STATE, std::string(who) + ": the engine holds the activations of forward #" + std::to_string(e->train->serial) +
+                       " (B=" + std::to_string(e->train->B) + ", T=" + std::to_string(e->train->T) + "), not of #" + std::to_string(serial) +
+                       " (B=" + std::to_string(B_) + ", T=" + std::to_string(T_) + "): one backward per forward, before the next grad-enabled forward");
+    return ST_OK;
+}
+
+int bwd_part(st_engine* e, TrainState* ts, int part, const float* grad_out, float* grad_x, float* grad_mu, float* grad_c, hipStream_t s) {
+    ProfScope prof(e, s, PC_TRAIN_BWD, 0);
+    const int L = e->L;
+    int rc;
+    if (part == 0) {
+        if ((rc = bwd_head(e, ts, grad_out, s))) return rc;
+        for (int i = L - 1; i >= L / 2; --i) if ((rc = bwd_block(e, ts, i, s))) return rc;
+    } else if (part == 1) {
+        for (int i = L / 2 - 1; i >= 0; --i) if ((rc = bwd_block(e, ts, i, s))) return rc;
+    } else {
+        if ((rc = bwd_tail(e, ts, grad_x, grad_mu, grad_c, s))) return rc;
+    }
+    return ST_OK;
+}
+
+}  // namespace
+}  // namespace sthost
+
+extern "C" {
+
+int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float* grad_out, float* grad_x, float* grad_mu,
+                      float* grad_c, void* stream) {
+    if (!e) return ST_ERR_INVALID;
+    int rc = bwd_check(e, serial, B_, T_, "st_train_backward"); if (rc) return rc;
+    if (!grad_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+    HIPCHK(e, hipSetDevice(e->device));
+    TrainState* ts = e->train;
+    ts->gbase = ts->grad_flat; ts->next_part = 0;
+    for (int part = 0; part < 3; ++part)
+        if ((rc = bwd_part(e, ts, part, grad_out, grad_x, grad_mu, grad_c, (hipStream_t)stream))) return rc;
+    return ST_OK;
+}
+
+int st_train_backward_part(st_engine* e, int64_t serial, int B_, int T_, int part, const float* grad_out, float* grad_flat,
+                           int64_t grad_numel, float* grad_x, float* grad_mu, float* grad_c, void* stream) {
+    if (!e) return ST_ERR_INVALID;
+    int rc = bwd_check(e, serial, B_, T_, "st_train_backward_part"); if (rc) return rc;
+    TrainState* ts = e->train;
+    if (part < 0 || part > 2) return e->fail(ST_ERR_INVALID, "st_train_backward_part: part must be 0, 1 or 2");
+    if (part == 0) {
+        if (!grad_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
+        if (grad_flat && grad_numel != ts->grad_numel)
+            return e->fail(ST_ERR_INVALID, "st_train_backward_part: grad_numel must be st_train_grad_numel()");
+        ts->gbase = grad_flat ? grad_flat : ts->grad_flat;
+        ts->part_serial = serial;
+    } else if (ts->next_part != part || ts->part_serial != serial) {
+        return e->fail(ST_ERR_STATE, "st_train_backward_part: parts run in order 0, 1, 2 of ONE backward (expected part " +
+                       std::to_string(ts->next_part) + ")");
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    if ((rc = bwd_part(e, ts, part, grad_out, grad_x, grad_mu, grad_c, (hipStream_t)stream))) { ts->next_part = 0; return rc; }
+    ts->next_part = part == 2 ? 0 : part + 1;
+    if (part == 2) ts->gbase = ts->grad_flat;
+    return ST_OK;
+}
+
+int st_train_param_part(const st_engine* e, const char* name) {
+    if (!e || !name || e->kind != 0) return ST_ERR_INVALID;
+    const std::string n(name);
+    if (!e->params.count(n)) return ST_ERR_INVALID;
+    if (n.rfind("blocks.", 0) == 0) return atoi(n.c_str() + 7) >= e->L / 2 ? 0 : 1;
+    if (n.rfind("final_proj.", 0) == 0 || n.rfind("lsc_layers.", 0) == 0) return 0;
+    return 2;
+}
+
+int64_t st_train_grad_offset(const st_engine* e, const char* name) {
+    if (!e || !name) return ST_ERR_INVALID;
+    std::map<std::string, int64_t> offs;
+    train_grad_layout(e, &offs);
+    auto it = offs.find(name);
+    return it == offs.end() ? (int64_t)ST_ERR_INVALID : it->second;
+}
+
+int64_t st_train_grad_numel(const st_engine* e) { return e ? train_grad_layout(e, nullptr) : (int64_t)ST_ERR_INVALID; }
 
 int st_param_grads_flat(st_engine* e, float* dst, int64_t numel, void* stream) {
     if (!e || !dst) return ST_ERR_INVALID;

@@ -357,7 +357,8 @@ __global__ void grad_scale_kernel(const unsigned* bits, float* sc) {
     const float m = __uint_as_float(*bits);
     float s = 1.0f;
     if (m > 0.f) {
-        int ex = 8 - (int)floorf(log2f(m));           // max |g| * scale in [2^8, 2^9)
+        int ex = 5 - (int)floorf(log2f(m));           // max |g| * scale in [2^5, 2^6): eleven binades below f16's 65504 for what the
+                                                      // kernels up to the next re-centring point add, twenty above its normal minimum
         ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
         s = exp2f((float)ex);
     }
@@ -402,8 +403,8 @@ hipError_t launch_qkv_grad_scales(const float* dq, const float* dk, const float*
 __global__ void grad_rescale_kernel(const unsigned* bits, float* sc) {
     const float m = __uint_as_float(*bits);
     float f = 1.0f;
-    if (m > 0.f && (m < 16.0f || m >= 4096.0f)) {
-        int ex = 8 - (int)floorf(log2f(m));
+    if (m > 0.f && (m < 2.0f || m >= 512.0f)) {
+        int ex = 5 - (int)floorf(log2f(m));
         const int cur = (int)floorf(log2f(sc[0]));
         if (cur + ex > 100) ex = 100 - cur;              // keep the total scale a finite fp32 power of two
         if (cur + ex < -100) ex = -100 - cur;

@@ -105,7 +105,7 @@ def test_attention_backward_at_matched_inputs(sd, dt):
         m = inp["mask"][:, 0].double().numpy()
         bias = (1 - m)[:, None, None, :] * (-1e30)
         for i in (5, 2):
-            scale = float(eng.debug_fetch(f"g.scale_{i}")[0])      # the pass-wide power-of-two scale is re-centred block by block
+            scale = float(eng.debug_fetch(f"g.scale_a{i}")[0])     # the pass-wide power-of-two scale, re-centred before the attention part
             q = eng.debug_fetch(f"t{i}.q").reshape(B, 4, T, 64).astype(np.float64)        # q_s = q_r * log2(e) / 8
             k = eng.debug_fetch(f"t{i}.k").reshape(B, 4, T, 64).astype(np.float64)
             v = eng.debug_fetch(f"t{i}.vt").reshape(B, 4, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)
@@ -131,8 +131,9 @@ SIZE_B, SIZE_T, SIZE_LENS = 4, 1000, [1000, 873, 655, 512]
 # q / k projections at T = 1000 (measured on MI355X, f16 / bf16):
 #   end to end vs the fp32 oracle       2.2e-1 / 1.46, cosine 0.992 / 0.83   -- conditioning of d q, d k in the forward's operand rounding
 #   vs the oracle AT the native q, k, v  4.2e-3 / 2.6e-2, cosine 0.999995 / 0.99978  -- the native backward chain itself (the gate)
-TOL_QK_SIZE = {"f16": 4e-1, "bf16": 2.5}
-COS_QK_SIZE = {"f16": 0.98, "bf16": 0.7}
+TOL_QK_SIZE = {"f16": 4e-1, "bf16": None}      # bf16: a max-norm gate of 250 % is no gate -- its end-to-end q / k gradients are gated by
+COS_QK_SIZE = {"f16": 0.98, "bf16": 0.7}        # direction only (cosine) and by the matched-operand chain; bf16 is not a training dtype
+                                                # with parity (train with the default f16 operands)
 TOL_QK_MATCHED = {"f16": 1e-2, "bf16": 6e-2}
 
 
@@ -221,7 +222,7 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
         m = inp["mask"][:, 0].double().numpy()
         bias = (1 - m)[:, None, None, :] * (-1e30)
         for i in (5, 0):
-            scale = float(eng.debug_fetch(f"g.scale_{i}")[0])      # the pass-wide power-of-two scale is re-centred block by block
+            scale = float(eng.debug_fetch(f"g.scale_a{i}")[0])     # the pass-wide power-of-two scale, re-centred before the attention part
             q = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64).astype(np.float64)
             k = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64).astype(np.float64)
             v = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)
@@ -268,11 +269,117 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
         print(f"[{dt}/{tiles}] q/k gradients vs the oracle evaluated at the native q, k, v: worst {max(wm.values()):.2e}, min cosine {min(cm.values()):.6f}")
         assert max(wm.values()) <= TOL_QK_MATCHED[dt], wm
         # ---- and the end-to-end q / k numbers (conditioning-limited, see the docstring): loose gate
-        badq = {k: v for k, v in worst.items() if _is_qk(k) and v > TOL_QK_SIZE[dt]}
+        badq = {k: v for k, v in worst.items() if _is_qk(k) and TOL_QK_SIZE[dt] is not None and v > TOL_QK_SIZE[dt]}
         assert not badq, badq
         assert min(cosq.values()) >= COS_QK_SIZE[dt], cosq
     finally:
         eng.debug_capture(False)
+
+
+# ---------------------------------------------------------------- K optimizer steps vs the fp32 oracle
+TRAJ_B, TRAJ_T, TRAJ_LENS, TRAJ_K = 4, 250, [250, 231, 188, 120], 12
+
+
+def _traj_draws(k):
+    g0 = torch.Generator().manual_seed(7000 + k)
+    x1 = torch.randn(TRAJ_B, 128, TRAJ_T, generator=g0)
+    t_rand = torch.rand(TRAJ_B, 1, 1, generator=g0)
+    z = torch.randn(TRAJ_B, 128, TRAJ_T, generator=g0)
+    return x1, t_rand, z
+
+
+@pytest.fixture(scope="module")
+def oracle_trajectories(sd):
+    """K AdamW steps of oracle.compute_loss (fp32 PyTorch-CPU autograd: models/flow_matching.py:69-100 + train.py:78-82's
+    zero_grad / backward / step) from the seeded weights, dropout off, fixed per-step draws; for the reference's learning rate
+    (config.py:37: 1e-4) and for 10x it (ten times the parameter drift)."""
+    inp = make_inputs(TRAJ_B, TRAJ_T, seed=101, lengths=TRAJ_LENS)
+    out = {}
+    for lr in (1e-4, 1e-3):
+        pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.AdamW(list(pr.values()), lr=lr)
+        losses = []
+        for k in range(TRAJ_K):
+            x1, t_rand, z = _traj_draws(k)
+            opt.zero_grad()
+            with torch.enable_grad():
+                loss, _ = oracle.compute_loss(pr, x1, inp["mask"], inp["mu"], inp["c"], t_rand, z)
+                loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        out[lr] = dict(losses=losses, params={k: v.detach().numpy().copy() for k, v in pr.items()})
+    return dict(inp=inp, runs=out)
+
+
+@pytest.mark.parametrize("lr", [1e-4, 1e-3])
+def test_training_trajectory_matches_the_fp32_oracle(sd, oracle_trajectories, lr):
+    """Config 5's end-to-end statement: K = 12 AdamW steps through the NATIVE forward / backward (f16 operands, the shipping
+    type; in-place weight updates re-packed on the stream) against the same K steps through the fp32 oracle on the same
+    draws.  Per step the loss must agree to 1e-3; after K steps EVERY parameter tensor -- conv_q / conv_k, whose single-step
+    gradient is ill-conditioned at random init, included -- must sit within 2e-3 of the oracle's (max |d| / max |ref|), and the
+    accumulated UPDATE theta_K - theta_0 of every tensor must point the same way (cosine; Adam normalises each element's step to
+    ~lr, so an element whose tiny gradient flips sign moves by 2 lr whatever the backward's accuracy: the max-norm of the update
+    difference is printed, the cosine is gated)."""
+    inp = oracle_trajectories["inp"]
+    ref = oracle_trajectories["runs"][lr]
+    dec = _decoder(sd, "f16")                      # eval mode: dropout off (the masks are covered by their own test)
+    opt = torch.optim.AdamW(dec.parameters(), lr=lr)
+    mask, mu, c = inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()
+    losses = []
+    for k in range(TRAJ_K):
+        x1, t_rand, z = _traj_draws(k)
+        opt.zero_grad()
+        loss, _ = dec.compute_loss(x1.cuda(), mask, mu, c, t_rand=t_rand.cuda(), z=z.cuda())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    rel_loss = [abs(a - b) / b for a, b in zip(losses, ref["losses"])]
+    print(f"[lr={lr:g}] loss oracle {ref['losses'][0]:.5f} -> {ref['losses'][-1]:.5f}, native {losses[0]:.5f} -> {losses[-1]:.5f}; "
+          f"worst per-step rel diff {max(rel_loss):.2e}")
+    assert max(rel_loss) <= 1e-3, rel_loss
+    worst, cosw, upd = {}, {}, {}
+    for name, p in dec.estimator.named_parameters():
+        a, b, p0 = p.detach().cpu().numpy(), ref["params"][name], sd[name].numpy()
+        worst[name] = _rel(a, b)
+        cosw[name] = _cos(a - p0, b - p0)
+        upd[name] = _rel(a - p0, b - p0)
+    qk = [n for n in worst if _is_qk(n)]
+    print(f"[lr={lr:g}] after {TRAJ_K} steps: worst parameter diff {max(worst.values()):.2e} (q/k {max(worst[n] for n in qk):.2e}); update "
+          f"cosine min {min(cosw.values()):.4f} (q/k {min(cosw[n] for n in qk):.4f}); update max-norm diff worst {max(upd.values()):.2e} "
+          f"(q/k {max(upd[n] for n in qk):.2e})")
+    steps_off = {n: float(np.abs(p.detach().cpu().numpy() - ref["params"][n]).max()) / lr for n, p in dec.estimator.named_parameters()}
+    print(f"[lr={lr:g}] worst element deviation {max(steps_off.values()):.2f} lr (q/k {max(steps_off[n] for n in qk):.2f} lr)")
+    badc = {k: v for k, v in cosw.items() if v < 0.995}
+    assert not badc, badc
+    bads = {k: v for k, v in steps_off.items() if v > 3.0}
+    assert not bads, bads
+
+
+def test_qk_gradients_with_trained_like_attention(size_case):
+    """The conditioning argument of the module docstring, tested from the other side: with weights that look TRAINED -- adaLN
+    gates of O(1) (ada_std 0.15) and q / k projections scaled 6x, so the attention is peaky instead of near-uniform -- d q and d k
+    are no longer differences of nearly equal terms, and the END-TO-END conv_q / conv_k gradients of the shipping dtype must
+    match the fp32 oracle's autograd like every other tensor does (B = 4 x T = 1000 ragged, gate 2e-2)."""
+    sc = size_case
+    sd2 = oracle.make_state_dict(1234, ada_std=0.15)
+    for i in range(6):
+        for nm in ("q", "k"):
+            sd2[f"blocks.{i}.block.attn.conv_{nm}.weight"] = sd2[f"blocks.{i}.block.attn.conv_{nm}.weight"] * 6.0
+    inp = sc["inp"]
+    with torch.enable_grad():
+        pr = {k: v.clone().requires_grad_(True) for k, v in sd2.items()}
+        loss_ref, _ = oracle.compute_loss(pr, sc["x1"], inp["mask"], inp["mu"], inp["c"], sc["t_rand"], sc["z"])
+        loss_ref.backward()
+    dec = _decoder(sd2, "f16")
+    loss, _ = dec.compute_loss(sc["x1"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda(), t_rand=sc["t_rand"].cuda(), z=sc["z"].cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-3 * float(loss_ref.detach())
+    worst = {n: _rel(p.grad.cpu().numpy(), pr[n].grad.numpy()) for n, p in dec.estimator.named_parameters()}
+    cosq = {n: _cos(p.grad.cpu().numpy(), pr[n].grad.numpy()) for n, p in dec.estimator.named_parameters() if _is_qk(n)}
+    wq = max(v for k, v in worst.items() if _is_qk(k)); wo = max(v for k, v in worst.items() if not _is_qk(k))
+    print(f"trained-like weights (ada_std 0.15, q/k x6), B={SIZE_B} x T={SIZE_T}: worst non-q/k {wo:.2e}; q/k END TO END {wq:.2e}, min cosine {min(cosq.values()):.6f}")
+    assert wq <= 2e-2, {k: v for k, v in worst.items() if _is_qk(k)}
+    assert wo <= 1e-2, {k: v for k, v in worst.items() if not _is_qk(k) and v > 1e-2}
 
 
 @pytest.mark.parametrize("dt", ["f16"])
@@ -554,6 +661,39 @@ def test_ddp_two_ranks_match_single_process(tmp_path):
     assert a["losses"][-1] < a["losses"][0]                       # it trains
     for k in a["params"]:
         assert _rel(a["params"][k].numpy(), b["params"][k].numpy()) <= 2e-3, k
+
+
+def test_ddp_reduces_buckets_while_the_backward_is_still_running(tmp_path):
+    """train.py:49-51,78-81 under DDP: the native backward runs in three parts behind three chained autograd nodes
+    (st_train_backward_part), so the gradients of final_proj / the upper blocks / the long-skip convs reach DDP's reducer while
+    the lower blocks and the prenet are still to be enqueued.  From the second step on (DDP rebuilds its buckets in the order the
+    gradients arrived in the first) the reducer must launch its first bucket BEFORE the last part of the backward is enqueued
+    -- with one autograd node for the whole backward every bucket became ready at the same instant, after it.  2 ranks over gloo
+    on the shared GPU; losses as in the single-process run."""
+    out2, out1 = tmp_path / "ddp.pt", tmp_path / "one.pt"
+    port = 29500 + (os.getpid() % 200)
+    env = dict(os.environ, BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "train_ddp.py"), "--out", str(out2), "--backend", "gloo", "--trace"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_ddp.py"), "--out", str(out1)],
+                        env=dict(os.environ), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    a, b = torch.load(out2), torch.load(out1)
+    for la, lb in zip(a["losses"], b["losses"]):
+        assert abs(la - lb) <= 2e-4 * abs(lb), (a["losses"], b["losses"])
+    tr = a["trace"]
+    steps = [i for i, ev in enumerate(tr) if ev[0] == "step"] + [len(tr)]
+    for k in range(1, len(steps) - 1):                      # steps 1.. (buckets rebuilt after step 0)
+        ev = tr[steps[k]:steps[k + 1]]
+        parts = [i for i, x in enumerate(ev) if x[0] == "backward_part"]
+        buckets = [i for i, x in enumerate(ev) if x[0] == "bucket"]
+        assert [ev[i][1] for i in parts] == [0, 1, 2], ev
+        assert buckets and buckets[0] < parts[2], ev        # the reducer is at work before the last part is enqueued
+        before_last = sum(ev[i][2] for i in buckets if i < parts[2])
+        print(f"step {k}: {len(buckets)} buckets, {sum(1 for i in buckets if i < parts[1])} launched before part 1, "
+              f"{sum(1 for i in buckets if i < parts[2])} before part 2 ({before_last * 4 / 1e6:.1f} MB of {sum(ev[i][2] for i in buckets) * 4 / 1e6:.1f} MB)")
 
 
 def test_ddp_over_rccl_one_rank(tmp_path):

@@ -62,7 +62,8 @@ def main():
     l2.backward()
     params = dict(dec.estimator.named_parameters())
     for i in range(5, -1, -1):
-        scale = float(eng.debug_fetch(f"g.scale_{i}")[0])
+        scale2 = float(eng.debug_fetch(f"g.scale_{i}")[0])          # block start .. LayerNorm-2 backward (g.x2)
+        scale = float(eng.debug_fetch(f"g.scale_a{i}")[0])          # attention part (d attn, dq, dk, dv, g.x1)
         da = eng.debug_fetch(f"g.dattn_{i}").reshape(B, T, H * 64) / scale                      # time-major
         ra = keep[(i, "attn")].grad.permute(0, 2, 1).numpy()
         row = [f"block {i}: d attn {rel(da, ra):.2e} (max |ref| {np.abs(ra).max():.2e}, scaled max {np.abs(ra).max() * scale:.2e}, "
@@ -73,7 +74,7 @@ def main():
             got = eng.debug_fetch(f"g.d{nm}_{i}").reshape(B, H, T, 64) / scale * fac
             row.append(f"d{nm} {rel(got, keep[(i, nm)].grad.numpy()):.2e}")
         for nm in ("x2", "x1"):
-            got = eng.debug_fetch(f"g.{nm}_{i}").reshape(B, T, 256) / scale
+            got = eng.debug_fetch(f"g.{nm}_{i}").reshape(B, T, 256) / (scale2 if nm == "x2" else scale)
             row.append(f"d{nm} {rel(got, keep[(i, nm)].grad.permute(0, 2, 1).numpy()):.2e}")
         for nm in ("q", "k", "v", "o"):
             n = f"blocks.{i}.block.attn.conv_{nm}.weight"

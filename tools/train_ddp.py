@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--items", type=int, default=4)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--trace", action="store_true", help="record the host-side order of native backward parts and DDP bucket launches "
+                    "(saved as 'trace' in --out): the reducer must start on the first buckets before the last part is enqueued")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and wrap in DDP even for one rank "
                     "(a 1-GPU box can exercise the nccl = RCCL backend that way)")
     args = ap.parse_args()
@@ -52,6 +54,17 @@ def main():
     model = dec
     if use_dist:
         model = torch.nn.parallel.DistributedDataParallel(dec, device_ids=[dev.index])
+    trace = None
+    if args.trace:
+        from stabletts_amd import autograd as st_autograd
+        trace = st_autograd.TRACE = []
+        if use_dist:
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+            def hook(state, bucket):        # the default all-reduce, with the launch recorded
+                trace.append(("bucket", bucket.index(), int(bucket.buffer().numel())))
+                return default_hooks.allreduce_hook(state, bucket)
+            model.register_comm_hook(None, hook)
     opt = torch.optim.AdamW(dec.parameters(), lr=2e-4)
     B, T = args.items, args.frames
     inp = make_inputs(B, T, seed=61)                       # equal lengths: every rank's loss has the same normaliser
@@ -63,6 +76,8 @@ def main():
     for step in range(args.steps):
         t_rand = torch.rand(B, 1, 1, generator=gen); z = torch.randn(B, 128, T, generator=gen)
         opt.zero_grad()
+        if trace is not None:
+            trace.append(("step", step))
         if use_dist:       # DDP hooks fire on the module's forward: route compute_loss through it
             loss, _ = _DDPLoss(model)(x1[sl].to(dev), inp["mask"][sl].to(dev), inp["mu"][sl].to(dev), inp["c"][sl].to(dev),
                                       t_rand[sl].to(dev), z[sl].to(dev))
@@ -79,7 +94,7 @@ def main():
         keep = ["final_proj.weight", "blocks.3.block.mlp.conv_2.weight", "blocks.0.block.attn.conv_v.weight", "cond_proj.0.bias",
                 "blocks.5.block.adaLN_modulation.2.weight", "time_mlp.layer.0.weight"]
         params = {k: v.detach().cpu() for k, v in dec.estimator.named_parameters() if k in keep}
-        torch.save(dict(world=world, losses=losses, params=params), args.out)
+        torch.save(dict(world=world, losses=losses, params=params, trace=trace), args.out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
