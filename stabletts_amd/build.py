@@ -22,6 +22,8 @@ SOURCES = ["engine.cpp", "engine_train.cpp", "engine_vocos.cpp", "vocos_kernels.
 HEADERS = ["common.h", "launch.h", "train_launch.h", "vocos_launch.h", "engine_internal.h", "conv_gemm2_impl.h", "conv_gemm_phased.h", "conv_gemm2_inst.h", "ffn_fused.h", os.path.join("..", "..", "include", "stabletts_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-Rpass-analysis=kernel-resource-usage"]
+# per-source flags: the attention kernels keep their fp32 row-sum adds scalar (common.h: add_f32_scalar)
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 RESOURCES = os.path.join(OBJ, "kernel_resources.json")    # per-kernel VGPR / SGPR / scratch / occupancy of the last build
 FLAGS += os.environ.get("ST_BUILD_DEFS", "").split()
 
@@ -72,7 +74,7 @@ def _digest():
     for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -89,7 +91,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

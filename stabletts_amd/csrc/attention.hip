@@ -250,8 +250,8 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int r = 4 * g4 + 2 * h2;
                         float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                        psum[0] = add_f32_scalar(psum[0], p0);
-                        psum[1] = add_f32_scalar(psum[1], p1);
+                        psum[0] = add_f32_asm_safe(psum[0], p0);
+                        psum[1] = add_f32_asm_safe(psum[1], p1);
                         if (a.drop.thresh16) {
                             const float2 f = drop_factors2(a.drop, drop_pair(drop_rh, h2 ? ch.y : ch.x));
                             p0 *= f.x; p1 *= f.y;

@@ -79,11 +79,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + er);
 }
 
-// fp32 add that hipcc's SLP vectoriser cannot fuse into v_pk_add_f32: beside MFMAs a packed fp32 op costs more than the
-// two scalar ones it replaces (MI355X_MICROARCH.md, per-instruction constants; measured here: attention +28 %)
-__device__ __forceinline__ float add_f32_scalar(float a, float b) {
+// fp32 add of the attention kernels' row sums.  hipcc's SLP vectoriser would fuse neighbouring adds into v_pk_add_f32, and beside
+// MFMAs a packed fp32 op costs more than the two scalar ones it replaces (MI355X_MICROARCH.md, per-instruction constants;
+// measured here: attention +28 %) -- so attention.hip is compiled with -fno-slp-vectorize (build.py) and this is a plain add.
+// Until round 4 it was an inline-asm v_add_f32: hipcc does not run its hazard recogniser over asm operands, and where it
+// scheduled the add directly behind the v_exp_f32 that produces its input (the rarely taken re-reference path of the inference
+// kernel) the add read the register before the transcendental unit had written it (gfx950 needs one wait state there): row sums
+// off by the stale value, outputs scaled by up to 4x for moderately peaky attention (profiles/r04_attention_trans_hazard.txt).
+__device__ __forceinline__ float add_f32_scalar(float a, float b) { return a + b; }
+// The training variant of the attention kernel sits exactly at 128 VGPRs and spills with the plain add: it keeps the asm form,
+// with the wait state the hazard needs INSIDE the statement (s_nop 0 = one wait state: the transcendental result is readable).
+__device__ __forceinline__ float add_f32_asm_safe(float a, float b) {
     float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("s_nop 0\n\tv_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 

@@ -355,31 +355,82 @@ def test_training_trajectory_matches_the_fp32_oracle(sd, oracle_trajectories, lr
     assert not bads, bads
 
 
-def test_qk_gradients_with_trained_like_attention(size_case):
-    """The conditioning argument of the module docstring, tested from the other side: with weights that look TRAINED -- adaLN
-    gates of O(1) (ada_std 0.15) and q / k projections scaled 6x, so the attention is peaky instead of near-uniform -- d q and d k
-    are no longer differences of nearly equal terms, and the END-TO-END conv_q / conv_k gradients of the shipping dtype must
-    match the fp32 oracle's autograd like every other tensor does (B = 4 x T = 1000 ragged, gate 2e-2)."""
+def test_gradients_with_trained_like_weights(size_case):
+    """Weights that look TRAINED rather than initialised: adaLN gates of O(1) (ada_std 0.15) and q / k projections scaled 6x
+    (peaky attention), B = 4 x T = 1000 ragged, shipping dtype.  Two statements:
+      1. The native BACKWARD is right: every gradient -- all 116 tensors, conv_q / conv_k included -- agrees with the oracle's
+         autograd evaluated at the native forward's own q, k, v to 1.5e-2 (measured 6e-3).  (Round 3's backward overflowed f16
+         inside a block here -- the gradient grows ~350x between two LayerNorm backwards -- and returned NaN; the scale is now
+         re-centred after each of them.)
+      2. Why the comparison is made at matched attention operands: this high-gain random network is CHAOTIC.  Rounding the fp32
+         oracle's own q, k, v to f16 -- nothing native involved -- moves its own gradients by tens of percent (asserted > 5 %,
+         measured O(1)), so an end-to-end number against the un-perturbed fp32 oracle measures the network's conditioning, not the
+         kernels.  (At the seeded init the same end-to-end comparison holds to 1e-3 for every tensor but q / k, and the K-step
+         trajectory test above holds for all of them.)"""
     sc = size_case
     sd2 = oracle.make_state_dict(1234, ada_std=0.15)
     for i in range(6):
         for nm in ("q", "k"):
             sd2[f"blocks.{i}.block.attn.conv_{nm}.weight"] = sd2[f"blocks.{i}.block.attn.conv_{nm}.weight"] * 6.0
     inp = sc["inp"]
-    with torch.enable_grad():
-        pr = {k: v.clone().requires_grad_(True) for k, v in sd2.items()}
-        loss_ref, _ = oracle.compute_loss(pr, sc["x1"], inp["mask"], inp["mu"], inp["c"], sc["t_rand"], sc["z"])
-        loss_ref.backward()
+    B, T, H = SIZE_B, SIZE_T, 4
+    Tp = (T + 63) // 64 * 64
+    tt = np.arange(Tp)
+    pos = (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)
+
+    def oracle_grads(subst=None):
+        with torch.enable_grad():
+            pr = {k: v.clone().requires_grad_(True) for k, v in sd2.items()}
+            loss, _ = oracle.compute_loss(pr, sc["x1"], inp["mask"], inp["mu"], inp["c"], sc["t_rand"], sc["z"],
+                                          **({"qkv_subst": subst} if subst is not None else {}))
+            loss.backward()
+        return float(loss.detach()), {k: v.grad.numpy() for k, v in pr.items()}
+
+    loss_ref, g_ref = oracle_grads()
+    # (2) the oracle's own q, k, v rounded to f16 (taps of its fp32 forward), straight-through
+    taps = {}
+    with torch.no_grad():
+        t = 1 - torch.cos(sc["t_rand"] * 0.5 * torch.pi)
+        y = (1 - (1 - 1e-4) * t) * sc["z"] + t * sc["x1"]
+        oracle.decoder_forward(sd2, t.squeeze(), y, inp["mask"], inp["mu"], inp["c"], taps=taps)
+    sub16 = [{k: taps[f"b{i}.{k}"].half().float() for k in ("q", "k", "v")} for i in range(6)]
+    _, g_16 = oracle_grads(sub16)
+    cond = {n: _rel(g_16[n], g_ref[n]) for n in g_ref}
+    print(f"trained-like weights: fp32 oracle vs the SAME oracle with its q, k, v rounded to f16: gradients move by up to "
+          f"{max(cond.values()):.2e} (median over tensors {float(np.median(list(cond.values()))):.2e})")
+    assert max(cond.values()) > 5e-2
+    # (1) native backward vs the oracle at the native q, k, v
     dec = _decoder(sd2, "f16")
-    loss, _ = dec.compute_loss(sc["x1"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda(), t_rand=sc["t_rand"].cuda(), z=sc["z"].cuda())
-    loss.backward()
-    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-3 * float(loss_ref.detach())
-    worst = {n: _rel(p.grad.cpu().numpy(), pr[n].grad.numpy()) for n, p in dec.estimator.named_parameters()}
-    cosq = {n: _cos(p.grad.cpu().numpy(), pr[n].grad.numpy()) for n, p in dec.estimator.named_parameters() if _is_qk(n)}
-    wq = max(v for k, v in worst.items() if _is_qk(k)); wo = max(v for k, v in worst.items() if not _is_qk(k))
-    print(f"trained-like weights (ada_std 0.15, q/k x6), B={SIZE_B} x T={SIZE_T}: worst non-q/k {wo:.2e}; q/k END TO END {wq:.2e}, min cosine {min(cosq.values()):.6f}")
-    assert wq <= 2e-2, {k: v for k, v in worst.items() if _is_qk(k)}
-    assert wo <= 1e-2, {k: v for k, v in worst.items() if not _is_qk(k) and v > 1e-2}
+    eng = dec.estimator.engine()
+    eng.debug_capture(True)
+    try:
+        loss, _ = dec.compute_loss(sc["x1"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda(), t_rand=sc["t_rand"].cuda(), z=sc["z"].cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.detach()) - loss_ref) <= 1e-3 * loss_ref
+        subst = []
+        for i in range(6):
+            qn = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64) * (8.0 / math.log2(math.e))
+            kn = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64)
+            vn = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2)
+            subst.append({"q": torch.from_numpy(np.ascontiguousarray(qn)), "k": torch.from_numpy(np.ascontiguousarray(kn)),
+                          "v": torch.from_numpy(np.ascontiguousarray(vn))})
+    finally:
+        eng.debug_capture(False)
+    _, g_m = oracle_grads(subst)
+    with torch.no_grad():       # how far the 16-bit FORWARD is from fp32 in this regime (one evaluation at t = 0.5)
+        tq = torch.tensor(0.5)
+        fr = oracle.decoder_forward(sd2, tq, sc["z"], inp["mask"], inp["mu"], inp["c"])
+        fn = dec.estimator(tq.cuda(), sc["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+    print(f"trained-like weights: one forward evaluation, native f16 vs fp32 oracle: {_rel(fn.numpy(), fr.numpy()):.2e}")
+    params = dict(dec.estimator.named_parameters())
+    assert all(torch.isfinite(p.grad).all() for p in params.values())
+    worst = {n: _rel(params[n].grad.cpu().numpy(), g_m[n]) for n in params}
+    e2e = {n: _rel(params[n].grad.cpu().numpy(), g_ref[n]) for n in params}
+    print(f"trained-like weights: native vs the oracle at the native q, k, v: worst {max(worst.values()):.2e} (q/k "
+          f"{max(v for k, v in worst.items() if _is_qk(k)):.2e}); vs the un-perturbed fp32 oracle {max(e2e.values()):.2e} (conditioning, see (2))")
+    bad = {k: v for k, v in worst.items() if v > 1.5e-2}
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("dt", ["f16"])

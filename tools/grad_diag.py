@@ -24,7 +24,12 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     lens = [T, int(T * 0.873), int(T * 0.655), int(T * 0.512)][:B] + [T] * max(0, B - 4)
-    sd = oracle.make_state_dict(1234)
+    ada, qk = float(os.environ.get("GRAD_DIAG_ADA", "0.02")), float(os.environ.get("GRAD_DIAG_QK", "1"))
+    sd = oracle.make_state_dict(1234, ada_std=ada)         # GRAD_DIAG_ADA=0.15 GRAD_DIAG_QK=6: the "trained-like" weights of the tests
+    for i in range(6):
+        for nm in ("q", "k"):
+            sd[f"blocks.{i}.block.attn.conv_{nm}.weight"] = sd[f"blocks.{i}.block.attn.conv_{nm}.weight"] * qk
+    print(f"weights: ada_std {ada}, q/k projections x{qk}")
     dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dt)
     dec.estimator.load_state_dict(sd)
     dec = dec.cuda().eval()
