@@ -160,6 +160,19 @@ int st_generate_path(const float* duration, const float* mask, int B, int Tx, in
 int st_align(const float* cum, const float* x_mask, const int64_t* y_lengths, const float* mu_x, int B, int M, int Tx, int Ty,
              float* attn, float* mu_y, float* y_mask, void* stream);
 
+/* ---- CFMDecoder.compute_loss's own arithmetic (models/flow_matching.py:86-100), stateless like the alignment helpers ------
+ * st_cfm_loss_prep: t = 1 - cos(t_rand pi / 2) (:88), y = (1 - (1 - sigma) t) z + t x1 (:93), u = x1 - (1 - sigma) z (:96).
+ *   x1, z, y, u: (B, M, T); t_rand, t: (B).
+ * st_cfm_loss: loss = sum((pred - u)^2) / (sum(mask) * M) (:100; u is NOT masked, as in the reference) -> *loss (device);
+ *   scratch: st_cfm_loss_scratch_floats() floats, keeps the denominator for the backward; deterministic summation order.
+ * st_cfm_loss_backward: grad_pred = grad_loss[0] * 2 (pred - u) / (sum(mask) * M)  (grad_loss: device scalar). */
+int st_cfm_loss_prep(const float* x1, const float* z, const float* t_rand, float sigma_min, int B, int M, int T, float* t, float* y,
+                     float* u, void* stream);
+int st_cfm_loss(const float* pred, const float* u, const float* mask, int B, int M, int T, float* scratch, float* loss, void* stream);
+int st_cfm_loss_backward(const float* pred, const float* u, const float* scratch, const float* grad_loss, int B, int M, int T,
+                         float* grad_pred, void* stream);
+int st_cfm_loss_scratch_floats(void);
+
 /* ---- Vocos vocoder: mel -> waveform, the step after the decoder (api.py:76) ------------------------ */
 
 /* Replaces Vocos.__init__(VocosConfig(), MelConfig()) (vocoders/vocos/models/model.py:11-15, config.py:4-19,46-50). */

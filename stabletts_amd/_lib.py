@@ -30,6 +30,7 @@ EXPORTS = [
     "st_device_bytes", "st_train_forward", "st_train_backward", "st_train_backward_part", "st_train_param_part", "st_train_grad_offset",
     "st_train_grad_numel", "st_param_grad", "st_param_grads_flat",
     "st_durations", "st_generate_path", "st_align", "st_create_vocoder", "st_vocos_forward",
+    "st_cfm_loss_prep", "st_cfm_loss", "st_cfm_loss_backward", "st_cfm_loss_scratch_floats",
 ]
 
 
@@ -147,6 +148,14 @@ def load():
     lib.st_generate_path.restype = c_int
     lib.st_align.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.st_align.restype = c_int
+    lib.st_cfm_loss_prep.argtypes = [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.st_cfm_loss_prep.restype = c_int
+    lib.st_cfm_loss.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.st_cfm_loss.restype = c_int
+    lib.st_cfm_loss_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.st_cfm_loss_backward.restype = c_int
+    lib.st_cfm_loss_scratch_floats.argtypes = []
+    lib.st_cfm_loss_scratch_floats.restype = c_int
     lib.st_create_vocoder.argtypes = [ctypes.POINTER(StVocosConfig), c_int, ctypes.POINTER(c_void_p)]
     lib.st_create_vocoder.restype = c_int
     lib.st_vocos_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]

@@ -164,3 +164,72 @@ def estimator_apply(decoder, t, x, mask, mu, c):
     tok = _BottomFn.apply(sh, tuple(groups[2][0]), t, x, mask, mu, c, *groups[2][1])
     tok = _MidFn.apply(sh, tuple(groups[1][0]), tok, *groups[1][1])
     return _TopFn.apply(sh, tuple(groups[0][0]), tok, *groups[0][1])
+
+
+# ---------------------------------------------------------------- compute_loss's own arithmetic (models/flow_matching.py:86-100)
+def _check(rc):
+    from . import _lib
+    if rc != _lib.ST_OK:
+        raise _lib.NativeError(rc, _lib.load().st_last_error(None).decode())
+
+
+def cfm_loss_prep(x1, z, t_rand, sigma_min):
+    """t = 1 - cos(t_rand pi / 2), y = (1 - (1 - sigma) t) z + t x1, u = x1 - (1 - sigma) z in ONE native kernel
+    (st_cfm_loss_prep).  x1, z: (B, M, T) fp32 on the HIP device, t_rand: B values.  Returns t (B), y, u."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    dev = x1.device
+    B, M, T = x1.shape
+    x1c, zc = x1.detach().float().contiguous(), z.detach().float().contiguous()
+    tr = t_rand.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    if tr.numel() != B or zc.shape != x1c.shape:
+        raise ValueError("shape mismatch: x1 / z (B, M, T), t_rand B values")
+    t = torch.empty(B, device=dev, dtype=torch.float32)
+    y, u = torch.empty_like(x1c), torch.empty_like(x1c)
+    with torch.cuda.device(dev):
+        _check(lib.st_cfm_loss_prep(x1c.data_ptr(), zc.data_ptr(), tr.data_ptr(), float(sigma_min), B, M, T, t.data_ptr(), y.data_ptr(),
+                                    u.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return t, y, u
+
+
+class _CfmLossFn(torch.autograd.Function):
+    """sum((pred - u)^2) / (sum(mask) * n_feats) (:100) natively, forward and backward (u is data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, pred, u, mask):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        dev = pred.device
+        B, M, T = pred.shape
+        p32, u32 = pred.detach().float().contiguous(), u.detach().float().contiguous()
+        m32 = mask.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if u32.shape != p32.shape or m32.numel() != B * T:
+            raise ValueError("shape mismatch: pred / u (B, M, T), mask (B, 1, T)")
+        scratch = torch.empty(lib.st_cfm_loss_scratch_floats(), device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _check(lib.st_cfm_loss(p32.data_ptr(), u32.data_ptr(), m32.data_ptr(), B, M, T, scratch.data_ptr(), loss.data_ptr(),
+                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.save_for_backward(p32, u32, scratch)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        p32, u32, scratch = ctx.saved_tensors
+        dev = p32.device
+        B, M, T = p32.shape
+        g = grad_loss.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        gp = torch.empty_like(p32)
+        with torch.cuda.device(dev):
+            _check(lib.st_cfm_loss_backward(p32.data_ptr(), u32.data_ptr(), scratch.data_ptr(), g.data_ptr(), B, M, T, gp.data_ptr(),
+                                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return gp, None, None
+
+
+def cfm_loss(pred, u, mask):
+    return _CfmLossFn.apply(pred, u, mask)

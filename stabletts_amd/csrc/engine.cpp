@@ -187,7 +187,7 @@ struct Plan {
     bool cfg;
     // 16-bit MFMA operands.  *lo tensors hold x - float(hi): the split-precision operand pairs of the three GEMMs
     // whose rounding error reaches the output un-gated (in_proj x-part and cond-part, final_proj)
-    void *mu16, *pre1, *pre2, *cond16, *cond16lo, *x16, *x16lo, *h16, *q16, *k16, *vt16, *ao16, *u16, *cur16, *cur16lo;
+    void *mu16, *pre1, *pre2, *cond16, *cond16lo, *x16, *x16lo, *h16, *h2_16, *q16, *k16, *vt16, *ao16, *u16, *cur16, *cur16lo;
     void* skip16[8];
     // fp32
     float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
@@ -225,6 +225,11 @@ size_t layout_plan(st_engine* e, int B, int T, bool cfg, int n_t, size_t off, Pl
     want((void**)&p->ode_out, 16);
     want((void**)&p->X, N * TT * C * 4);
     want(&p->h16, N * TT * C * 2);
+    // FFN input of the fused FFN kernel: its blocks read h2 rows of NEIGHBOURING tiles (conv halo) until their last chunk while
+    // other blocks already write the next block's LayerNorm output -- which the two-kernel path puts into h16 itself (conv_1 has
+    // finished with it by then).  A separate buffer removes that cross-block write-after-read (found as run-to-run differences of
+    // 4e-5 with several solve parts in flight).
+    want(&p->h2_16, N * TT * C * 2);
     want(&p->q16, N * TT * C * 2);
     want(&p->k16, N * TT * C * 2);
     want(&p->vt16, N * (size_t)C * p->Tp * 2);
@@ -462,19 +467,20 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
         if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
+        // Big grids: the whole FFN as ONE kernel, u never leaves the CU (ffn_fused.h; bit-identical to the two launches below).
+        // Debug capture keeps the two-kernel path (it taps u).
+        const bool fused = e->fused_ffn && !cap && (int)e->ffn_stream.size() == L && e->ffn_stream[i] &&
+                           (int64_t)e->conc * N * ((T + kFfnFusedFrames - 1) / kFfnFusedFrames) >= e->big_min_blocks;
+        void* h2buf = fused ? p.h2_16 : p.h16;
         {   // out projection, gate, mask, residual (diffusion_transformer.py:65,111) + LN2, modulate, mask (:112,26)
             ConvGemmArgs a = base_args(e, p, e->oproj[i], N);
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
-            a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
+            a.ln_h16 = h2buf; a.ln_film = nullptr; a.ln_film_mod = 1;
             a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
             HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
         if (cap) { capture(e, bn + "x2", p.X, rowsC, false, s); capture(e, bn + "h2", p.h16, rowsC, true, s); }
-        // Big grids: the whole FFN as ONE kernel, u never leaves the CU (ffn_fused.h; bit-identical to the two launches below).
-        // Debug capture keeps the two-kernel path (it taps u).
-        const bool fused = e->fused_ffn && !cap && (int)e->ffn_stream.size() == L && e->ffn_stream[i] &&
-                           (int64_t)e->conc * N * ((T + kFfnFusedFrames - 1) / kFfnFusedFrames) >= e->big_min_blocks;
         if (!fused) {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
             ConvGemmArgs a = base_args(e, p, e->ffn1[i], N);
             a.a0 = p.h16; a.c0 = C; a.mask = mask; a.flags = GF_SILU | GF_MASK; a.out16 = p.u16;
@@ -486,7 +492,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
         {   // FFN conv_2, mask, gate, residual (diffusion_transformer.py:29-30,112) [+ FiLM/LN1 of block i+1]
             ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
-            if (fused) { a.a0 = p.h16; a.c0 = C; a.w = e->ffn_stream[i]; a.bias1 = e->ffn1[i].bias; a.cmid = F; a.flags = GF_SILU | GF_MASK; }
+            if (fused) { a.a0 = h2buf; a.c0 = C; a.w = e->ffn_stream[i]; a.bias1 = e->ffn1[i].bias; a.cmid = F; a.flags = GF_SILU | GF_MASK; }
             a.out16 = copy16;
             if (i + 1 == L) a.out16_lo = p.cur16lo;        // operand pair of final_proj
             if (i + 1 < L / 2) fuse_ln1(a, i + 1);         // blocks >= L/2 start with the long-skip conv instead
@@ -1532,6 +1538,35 @@ int st_output_status(st_engine* e, void* stream, int* nonfinite) {
     e->arena_poisoned();      // clears the word; the next call re-zeroes the arena
     return ST_OK;
 }
+
+// ---- compute_loss's own arithmetic: stateless helpers (errors through st_last_error(NULL))
+int st_cfm_loss_prep(const float* x1, const float* z, const float* t_rand, float sigma_min, int B, int M, int T, float* t, float* y,
+                     float* u, void* stream) {
+    if (!x1 || !z || !t_rand || !t || !y || !u) return align_fail(ST_ERR_INVALID, "null tensor pointer");
+    if (B < 1 || M < 1 || T < 1 || B > 65535) return align_fail(ST_ERR_INVALID, "shape out of range");
+    if (launch_cfm_loss_prep(x1, z, t_rand, sigma_min, B, M, T, t, y, u, (hipStream_t)stream) != hipSuccess)
+        return align_fail(ST_ERR_HIP, "cfm_loss_prep kernel launch failed");
+    return ST_OK;
+}
+
+int st_cfm_loss(const float* pred, const float* u, const float* mask, int B, int M, int T, float* scratch, float* loss, void* stream) {
+    if (!pred || !u || !mask || !scratch || !loss) return align_fail(ST_ERR_INVALID, "null tensor pointer");
+    if (B < 1 || M < 1 || T < 1) return align_fail(ST_ERR_INVALID, "shape out of range");
+    if (launch_cfm_loss(pred, u, mask, B, M, T, scratch, loss, (hipStream_t)stream) != hipSuccess)
+        return align_fail(ST_ERR_HIP, "cfm_loss kernel launch failed");
+    return ST_OK;
+}
+
+int st_cfm_loss_backward(const float* pred, const float* u, const float* scratch, const float* grad_loss, int B, int M, int T,
+                         float* grad_pred, void* stream) {
+    if (!pred || !u || !scratch || !grad_loss || !grad_pred) return align_fail(ST_ERR_INVALID, "null tensor pointer");
+    if (B < 1 || M < 1 || T < 1) return align_fail(ST_ERR_INVALID, "shape out of range");
+    if (launch_cfm_loss_bwd(pred, u, scratch, grad_loss, B, M, T, grad_pred, (hipStream_t)stream) != hipSuccess)
+        return align_fail(ST_ERR_HIP, "cfm_loss_bwd kernel launch failed");
+    return ST_OK;
+}
+
+int st_cfm_loss_scratch_floats(void) { return 2 * kCfmLossBlocks + 2; }
 
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects) {
     if (!e) return ST_ERR_INVALID;

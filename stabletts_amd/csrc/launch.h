@@ -175,6 +175,13 @@ hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n
 struct PackJob { const float* src; void* dst; int kind, cout, cin_total, K, ci_off, ci_cnt, row_off, cin_p, col_off, slice_w, lo; unsigned blk0; };
 hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t s);
 
+// ---------------------------------------------------------------- compute_loss's own arithmetic (flow_matching.py:86-100)
+constexpr int kCfmLossBlocks = 1024;       // scratch of launch_cfm_loss: 2 * kCfmLossBlocks + 2 floats
+hipError_t launch_cfm_loss_prep(const float* x1, const float* z, const float* t_rand, float sigma_min, int B, int M, int T,
+                                float* t_out, float* y, float* u, hipStream_t s);
+hipError_t launch_cfm_loss(const float* pred, const float* u, const float* mask, int B, int M, int T, float* scratch, float* loss, hipStream_t s);
+hipError_t launch_cfm_loss_bwd(const float* pred, const float* u, const float* scratch, const float* grad_loss, int B, int M, int T, float* gpred, hipStream_t s);
+
 // ---------------------------------------------------------------- duration -> alignment -> mu_y (align_kernels.hip; models/model.py:17-27,82-96)
 hipError_t launch_durations(const float* logw, const float* x_mask, float length_scale, int B, int Tx, float* w_ceil,
                             float* cum, long long* y_len, hipStream_t s);

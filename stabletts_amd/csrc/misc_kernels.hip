@@ -398,6 +398,90 @@ hipError_t launch_pack_weight(int dtype, const float* src, int cout, int cin_tot
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// CFMDecoder.compute_loss's own arithmetic (models/flow_matching.py:86-100) around the estimator call: the interpolant and the
+// target (prep), the masked-sum MSE (loss) and its gradient (loss_bwd).  Boundary layout (B, M, T) fp32, elementwise.
+__global__ __launch_bounds__(256) void cfm_loss_prep_kernel(const float* x1, const float* z, const float* t_rand, float one_minus_sigma,
+                                                            int B, int64_t per_item, float* t_out, float* y, float* u) {
+    const int b = blockIdx.y;
+    // t = 1 - cos(t_rand * 0.5 * pi) (:88), fp32 like the reference's tensor arithmetic
+    const float t = 1.0f - cosf(t_rand[b] * 0.5f * 3.14159265358979323846f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) t_out[b] = t;
+    const float cz = 1.0f - one_minus_sigma * t;      // y = (1 - (1 - sigma) t) z + t x1 (:93), u = x1 - (1 - sigma) z (:96)
+    const int64_t base = (int64_t)b * per_item;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < per_item; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= per_item && ((base + i) & 3) == 0) {
+            const float4 a = *(const float4*)(x1 + base + i), n = *(const float4*)(z + base + i);
+            *(float4*)(y + base + i) = make_float4(cz * n.x + t * a.x, cz * n.y + t * a.y, cz * n.z + t * a.z, cz * n.w + t * a.w);
+            *(float4*)(u + base + i) = make_float4(a.x - one_minus_sigma * n.x, a.y - one_minus_sigma * n.y, a.z - one_minus_sigma * n.z, a.w - one_minus_sigma * n.w);
+        } else {
+            for (int64_t j = i; j < per_item && j < i + 4; ++j) {
+                y[base + j] = cz * z[base + j] + t * x1[base + j];
+                u[base + j] = x1[base + j] - one_minus_sigma * z[base + j];
+            }
+        }
+    }
+}
+hipError_t launch_cfm_loss_prep(const float* x1, const float* z, const float* t_rand, float sigma_min, int B, int M, int T,
+                                float* t_out, float* y, float* u, hipStream_t s) {
+    const int64_t per_item = (int64_t)M * T;
+    int gx = (int)((per_item / 4 + 255) / 256); if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(cfm_loss_prep_kernel, dim3(gx, B), dim3(256), 0, s, x1, z, t_rand, 1.0f - sigma_min, B, per_item, t_out, y, u);
+    return hipGetLastError();
+}
+
+// sum (pred - u)^2 over every element and sum(mask): fixed partition, fixed combination order (deterministic).
+// scratch: [0, kCfmLossBlocks) partial sums, [kCfmLossBlocks, 2 kCfmLossBlocks) partial mask sums, [2 k] = the squared sum,
+// [2 k + 1] = the denominator sum(mask) * M (kept for the backward)
+__global__ __launch_bounds__(256) void cfm_loss_partial_kernel(const float* pred, const float* u, const float* mask, int64_t n, int64_t nm, float* scratch) {
+    __shared__ float red[2][4];
+    float acc = 0.f, am = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = pred[i] - u[i];
+        acc += d * d;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += (int64_t)gridDim.x * blockDim.x) am += mask[i];
+    acc = wave_sum(acc); am = wave_sum(am);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc; red[1][threadIdx.x >> 6] = am; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        scratch[kCfmLossBlocks + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+__global__ __launch_bounds__(256) void cfm_loss_final_kernel(float* scratch, int nblocks, int M, float* loss) {
+    __shared__ float red[2][4];
+    float a = 0.f, m = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += scratch[i]; m += scratch[kCfmLossBlocks + i]; }
+    a = wave_sum(a); m = wave_sum(m);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ss = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float den = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (float)M;
+        scratch[2 * kCfmLossBlocks] = ss; scratch[2 * kCfmLossBlocks + 1] = den;
+        *loss = ss / den;          // mse_loss(pred, u, "sum") / (sum(mask) * n_feats) (:100); u is NOT masked (reference quirk)
+    }
+}
+hipError_t launch_cfm_loss(const float* pred, const float* u, const float* mask, int B, int M, int T, float* scratch, float* loss, hipStream_t s) {
+    const int64_t n = (int64_t)B * M * T, nm = (int64_t)B * T;
+    int grid = (int)((n / 8 + 255) / 256); if (grid > kCfmLossBlocks) grid = kCfmLossBlocks; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cfm_loss_partial_kernel, dim3(grid), dim3(256), 0, s, pred, u, mask, n, nm, scratch);
+    hipLaunchKernelGGL(cfm_loss_final_kernel, dim3(1), dim3(256), 0, s, scratch, grid, M, loss);
+    return hipGetLastError();
+}
+// d loss / d pred = grad_loss * 2 (pred - u) / den
+__global__ __launch_bounds__(256) void cfm_loss_bwd_kernel(const float* pred, const float* u, const float* scratch, const float* grad_loss, int64_t n, float* gpred) {
+    const float f = 2.0f * grad_loss[0] / scratch[2 * kCfmLossBlocks + 1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) gpred[i] = f * (pred[i] - u[i]);
+}
+hipError_t launch_cfm_loss_bwd(const float* pred, const float* u, const float* scratch, const float* grad_loss, int B, int M, int T, float* gpred, hipStream_t s) {
+    const int64_t n = (int64_t)B * M * T;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cfm_loss_bwd_kernel, dim3(grid), dim3(256), 0, s, pred, u, scratch, grad_loss, n, gpred);
+    return hipGetLastError();
+}
+
 // fused-FFN weight stream (common.h: ffn_stream_index)
 template <class P>
 __global__ void pack_ffn_stream_kernel(const float* src, int stage, int F, typename P::elem* dst) {

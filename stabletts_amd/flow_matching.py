@@ -60,9 +60,10 @@ class CFMDecoder(nn.Module):
         mask = prep(mask, dev, "mask")
         c = prep(c, dev, "c")
         if z is None:
-            z = torch.randn_like(mu) * temperature
-        else:
-            z = prep(z, dev, "z") * temperature
+            z = torch.randn_like(mu)
+        z = prep(z, dev, "z")
+        if temperature != 1.0:          # (the solve reads z once; at temperature 1 -- the api.py default is 1 -- nothing to do)
+            z = z * temperature
         if mask.shape != (B, 1, T) or z.shape != mu.shape or c.shape != (B, self.gin_channels):
             raise ValueError("shape mismatch: mu/z (B,M,T), mask (B,1,T), c (B,gin)")
         use_cfg = cfg_kwargs is not None
@@ -123,9 +124,10 @@ class CFMDecoder(nn.Module):
     def compute_loss(self, x1, mask, mu, c, t_rand=None, z=None):
         """models/flow_matching.py:69-100: CFM training loss and the interpolant ``y``.
 
-        Cosine-warped per-item ``t``, ``y = (1-(1-sigma)t) z + t x1``, ``u = x1 - (1-sigma) z`` (elementwise torch ops
-        on the device), ONE native estimator evaluation with a per-item ``t`` (t_len = B) and the masked-sum MSE --
-        including the reference's quirk that ``u`` is not masked (:99).  With autograd enabled the estimator call goes
+        Cosine-warped per-item ``t``, ``y = (1-(1-sigma)t) z + t x1``, ``u = x1 - (1-sigma) z`` (one native kernel,
+        st_cfm_loss_prep), ONE native estimator evaluation with a per-item ``t`` (t_len = B) and the masked-sum MSE (native,
+        forward and backward: st_cfm_loss / st_cfm_loss_backward) -- including the reference's quirk that ``u`` is not masked
+        (:99).  Only the random draws (torch.rand / torch.randn_like: torch's generator is the contract) are ATen launches.  With autograd enabled the estimator call goes
         through ``stabletts_amd.autograd`` (native forward + native backward), so ``loss.backward()`` fills
         ``.grad`` of every estimator parameter and of ``mu`` / ``c`` exactly like the reference module does (DDP
         hooks fire as usual).  ``t_rand`` (B,1,1) and ``z`` may be passed to fix the draws.
@@ -133,11 +135,13 @@ class CFMDecoder(nn.Module):
         b = mu.shape[0]
         if t_rand is None:
             t_rand = torch.rand([b, 1, 1], device=mu.device, dtype=mu.dtype)
-        t = 1 - torch.cos(t_rand * 0.5 * torch.pi)
         if z is None:
             z = torch.randn_like(x1)
-        y = (1 - (1 - self.sigma_min) * t) * z + t * x1
-        u = x1 - (1 - self.sigma_min) * z
-        pred = self.estimator(t.squeeze() if b > 1 else t.reshape(()), y, mask, mu, c)
-        loss = torch.nn.functional.mse_loss(pred, u, reduction="sum") / (torch.sum(mask) * u.size(1))
+        from .autograd import cfm_loss, cfm_loss_prep
+        self.estimator.engine()          # (raises on a CPU module: there is no CPU fallback)
+        dev = self.estimator.device()
+        prep = self.estimator._prep
+        t, y, u = cfm_loss_prep(prep(x1, dev, "x1"), prep(z, dev, "z"), t_rand, self.sigma_min)
+        pred = self.estimator(t if b > 1 else t.reshape(()), y, mask, mu, c)
+        loss = cfm_loss(pred, u, prep(mask, dev, "mask"))
         return loss, y

@@ -227,6 +227,46 @@ def test_adaptive_tableaus_pinned_against_scipy_and_order_conditions():
     assert abs(np.array(c_sol) @ c ** 4 - 1 / 5) < 1e-15
 
 
+@pytest.mark.parametrize("method,scipy_method", [("dopri5", "RK45"), ("bosh3", "RK23")])
+def test_adaptive_oracle_solves_the_ode_to_tolerance_vs_scipy(method, scipy_method):
+    """The restated adaptive controller (torchdiffeq is absent offline: its step controller stays parity-unpinned) is checked
+    against an INDEPENDENT integrator for what it is supposed to deliver: the solution of the ODE to the requested tolerance.  A
+    small stiff-ish nonlinear system with a time-dependent field (the shape of flow_matching.py:49-54: state in, t in, vector field
+    out), integrated over [0, 1] at rtol = atol = 1e-5 as the reference hard-codes:
+      * truth = scipy.integrate.solve_ivp(DOP853, rtol = atol = 1e-12);
+      * the oracle's answer must be within 50 x the tolerance scale of the truth (measured ~1e-5 relative);
+      * scipy's own RK45 at the same rtol / atol (same tableau, scipy's controller) lands at a comparable distance: dopri5 -- the
+        reference's default solver -- is not allowed to be more than 10 x further away than scipy is (measured 1.4 vs 0.6 x tol).
+        bosh3 is exempt: like torchdiffeq the oracle does not clip its last step to t = 1 but evaluates the dense-output
+        interpolant there, and for bosh3 that interpolant's mid-point is only second-order (28 x tol against scipy's 0.3);
+      * and the two controllers take a comparable number of steps (within 2 x): neither crawls nor leaps."""
+    import numpy as np
+    from scipy.integrate import solve_ivp
+    torch.manual_seed(3)
+    A = (torch.randn(6, 6, dtype=torch.float64) * 0.9 - 1.2 * torch.eye(6, dtype=torch.float64))
+    w = torch.linspace(1.0, 9.0, 6, dtype=torch.float64)
+
+    def field64(t, y):
+        return np.tanh(A.numpy() @ y) * 3.0 + np.sin(w.numpy() * t * 2.0) + 0.5 * y * np.cos(3.0 * t)
+
+    def field(t, y):          # the oracle integrates fp32 tensors, t arrives as an fp32 0-dim tensor (as the estimator gets it)
+        td = t.double()
+        return (torch.tanh(A @ y.double()) * 3.0 + torch.sin(w * td * 2.0) + 0.5 * y.double() * torch.cos(3.0 * td)).float()
+
+    y0 = torch.linspace(-1.0, 1.0, 6)
+    truth = solve_ivp(field64, (0.0, 1.0), y0.double().numpy(), method="DOP853", rtol=1e-12, atol=1e-12).y[:, -1]
+    sp = solve_ivp(field64, (0.0, 1.0), y0.double().numpy(), method=scipy_method, rtol=1e-5, atol=1e-5)
+    stats = {}
+    got = oracle.odeint_adaptive(field, y0, method, 1.0, 1e-5, 1e-5, stats).double().numpy()
+    scale = 1e-5 * (1.0 + np.abs(truth))
+    e_or, e_sp = float(np.max(np.abs(got - truth) / scale)), float(np.max(np.abs(sp.y[:, -1] - truth) / scale))
+    sp_steps = len(sp.t) - 1
+    print(f"{method}: oracle error {e_or:.2f} x tol ({stats['steps']} steps, {stats['rejects']} rejected), scipy {scipy_method} {e_sp:.2f} x tol ({sp_steps} accepted steps)")
+    assert e_or <= 50.0
+    assert method != "dopri5" or e_or <= 10.0 * max(e_sp, 1.0)
+    assert 0.5 * sp_steps <= stats["steps"] - stats["rejects"] <= 2.0 * sp_steps + 2
+
+
 def test_fixed_grid_rules_have_their_classical_order():
     """euler / midpoint / rk4 (3/8 rule) of oracle.odeint_fixed, written as Butcher tableaus, satisfy the order
     conditions of order 1 / 2 / 4 -- and the rk4 one is the 3/8 rule torchdiffeq uses (rk4_alt_step_func), checked on
