@@ -35,11 +35,15 @@ static float run(const ConvGemmArgs& a0, int reps, hipStream_t s) {
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 1000, F = 1024, C = 256, reps = 20, rounds = 3;
+    // data fill (argv[3]): 0 = uniform random (default), 1 = zeros (lowest switching power: how far is the kernel from its
+    // schedule-bound time?), 2 = normal-like activations / small weights (closer to the model's statistics)
+    const int fill = argc > 3 ? atoi(argv[3]) : 0;
     hipStream_t s; CK(hipStreamCreate(&s));
     const size_t rows = (size_t)N * T;
     std::vector<_Float16> h(rows * C), w((size_t)2 * F * C * 3);
-    for (auto& v : h) v = (_Float16)(frand() * 2.0f);
-    for (auto& v : w) v = (_Float16)(frand() * 0.08f);
+    for (auto& v : h) v = (_Float16)(fill == 1 ? 0.0f : fill == 2 ? (frand() + frand() + frand() + frand()) * 1.7f : frand() * 2.0f);
+    for (auto& v : w) v = (_Float16)(fill == 1 ? 0.0f : fill == 2 ? (frand() + frand() + frand()) * 0.04f : frand() * 0.08f);
+    printf("fill mode %d\n", fill);
     std::vector<float> b1(F), b2(C), gate((size_t)N * C), mask((size_t)(N / 2) * T, 1.0f), x(rows * C), film(2 * C), ada((size_t)N * 2 * C);
     for (auto& v : b1) v = frand() * 0.1f;
     for (auto& v : b2) v = frand() * 0.1f;
