@@ -124,6 +124,31 @@ def test_fused_ffn_is_bit_identical_to_the_two_kernel_path(sd, cfg_params, monke
         assert torch.equal(new.estimator(*args), old.estimator(*args))
 
 
+@pytest.mark.parametrize("F", [512, 768, 2048])
+def test_fused_ffn_other_filter_widths(cfg_params, monkeypatch, F):
+    """The fused kernel walks the intermediate in 256-channel chunks (2, 3, 8 of them here instead of the 31M model's 4); its
+    weight stream, bias area and wait counts depend on the chunk count only through `last chunk`.  Bit-identical to the
+    two-kernel path, ragged, repeated."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    cfg = oracle.DecoderConfig(filter_channels=F)
+    sdf = oracle.make_state_dict(777, cfg)
+    kw = _kw(cfg_params, 2.0)
+    decs = []
+    for fused in ("0", "1"):
+        for k, v in dict(ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN=fused, ST_SMALL_GRID="0").items():
+            monkeypatch.setenv(k, v)
+        d = CFMDecoder(128, 128, 256, 128, F, 4, 6, 3, 0.1, 256)
+        d.estimator.load_state_dict(sdf)
+        d = d.to("cuda:0"); d.estimator.engine()
+        decs.append(d)
+    for k in ("ST_BIG_MIN_BLOCKS", "ST_FUSED_FFN", "ST_SMALL_GRID"):
+        monkeypatch.delenv(k)
+    inp = make_inputs(3, 380, seed=33, lengths=[380, 251, 127])
+    ref = _solve(decs[0], inp, 2, "euler", kw)
+    for _ in range(2):
+        assert torch.equal(_solve(decs[1], inp, 2, "euler", kw), ref)
+
+
 def test_small_grid_variants_match_the_plain_kernels(sd, cfg_params, monkeypatch):
     """Split-K convolutions (+ row-wise finish kernel), 64-frame tiles and the key-split attention kernel change only
     the fp32 summation order: a small solve with them (default) and without (ST_SMALL_GRID=0) must agree to fp32
