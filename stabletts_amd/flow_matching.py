@@ -79,6 +79,12 @@ class CFMDecoder(nn.Module):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             eng.cfm_solve(mu, mask, z, c, int(n_timesteps), _lib.SOLVERS[solver], use_cfg, strength, fs, fc, out, stream)
+            if solver == "implicit_adams":      # (host-controlled solver: its statistics are final when the call returns)
+                rej = eng.last_solve_stats()["rejects"]
+                if rej:
+                    import warnings
+                    warnings.warn(f"implicit_adams: the Adams-Moulton corrector did not converge in {rej} step(s) "
+                                  "(torchdiffeq warns 'Functional iteration did not converge. Solution may be incorrect.' here)")
             if self.check_finite and eng.output_nonfinite(stream):
                 raise FloatingPointError(
                     "stabletts_amd: the solve produced NaN / Inf.  With operand_dtype='f16' an activation beyond 65504 "

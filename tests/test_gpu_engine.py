@@ -1,6 +1,7 @@
 """Engine behaviour on a real MI355X that is not numerics-vs-oracle: solve-part splitting, HIP-graph replay across
 table reallocations, weight synchronisation, device checks, and the multi-process utterance-sharded path
 (2 ranks sharing the one visible GPU).  Run with ``-m gpu``."""
+import ctypes
 import os
 import subprocess
 import sys
@@ -278,3 +279,55 @@ def test_ragged_tile_skipping_and_qkv_two_block_tiles_are_bitwise_neutral(sd, cf
     inp2 = make_inputs(3, 700, seed=96, lengths=[700, 333, 90])
     _solve(base, inp2, 2, "euler", kw)
     assert torch.equal(_solve(base, inp, 3, "euler", kw), ref)
+
+
+def test_nonfinite_guard_and_recovery(sd, cfg_params):
+    """(a) f16 operands overflow at 65504 where the fp32 reference does not -- the engine must SAY so: the boundary
+    kernel raises a host-visible flag on NaN / Inf outputs (st_output_status; CFMDecoder(check_finite=True) raises with the remedy);
+    (b) a call that produced NaN must not poison later calls of the same layout: ragged tile skipping leaves stale frames that only
+    don't-care positions read, but 0 x NaN = NaN -- after a flagged call the engine re-zeroes its workspace by itself."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, check_finite=True)
+    d.estimator.load_state_dict(sd)
+    d = d.to("cuda:0")
+    kw = _kw(cfg_params, 3.0)
+    inp = make_inputs(4, 300, seed=12, lengths=[300, 180, 120, 40])          # ragged: tiles past 180 / 120 / 40 (+4) are skipped
+    good = _solve(d, inp, 2, "euler", kw)
+    eng = d.estimator.engine()
+    assert not eng.output_nonfinite(torch.cuda.current_stream().cuda_stream)
+    bad = dict(inp)
+    bad["mu"] = inp["mu"].clone(); bad["mu"][:, :, :] = float("nan")          # every frame, padded ones included
+    with pytest.raises(FloatingPointError, match="bf16"):
+        _solve(d, bad, 2, "euler", kw)
+    again = _solve(d, inp, 2, "euler", kw)                                    # same layout, clean inputs
+    assert torch.isfinite(again).all() and torch.equal(again, good)
+    # an activation beyond f16's range: finite in the fp32 reference, Inf / NaN with f16 operands -> flagged; bf16 carries it
+    big = dict(inp); big["mu"] = inp["mu"] * 3e4
+    with pytest.raises(FloatingPointError):
+        _solve(d, big, 2, "euler", kw)
+    d16 = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="bf16", check_finite=True)
+    d16.estimator.load_state_dict(sd)
+    d16 = d16.to("cuda:0")
+    assert torch.isfinite(_solve(d16, big, 2, "euler", kw)).all()
+
+
+def test_repack_after_rebind_needs_finalize(sd):
+    """st_bind_param moves the engine to other fp32 tensors; a st_repack without st_finalize would leave
+    instantiated graphs and the recorded re-pack jobs pointing at the old ones.  It now fails with ST_ERR_STATE, and binding drops
+    the graphs."""
+    from stabletts_amd import _lib
+    from stabletts_amd.flow_matching import CFMDecoder
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256)
+    d.estimator.load_state_dict(sd)
+    d = d.to("cuda:0")
+    eng = d.estimator.engine()
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.repack(stream)                                              # in-place update path: fine
+    name, p = next(iter(d.estimator.named_parameters()))
+    other = p.detach().clone()
+    shape = (ctypes.c_int64 * other.dim())(*other.shape)
+    assert eng.lib.st_bind_param(eng.handle, name.encode(), ctypes.c_void_p(other.data_ptr()), shape, other.dim()) == 0
+    with pytest.raises(_lib.NativeError, match="st_finalize"):
+        eng.repack(stream)
+    assert eng.lib.st_finalize(eng.handle) == 0
+    eng.repack(stream)
