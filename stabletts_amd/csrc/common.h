@@ -9,17 +9,25 @@ namespace st {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // 32x32x16 MFMA (gfx950): D[i][j] += sum_k A[i][k] B[k][j]
 //   A operand: lane l holds A[i = l&31][k-slots (l>>5)*8 .. +8]
 //   B operand: lane l holds B[k-slots (l>>5)*8 .. +8][j = l&31]
 //   C/D      : lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+// 16x16x32 MFMA (mfma16; the same FLOPs per cycle as 32x32x16 on zeros, ~17 % more sustained throughput on real data: the chip is
+// power-limited in the MFMA loops and this shape moves 20 % fewer register-file bytes per FLOP, profiles/r04_mfma_power_shapes.txt):
+//   A operand: lane l holds A[i = l&15][k-slots (l>>4)*8 .. +8]      B operand: lane l holds B[k-slots (l>>4)*8 .. +8][j = l&15]
+//   C/D      : lane l, reg r holds D[i = 4*(l>>4) + r][j = l&15]
 struct OpBF16 {
     using elem = __bf16;
     using vec8 = bf16x8_t;
     static constexpr float kMaskedScore = -1e30f;     // 16-bit representable "minus infinity" of a masked attention score
     static __device__ __forceinline__ f32x16_t mfma(vec8 a, vec8 b, f32x16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 };
 struct OpF16 {
@@ -28,6 +36,9 @@ struct OpF16 {
     static constexpr float kMaskedScore = -60000.0f;  // f16 saturates at 65504; exp2(-60000 + anything sane) == 0
     static __device__ __forceinline__ f32x16_t mfma(vec8 a, vec8 b, f32x16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
 
@@ -210,19 +221,23 @@ __device__ __forceinline__ unsigned drop_ffn_hash(const D& d, unsigned long long
     return drop_mix32(((unsigned)d.seed ^ ((unsigned)(i >> 1) * 0x9E3779B1u)) + (unsigned)(d.seed >> 32));
 }
 
-// Fused-FFN weight stream (launch.h: launch_pack_ffn_stream; ffn_fused.h consumes it): element idx of one stage's F*256*3 values ->
-// source offset in the fp32 conv weight and destination offset in the stream (16-bit elements).  hidden = 256 hard-wired.
-//   idx = ((c*24 + sl)*16 + f)*512 + lane*8 + e;  sl = (ci, tap, kp) = ci*6 + tap*2 + kp;  f = ksl*8 + a8
-//   stage 0, conv_1 (F, 256, 3): row = c*256 + a8*32 + (lane&31), cin = ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e
-//   stage 1, conv_2 (256, F, 3): row = a8*32 + (lane&31),         cin = c*256 + ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e
+// Fused-FFN weight stream (launch.h: launch_pack_ffn_stream; ffn_fused.h / ffn_fused16.h consume it): element idx of one stage's
+// F*256*3 values -> source offset in the fp32 conv weight and destination offset in the stream (16-bit elements).  hidden = 256
+// hard-wired.  stage bit 0 = conv_1 / conv_2, bit 1 = fragments of the 16x16x32 MFMA (ffn_fused16.h) instead of 32x32x16.
+//   idx = ((c*24 + sl)*16 + f)*512 + lane*8 + e;  sl = (ci, tap, kp) = ci*6 + tap*2 + kp
+//   32x32x16: f = ksl*8 + a8, row r = a8*32 + (lane&31), cin kk = ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e
+//   16x16x32: f = wq*4 + a,   row r = f*16 + (lane&15),  cin kk = ci*64 + kp*32 + (lane>>4)*8 + e
+//   conv_1 (F, 256, 3): source (c*256 + r, kk, tap);  conv_2 (256, F, 3): source (r, c*256 + kk, tap)
 __host__ __device__ __forceinline__ void ffn_stream_index(size_t idx, int stage, int F, size_t* src_off, size_t* dst_off) {
     const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), f = (int)((idx >> 9) & 15);
     const int sl = (int)((idx >> 13) % 24), c = (int)(idx / (24u * 8192u));
-    const int ksl = f >> 3, a8 = f & 7, ci = sl / 6, tap = (sl % 6) >> 1, kp = sl & 1;
-    const int kk = ci * 64 + (2 * kp + ksl) * 16 + (lane >> 5) * 8 + e;
-    if (stage == 0) *src_off = ((size_t)(c * 256 + a8 * 32 + (lane & 31)) * 256 + kk) * 3 + tap;
-    else            *src_off = ((size_t)(a8 * 32 + (lane & 31)) * F + c * 256 + kk) * 3 + tap;
-    *dst_off = (size_t)c * (48u * 8192u) + (size_t)(stage * 24 + sl) * 8192u + (idx & 8191);
+    const int ci = sl / 6, tap = (sl % 6) >> 1, kp = sl & 1;
+    int r, kk;
+    if (stage & 2) { r = f * 16 + (lane & 15); kk = ci * 64 + kp * 32 + (lane >> 4) * 8 + e; }
+    else           { r = (f & 7) * 32 + (lane & 31); kk = ci * 64 + (2 * kp + (f >> 3)) * 16 + (lane >> 5) * 8 + e; }
+    if ((stage & 1) == 0) *src_off = ((size_t)(c * 256 + r) * 256 + kk) * 3 + tap;
+    else                  *src_off = ((size_t)r * F + c * 256 + kk) * 3 + tap;
+    *dst_off = (size_t)c * (48u * 8192u) + (size_t)((stage & 1) * 24 + sl) * 8192u + (idx & 8191);
 }
 
 }  // namespace st

@@ -169,12 +169,15 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
 
 // LDS-staged epilogue shared by the gen-2 kernels.  fvalid = number of valid frame columns of the tile
 // (BF, or BF-2 for the 3-buffer k=3 kernel whose activation tile includes its own halo).
-template <class P, int EPI, int BC, int BF, int WC, int WF>
-__device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], float* stage, const ConvGemmArgs& g,
-                                            int n, int t0, int fvalid, int cbase, int wave, int lane) {
-    constexpr int NW = WC * WF, TC = BC / WC, TF = BF / WF, FC = TC / 32, FF = TF / 32, PITCH = BC + 4;
+// `park(fbase)` stores the calling wave's accumulator tile into `stage` as [frame][channel] fp32, frame rows from fbase on (row
+// pitch BC + 4 words): the only part that depends on the MFMA shape the K loop used (g2_epilogue: 32x32x16 fragments; the
+// fused FFN's 16x16x32 variant brings its own, ffn_fused16.h).
+template <class P, int EPI, int BC, int BF, int WC, int WF, class Park>
+__device__ __forceinline__ void g2_epilogue_core(Park park, float* stage, const ConvGemmArgs& g,
+                                                 int n, int t0, int fvalid, int cbase, int wave, int lane) {
+    constexpr int NW = WC * WF, TF = BF / WF, PITCH = BC + 4;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wc = wave % WC, wf = wave / WC;
+    const int wf = wave / WC;
     const int T = g.T;
     static_assert(EPI != EPI_QKV && EPI != EPI_ACT16 && EPI != EPI_SILU, "QKV: g2_epilogue_qkv; ACT16: g2_epilogue_act16; SILU: g2_epilogue_silu");
     static_assert(BC == 128 || BC == 256, "row walker handles 128 or 256 channels");
@@ -191,20 +194,7 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
     const int an = n < g.add_clamp ? n : g.add_clamp;
 #pragma unroll 1
     for (int p = 0; p < NPASS; ++p) {
-        if (wf / WFP == p) {
-            const int fbase = (wf % WFP) * TF;
-#pragma unroll
-            for (int a = 0; a < FC; ++a)
-#pragma unroll
-                for (int b = 0; b < FF; ++b)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int fl = fbase + b * 32 + l31;
-                        const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
-                        *(float4*)(stage + fl * PITCH + ch) = make_float4(acc[a][b][4 * q4 + 0], acc[a][b][4 * q4 + 1],
-                                                                          acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]);
-                    }
-        }
+        if (wf / WFP == p) park((wf % WFP) * TF);
         const int tbase = t0 + p * PASSF;
         // every global input of this wave's rows is requested before the barrier: the latency overlaps the other
         // waves' staging stores and the barrier wait
@@ -237,6 +227,26 @@ __device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / W
         }
         if (p + 1 < NPASS) __syncthreads();
     }
+}
+
+template <class P, int EPI, int BC, int BF, int WC, int WF>
+__device__ __forceinline__ void g2_epilogue(f32x16_t (&acc)[BC / WC / 32][BF / WF / 32], float* stage, const ConvGemmArgs& g,
+                                            int n, int t0, int fvalid, int cbase, int wave, int lane) {
+    constexpr int TC = BC / WC, FC = TC / 32, FF = BF / WF / 32, PITCH = BC + 4;
+    const int l31 = lane & 31, hi = lane >> 5, wc = wave % WC;
+    g2_epilogue_core<P, EPI, BC, BF, WC, WF>([&](int fbase) {
+#pragma unroll
+        for (int a = 0; a < FC; ++a)
+#pragma unroll
+            for (int b = 0; b < FF; ++b)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int fl = fbase + b * 32 + l31;
+                    const int ch = wc * TC + a * 32 + 8 * q4 + 4 * hi;
+                    *(float4*)(stage + fl * PITCH + ch) = make_float4(acc[a][b][4 * q4 + 0], acc[a][b][4 * q4 + 1],
+                                                                      acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]);
+                }
+    }, stage, g, n, t0, fvalid, cbase, wave, lane);
 }
 
 // Accumulator start value: EPI_ACT16 / EPI_QKV kernels start from the bias (one add per output saved in the epilogue).

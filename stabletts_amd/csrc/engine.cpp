@@ -500,7 +500,8 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             // block L/2 - 1 on the fp32 copy of x3 is dead, so it is not written (40 % of this epilogue's HBM bytes)
             else if (!cap) a.out32_readonly = 1;
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N) + (fused ? conv_flops(p, e->ffn1[i], N) : 0.0));
-            if (fused) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused_bf16(a, s) : launch_ffn_fused_f16(a, s));
+            if (fused && e->fused_ffn == 2) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused16_bf16(a, s) : launch_ffn_fused16_f16(a, s));
+            else if (fused) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused_bf16(a, s) : launch_ffn_fused_f16(a, s));
             else HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }
         if (cap) {
@@ -1207,8 +1208,9 @@ int pack_all(st_engine* e, hipStream_t s) {
             if (!e->ffn_stream[i] && (rc = dev_alloc(e, &e->ffn_stream[i], (size_t)2 * F * C * K * 2))) return rc;
             for (int st = 0; st < 2; ++st) {
                 const float* src = P(e, b + (st ? "mlp.conv_2.weight" : "mlp.conv_1.weight"));
-                HIPCHK(e, launch_pack_ffn_stream(e->dt, src, st, F, e->ffn_stream[i], s));
-                pk_push(PL, PackJob{src, e->ffn_stream[i], 3, F, 0, 0, 0, 0, 0, 0, 0, 0, st, 0u}, (size_t)F * C * K);
+                const int stg = st | (e->fused_ffn == 2 ? 2 : 0);      // bit 1: fragments of the 16x16x32 kernel
+                HIPCHK(e, launch_pack_ffn_stream(e->dt, src, stg, F, e->ffn_stream[i], s));
+                pk_push(PL, PackJob{src, e->ffn_stream[i], 3, F, 0, 0, 0, 0, 0, 0, 0, 0, stg, 0u}, (size_t)F * C * K);
             }
         }
     }

@@ -1,4 +1,5 @@
-#include "ffn_fused.h"
+#include "ffn_fused16.h"
 namespace st {
 hipError_t launch_ffn_fused_bf16(const ConvGemmArgs& a, hipStream_t s) { return launch_ffn_fused_t<OpBF16>(a, s); }
-}  // namespace st
+hipError_t launch_ffn_fused16_bf16(const ConvGemmArgs& a, hipStream_t s) { return launch_ffn_fused16_t<OpBF16>(a, s); }
+}

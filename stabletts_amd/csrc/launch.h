@@ -82,10 +82,13 @@ hipError_t launch_splitk_finish_f16(int epi, const ConvGemmArgs& a, const float*
 constexpr int kFfnFusedFrames = 126;      // output frames per block (128 u rows = the tile + conv_2's halo)
 hipError_t launch_ffn_fused_bf16(const ConvGemmArgs& a, hipStream_t s);
 hipError_t launch_ffn_fused_f16(const ConvGemmArgs& a, hipStream_t s);
+// the same kernel on 16x16x32 MFMA fragments (ffn_fused16.h; weight stream packed with stage bit 1 set)
+hipError_t launch_ffn_fused16_bf16(const ConvGemmArgs& a, hipStream_t s);
+hipError_t launch_ffn_fused16_f16(const ConvGemmArgs& a, hipStream_t s);
 // Weight stream of the fused FFN kernel, in the order the kernel consumes it: for each 256-channel chunk c of the intermediate
 // width, 24 conv_1 slabs (cin chunk, tap, k-step pair) then 24 conv_2 slabs (u sub-chunk, tap, k-step pair); a slab = 16 MFMA
 // A-fragments of 1 KiB stored lane-linear (fragment (ksl, a8): rows a8*32.., k-step 2*kp+ksl).  stage 0: src = conv_1 weight
-// (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).
+// (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).  stage | 2: the 16x16x32 kernel's fragments (common.h: ffn_stream_index).
 hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F, void* dst, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
