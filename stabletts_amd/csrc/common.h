@@ -55,6 +55,15 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     return __builtin_bit_cast(uint2, v);
 }
 
+// pack4 of four values times a common scale, every product rounded to fp32 FIRST: with -ffp-contract=fast hipcc fuses
+// (f16)(x * s) into v_fma_mixlo_f16 (one rounding) at some call sites and not at others -- the q/k/v kernels must agree bit for bit
+template <class P>
+__device__ __forceinline__ uint2 scale_pack4(float a, float b, float c, float d, float s) {
+    float pa = a * s, pb = b * s, pc = c * s, pd = d * s;
+    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));      // (the fold is an instruction-selection pattern: pragmas do not stop it)
+    return pack4<P>(pa, pb, pc, pd);
+}
+
 template <class P>
 __device__ __forceinline__ typename P::vec8 as_vec8(uint4 v) {
     return __builtin_bit_cast(typename P::vec8, v);
@@ -104,6 +113,16 @@ __device__ __forceinline__ float add_f32_asm_safe(float a, float b) {
     float r;
     asm("s_nop 0\n\tv_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+}
+
+// Partial-RoPE rotation of one pair (x1, x2) by (c, s) with a FIXED contraction (one fma per output: x1 c - x2 s = fma(x1, c, -(x2 s)),
+// x2 c + x1 s = fma(x2, c, x1 s)): the two q/k/v kernels (conv_gemm2_impl.h g2_epilogue_qkv, qkv_ws.hip) must round identically,
+// and left to -ffp-contract=fast hipcc picks the fused product per call site.
+__device__ __forceinline__ void rope_rot(float& x1, float& x2, float c, float s) {
+#pragma clang fp contract(off)
+    const float p = x2 * s, q = x1 * s;
+    const float a = __builtin_fmaf(x1, c, -p), b = __builtin_fmaf(x2, c, q);
+    x1 = a; x2 = b;
 }
 
 template <int CTRL>

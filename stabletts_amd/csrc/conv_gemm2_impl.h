@@ -455,16 +455,16 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
                 for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x1 = r[4 * q4 + e], x2 = r[4 * (q4 + 2) + e];
-                        r[4 * q4 + e] = x1 * cc[q4][e] - x2 * ss[q4][e];
-                        r[4 * (q4 + 2) + e] = x2 * cc[q4][e] + x1 * ss[q4][e];
+                        float x1 = r[4 * q4 + e], x2 = r[4 * (q4 + 2) + e];
+                        rope_rot(x1, x2, cc[q4][e], ss[q4][e]);
+                        r[4 * q4 + e] = x1; r[4 * (q4 + 2) + e] = x2;
                     }
                 unsigned char* row = stage + ((wc * HPW + hh) * BF + fl) * PQ + 4 * hi * 2;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    *(uint2*)(row + 16 * q4) = pack4<P>(r[4 * q4 + 0] * sc, r[4 * q4 + 1] * sc, r[4 * q4 + 2] * sc, r[4 * q4 + 3] * sc);
-                    *(uint2*)(row + 64 + 16 * q4) = pack4<P>(acc[2 * hh + 1][b][4 * q4 + 0] * sc, acc[2 * hh + 1][b][4 * q4 + 1] * sc,
-                                                             acc[2 * hh + 1][b][4 * q4 + 2] * sc, acc[2 * hh + 1][b][4 * q4 + 3] * sc);
+                    *(uint2*)(row + 16 * q4) = scale_pack4<P>(r[4 * q4 + 0], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3], sc);
+                    *(uint2*)(row + 64 + 16 * q4) = scale_pack4<P>(acc[2 * hh + 1][b][4 * q4 + 0], acc[2 * hh + 1][b][4 * q4 + 1],
+                                                                   acc[2 * hh + 1][b][4 * q4 + 2], acc[2 * hh + 1][b][4 * q4 + 3], sc);
                 }
             }
         }

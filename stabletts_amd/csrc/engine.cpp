@@ -130,6 +130,12 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
             return bf ? launch_splitk_finish_bf16(epi, a, e->kpart, ks, s) : launch_splitk_finish_f16(epi, a, e->kpart, ks, s);
         }
     }
+    // the fused q/k/v projection of big grids: weights in registers, activations streamed (qkv_ws.hip; bit-identical)
+    if (epi == EPI_QKV && e->qkv_ws && e->sink && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
+        (int64_t)e->conc * a.n_items * ((T + 63) / 64) >= e->qkv_ws_min_tiles) {
+        ConvGemmArgs b = a; b.sink = e->sink;
+        return launch_qkv_ws(e->dt, b, s);
+    }
     int cfg;
     if (big_tiles(e, a)) cfg = (e->phased && taps == 3) ? G2_PHASED : (epi == EPI_QKV && e->qkv_rc1) ? G2_RC1 : G2_BIG;
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
@@ -944,6 +950,8 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
     if (const char* v = getenv("ST_FUSED_FFN")) e->fused_ffn = atoi(v);
     if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);
+    if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
+    if (const char* v = getenv("ST_QKV_WS_MIN_TILES")) e->qkv_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)
     if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
         if (atoi(v) == 0) {                               // key-split attention): results independent of the batch composition
@@ -952,6 +960,7 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     }
     build_param_table(e);
     if (hipMalloc((void**)&e->kpart, kSplitKBytes) == hipSuccess) e->kpart_bytes = kSplitKBytes; else e->kpart = nullptr;
+    if (hipMalloc(&e->sink, 65536) != hipSuccess) e->sink = nullptr;      // (without it the q/k/v projection stays on the generic tile)
     if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         if (e->kpart) hipFree(e->kpart);
@@ -996,6 +1005,7 @@ void st_destroy(st_engine* e) {
     if (e->rope_cos) hipFree(e->rope_cos);
     if (e->rope_sin) hipFree(e->rope_sin);
     if (e->zeros) hipFree(e->zeros);
+    if (e->sink) hipFree(e->sink);
     if (e->kpart) hipFree(e->kpart);
     if (e->status_host) hipHostFree(e->status_host);
     delete e;

@@ -74,6 +74,7 @@ struct st_engine {
     std::vector<void*> owned;           // device allocations to free
 
     float* rope_cos = nullptr; float* rope_sin = nullptr; int rope_T = 0;
+    void* sink = nullptr;               // 64 KiB of scratch: store target of rows outside the tensor (qkv_ws.hip)
     void* zeros = nullptr;              // 256 zero bytes: halo source of the LDS-DMA conv path
 
     // workspace arena
@@ -105,6 +106,8 @@ struct st_engine {
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     void* adams_buf = nullptr; size_t adams_bytes = 0;     // extra state buffers of the implicit Adams solver (allocated at its first use)
     int big_min_blocks = 192;
+    int qkv_ws_min_tiles = 256;         // ... when the launch (x concurrent parts) has at least this many 64-frame tiles
+    int qkv_ws = 0;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip); ST_QKV_WS=0: the generic conv tile
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
     int fused_ffn = 2;                  // FFN of big grids as ONE kernel, the intermediate kept in LDS: 2 = on 16x16x32 MFMA fragments (ffn_fused16.h),

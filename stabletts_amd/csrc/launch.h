@@ -41,6 +41,7 @@ struct ConvGemmArgs {
     const float* rope_cos; const float* rope_sin;   // [T][16]
     int Tp; float qscale; int n_heads;
     const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
+    void* sink;                       // >= 64 KiB of scratch that rows outside the tensor are stored to (qkv_ws.hip: every wave issues a FIXED number of stores)
     // fused prologue of the NEXT op (row-complete tiles, cout == 256): FiLM -> *mask -> LayerNorm -> modulate.
     // When ln_h16 != nullptr, out32 receives the post-FiLM residual stream and ln_h16 the 16-bit operand.
     void* ln_h16;
@@ -90,6 +91,9 @@ hipError_t launch_ffn_fused16_f16(const ConvGemmArgs& a, hipStream_t s);
 // A-fragments of 1 KiB stored lane-linear (fragment (ksl, a8): rows a8*32.., k-step 2*kp+ksl).  stage 0: src = conv_1 weight
 // (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).  stage | 2: the 16x16x32 kernel's fragments (common.h: ffn_stream_index).
 hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F, void* dst, hipStream_t s);
+// Fused q / k / v projection + RoPE of big grids as a weight-stationary persistent kernel (qkv_ws.hip): same arguments and results
+// (bit for bit) as launch_conv_gemm2_*(G2_RC*, 1, EPI_QKV, ...); needs hidden = 256, 4 heads, a.sink.
+hipError_t launch_qkv_ws(int dtype, const ConvGemmArgs& a, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 
