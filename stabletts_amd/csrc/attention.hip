@@ -176,9 +176,14 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     __syncthreads();
 
     const int ntiles_run = ntiles;
+    // ragged batch, inference: a wave whose 32 queries all lie past the item's last needed frame only keeps moving its share of
+    // the K / V pieces and taking the barriers -- its SIMD's matrix and vector issue slots go to the waves with real queries
+    bool dead = false;
+    if constexpr (!TRAIN) dead = a.t_lim && qt * QB + wave * 32 >= a.t_lim[mb];
     int buf = 0;
     for (int kt = 0; kt < ntiles_run; ++kt) {
         if (kt + 2 < ntiles_run) issueKV(kt + 2, buf >= 1 ? buf - 1 : NBUF - 1);      // (buf + 2) % 3
+        if (!dead) {
 
         f32x16_t s[2];
         const bool partial = (kt + 1) * 64 > nfull;       // tiles inside the valid prefix have no masked key
@@ -321,12 +326,14 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
             for (int g = 0; g < 4; ++g)
                 o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
         }
+        }
         // tile kt+1 (asm-issued LDS-DMA, flying under the MFMAs and exps of two tiles) has landed; tile kt+2 stays in flight
         if (kt + 2 < ntiles_run) { if constexpr (NW <= 8) { if constexpr (NW == 8) ST_DMA_WAIT(2); else ST_DMA_WAIT(4); } else ST_DMA_WAIT(1); }
         else ST_DMA_WAIT(0);
         __syncthreads();      // publishes tile kt+1, frees buffer kt % 3 for tile kt+3
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
+    if (dead) return;      // (after the loop's last barrier; nothing below synchronises the block)
     const float m_run = m_ref;
 
     const float l_tot = xor32_sum(l_run);

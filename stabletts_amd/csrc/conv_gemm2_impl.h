@@ -192,6 +192,10 @@ __device__ __forceinline__ void g2_epilogue_core(Park park, float* stage, const 
     const G2Consts kc = g2_consts<EPI, LN>(g, n, cbase + chl);
     const float* mrow = g.mask ? g.mask + (size_t)(n % g.mask_mod) * T : nullptr;
     const int an = n < g.add_clamp ? n : g.add_clamp;
+    // ragged batches: rows of this tile at or past the item's last needed frame (t_lim, launch.h) are neither stored nor fetched --
+    // their loads are clamped to the last needed row (one cached line) -- so the HBM-bound row phase shrinks with the padding
+    // at ROW granularity, not only by whole tiles
+    const int tlim = g.t_lim ? min(T, g.t_lim[n % g.t_lim_mod]) : T;
 #pragma unroll 1
     for (int p = 0; p < NPASS; ++p) {
         if (wf / WFP == p) park((wf % WFP) * TF);
@@ -204,8 +208,8 @@ __device__ __forceinline__ void g2_epilogue_core(Park park, float* stage, const 
             const int f = LN ? (wave + u * NW) : ((wave + u * NW) * 2 + hi);
             const int t = tbase + f;
             fr[u] = f; tt[u] = t;
-            ok[u] = (t < T) && (p * PASSF + f < fvalid);
-            const int tl = t < T ? t : T - 1;            // loads of an invalid row are clamped, its stores dropped
+            ok[u] = (t < tlim) && (p * PASSF + f < fvalid);
+            const int tl = t < tlim ? t : tlim - 1;      // loads of an invalid row are clamped, its stores dropped
             mk[u] = mrow ? mrow[tl] : 1.0f;
             xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)((g.res32 ? g.res32 : g.out32) + ((size_t)n * T + tl) * g.cout + cbase + chl);
@@ -434,6 +438,7 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
     const int wc = wave % WC, wf = wave / WC;
     const int T = g.T, H = g.n_heads;
     const int which = cbase / BC;                 // 0 q, 1 k, 2 v
+    const int tlim = g.t_lim ? min(T, g.t_lim[n % g.t_lim_mod]) : T;      // ragged batches: q / k rows past the last needed frame are not stored
     if (which < 2) {
         const float sc = which == 0 ? g.qscale : 1.0f;
 #pragma unroll
@@ -476,7 +481,7 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
             const int rowid = (i * NW + wave) * 8 + rsub;
             const int head = rowid / BF, f = rowid % BF;
             const uint4 v = *(const uint4*)(stage + rowid * PQ + seg * 16);
-            if (t0 + f < T) store_row16(dst + (((size_t)n * H + head) * T + t0 + f) * 128 + seg * 16, v);
+            if (t0 + f < tlim) store_row16(dst + (((size_t)n * H + head) * T + t0 + f) * 128 + seg * 16, v);
         }
     } else {
 #pragma unroll
