@@ -259,4 +259,11 @@ __host__ __device__ __forceinline__ void ffn_stream_index(size_t idx, int stage,
     *dst_off = (size_t)c * (48u * 8192u) + (size_t)((stage & 1) * 24 + sl) * 8192u + (idx & 8191);
 }
 
+// Fragment-ordered copy of the fused q/k/v weight for qkv_ws.hip: element (output channel co of plane `plane`, input channel ci) ->
+// [plane][wave = co / 32][k-step = ci / 16][lane = (ci % 16 / 8) * 32 + co % 32][ci % 8]: a wave's 16 MFMA fragments are 16
+// consecutive 1-KiB pieces, lane-linear.
+__host__ __device__ __forceinline__ size_t qkv_frag_index(int plane, int co, int ci) {
+    return ((((size_t)(plane * 8 + (co >> 5)) * 16 + (ci >> 4)) * 64 + ((ci >> 3) & 1) * 32 + (co & 31)) << 3) + (ci & 7);
+}
+
 }  // namespace st

@@ -131,8 +131,8 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         }
     }
     // the fused q/k/v projection of big grids: weights in registers, activations streamed (qkv_ws.hip; bit-identical)
-    if (epi == EPI_QKV && e->qkv_ws && e->sink && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
-        (int64_t)e->conc * a.n_items * ((T + 63) / 64) >= e->qkv_ws_min_tiles) {
+    if (epi == EPI_QKV && e->qkv_ws && e->sink && a.w_frag && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
+        (int64_t)a.n_items * ((T + 63) / 64) >= e->qkv_ws_min_tiles) {      // (per LAUNCH: a block needs a handful of tiles to amortise its weight load)
         ConvGemmArgs b = a; b.sink = e->sink;
         return launch_qkv_ws(e->dt, b, s);
     }
@@ -447,7 +447,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.out32 = p.X;
             fuse_ln1(a, i);
             ProfScope ps(e, s, PC_LSC, conv_flops(p, e->lsc[j], N));
-            HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+            if (!(e->skip_mask >> PC_LSC & 1)) HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
         }
         if (cap) { capture(e, bn + "x1", p.X, rowsC, false, s); capture(e, bn + "h1", p.h16, rowsC, true, s); }
         {   // q, k, v projections + RoPE (diffusion_transformer.py:59-61,74-75)
@@ -455,9 +455,10 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.a0 = p.h16; a.c0 = C;
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
             a.Tp = p.Tp; a.n_heads = e->H;
+            if ((int)e->qkv_frag.size() == L) a.w_frag = e->qkv_frag[i];
             a.qscale = 1.4426950408889634f / sqrtf((float)(C / e->H));
             ProfScope ps(e, s, PC_QKV, conv_flops(p, e->qkv[i], N));
-            HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
+            if (!(e->skip_mask >> PC_QKV & 1)) HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
         }
         if (cap) {
             capture(e, bn + "q", p.q16, rowsC, true, s); capture(e, bn + "k", p.k16, rowsC, true, s);
@@ -470,7 +471,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.small_max_blocks = e->conc == 1 ? e->attn_small_blocks : 0;
             if (e->ragged_skip && !cap) a.t_lim = p.t_lim;
             ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
-            HIPCHK(e, launch_attention(e->dt, a, s));
+            if (!(e->skip_mask >> PC_ATTN & 1)) HIPCHK(e, launch_attention(e->dt, a, s));
         }
         if (cap) capture(e, bn + "attn", p.ao16, rowsC, true, s);
         // Big grids: the whole FFN as ONE kernel, u never leaves the CU (ffn_fused.h; bit-identical to the two launches below).
@@ -484,7 +485,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.ln_h16 = h2buf; a.ln_film = nullptr; a.ln_film_mod = 1;
             a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
-            HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
+            if (!(e->skip_mask >> PC_OPROJ & 1)) HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
         if (cap) { capture(e, bn + "x2", p.X, rowsC, false, s); capture(e, bn + "h2", p.h16, rowsC, true, s); }
         if (!fused) {   // FFN conv_1 + SiLU + mask (diffusion_transformer.py:26-28)
@@ -506,7 +507,8 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             // block L/2 - 1 on the fp32 copy of x3 is dead, so it is not written (40 % of this epilogue's HBM bytes)
             else if (!cap) a.out32_readonly = 1;
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N) + (fused ? conv_flops(p, e->ffn1[i], N) : 0.0));
-            if (fused && e->fused_ffn == 2) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused16_bf16(a, s) : launch_ffn_fused16_f16(a, s));
+            if (e->skip_mask >> PC_FFN2 & 1) {}
+            else if (fused && e->fused_ffn == 2) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused16_bf16(a, s) : launch_ffn_fused16_f16(a, s));
             else if (fused) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused_bf16(a, s) : launch_ffn_fused_f16(a, s));
             else HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }
@@ -554,6 +556,7 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
             a.a0 = p.h16; a.c0 = C;
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
             a.Tp = p.Tp; a.n_heads = e->H;
+            if ((int)e->qkv_frag.size() == L) a.w_frag = e->qkv_frag[i];
             a.qscale = 1.4426950408889634f / sqrtf((float)(C / e->H));
             ProfScope ps(e, s, PC_QKV, conv_flops(p, e->qkv[i], N));
             HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
@@ -950,6 +953,7 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
     if (const char* v = getenv("ST_FUSED_FFN")) e->fused_ffn = atoi(v);
     if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);
+    if (const char* v = getenv("ST_SKIP_CLASSES")) e->skip_mask = (unsigned)strtoul(v, nullptr, 0);      // developer tool: results are garbage
     if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
     if (const char* v = getenv("ST_QKV_WS_MIN_TILES")) e->qkv_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)
@@ -1204,8 +1208,17 @@ int pack_all(st_engine* e, hipStream_t s) {
         if (!q.w && (rc = dev_alloc(e, &q.w, (size_t)3 * C * C * 2))) return rc;
         if (!q.bias && (rc = dev_alloc(e, (void**)&q.bias, (size_t)3 * C * 4))) return rc;
         int r = 0;
+        const bool frag = C == 256 && e->H == 4;      // the weight-stationary kernel's copy (qkv_ws.hip)
+        if (frag) {
+            if ((int)e->qkv_frag.size() != L) e->qkv_frag.assign(L, nullptr);
+            if (!e->qkv_frag[i] && (rc = dev_alloc(e, &e->qkv_frag[i], (size_t)3 * C * C * 2))) return rc;
+        }
         for (const char* nm : {"q", "k", "v"}) {
             const std::string n = b + "attn.conv_" + nm;
+            if (frag) {
+                HIPCHK(e, launch_pack_qkv_frag(e->dt, P(e, n + ".weight"), r, e->qkv_frag[i], s));
+                pk_push(PL, PackJob{P(e, n + ".weight"), e->qkv_frag[i], 4, 0, 0, 0, 0, 0, r * 256, 0, 0, 0, 0, 0u}, (size_t)C * C);
+            }
             if ((rc = pk_weight(e, PL, P(e, n + ".weight"), C, C, 1, 0, C, q.w, r * C, C, 0, C, 0, s))) return rc;
             if ((rc = pk_copy(e, PL, q.bias + (size_t)r * C, P(e, n + ".bias"), C, s))) return rc;
             ++r;
@@ -1301,7 +1314,10 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         if (!adaptive && !e->capture && B >= 2 && (want >= 2 || (want != 0 && want != 1 && frames >= 24000 && B >= 8))) nparts = 2;
         // four parts from 48 000 CFG-doubled frames on (B >= 32 at T = 1000): 25.5 -> 24.8 ms at the headline size, interleaved A/B
         // (profiles/r03_ab_solve_parts.txt); six or eight parts are much slower (31 / 29.5 ms: 40-block launches from 6-8 queues)
-        if (!adaptive && !e->capture && want != 0 && want != 1 && want != 2 && frames >= 48000 && B >= 32) nparts = 4;
+        // ... with the generic q/k/v tile.  With the weight-stationary q/k/v kernel (qkv_ws.hip, default) TWO parts are faster: its
+        // persistent blocks want >= 5 tiles each, i.e. half-batch launches (paired A/B, round 4: 2 parts + qkv_ws 24.60 ms against
+        // 4 parts + generic tile 24.91, ragged 21.61 against 22.09; profiles/r04b_ab_parts_qkv_ws.txt)
+        if (!adaptive && !e->capture && want != 0 && want != 1 && want != 2 && frames >= 48000 && B >= 32 && !(e->qkv_ws && e->sink)) nparts = 4;
         if (want > 2 && B >= want) nparts = std::min(want, kMaxParts);
         if (want == 1 || want == 0) nparts = 1;
     }

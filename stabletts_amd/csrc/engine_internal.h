@@ -70,6 +70,7 @@ struct st_engine {
     std::vector<sthost::Conv> pre;              // 3 prenet convs
     sthost::Conv inx, inc, fin;                 // in_proj x-part / cond-part, final_proj
     std::vector<sthost::Conv> lsc, qkv, oproj, ffn1, ffn2;
+    std::vector<void*> qkv_frag;        // per block: the q/k/v weight in fragment order (qkv_ws.hip); empty if unsupported
     std::vector<void*> ffn_stream;      // per block: conv_1 + conv_2 weights as the fused FFN kernel's stream (ffn_fused.h); empty if unsupported
     std::vector<void*> owned;           // device allocations to free
 
@@ -106,8 +107,10 @@ struct st_engine {
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     void* adams_buf = nullptr; size_t adams_bytes = 0;     // extra state buffers of the implicit Adams solver (allocated at its first use)
     int big_min_blocks = 192;
-    int qkv_ws_min_tiles = 256;         // ... when the launch (x concurrent parts) has at least this many 64-frame tiles
-    int qkv_ws = 0;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip); ST_QKV_WS=0: the generic conv tile
+    unsigned skip_mask = 0;             // developer tool (ST_SKIP_CLASSES, bit = profile class): launches of these classes of run_estimator are NOT issued -- what a
+                                        // class costs the solve with its parts overlapping on four streams (tools/ab_engines.py); results are garbage
+    int qkv_ws_min_tiles = 400;         // ... when the launch has at least this many 64-frame tiles (>= 5 per persistent block)
+    int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip); ST_QKV_WS=0: the generic conv tile
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
     int fused_ffn = 1;                  // FFN of big grids as ONE kernel, the intermediate kept in LDS: 2 = on 16x16x32 MFMA fragments (ffn_fused16.h),

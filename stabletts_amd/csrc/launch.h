@@ -41,6 +41,7 @@ struct ConvGemmArgs {
     const float* rope_cos; const float* rope_sin;   // [T][16]
     int Tp; float qscale; int n_heads;
     const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
+    const void* w_frag;               // qkv_ws.hip: the q/k/v weight in fragment order (launch_pack_qkv_frag)
     void* sink;                       // >= 64 KiB of scratch that rows outside the tensor are stored to (qkv_ws.hip: every wave issues a FIXED number of stores)
     // fused prologue of the NEXT op (row-complete tiles, cout == 256): FiLM -> *mask -> LayerNorm -> modulate.
     // When ln_h16 != nullptr, out32 receives the post-FiLM residual stream and ln_h16 the 16-bit operand.
@@ -94,6 +95,9 @@ hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F,
 // Fused q / k / v projection + RoPE of big grids as a weight-stationary persistent kernel (qkv_ws.hip): same arguments and results
 // (bit for bit) as launch_conv_gemm2_*(G2_RC*, 1, EPI_QKV, ...); needs hidden = 256, 4 heads, a.sink.
 hipError_t launch_qkv_ws(int dtype, const ConvGemmArgs& a, hipStream_t s);
+// plane (0 q, 1 k, 2 v) of the fragment-ordered weight copy that kernel reads: src = fp32 conv weight (256, 256, 1) of the plane,
+// dst = the whole 3 x 256 x 256 16-bit buffer (common.h: qkv_frag_index).  PackJob kind 4 (row_off = 256 * plane) is the same map.
+hipError_t launch_pack_qkv_frag(int dtype, const float* src, int plane, void* dst, hipStream_t s);
 constexpr int kGemmFramesPerTile = 128;
 constexpr int kGemmChannelsPerTile = 128;
 
@@ -177,7 +181,7 @@ hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n
 // One launch for a whole list of packing jobs (the ~100 launch_pack_weight / launch_pack_weight_t calls and ~60 bias copies of a
 // re-pack after an optimizer step are each a few microseconds of launch latency: 0.75 ms per training step as separate launches).
 // kind 0: launch_pack_weight's mapping, kind 1: launch_pack_weight_t's (train_launch.h), kind 2: fp32 copy of `cout` elements,
-// kind 3: launch_pack_ffn_stream's (lo = stage, cout = F).
+// kind 3: launch_pack_ffn_stream's (lo = stage, cout = F), kind 4: launch_pack_qkv_frag's (row_off = 256 * plane).
 // blk0 = first 256-thread block of the job in the merged grid (jobs sorted by blk0).
 struct PackJob { const float* src; void* dst; int kind, cout, cin_total, K, ci_off, ci_cnt, row_off, cin_p, col_off, slice_w, lo; unsigned blk0; };
 hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t s);

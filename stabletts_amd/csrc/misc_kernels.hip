@@ -500,6 +500,19 @@ hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F,
     return hipGetLastError();
 }
 
+// fragment-ordered q/k/v weight (common.h: qkv_frag_index)
+template <class P>
+__global__ void pack_qkv_frag_kernel(const float* src, int plane, typename P::elem* dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 256 * 256) return;
+    dst[qkv_frag_index(plane, idx >> 8, idx & 255)] = to16<P>(src[idx]);
+}
+hipError_t launch_pack_qkv_frag(int dtype, const float* src, int plane, void* dst, hipStream_t s) {
+    if (dtype == DT_BF16) hipLaunchKernelGGL((pack_qkv_frag_kernel<OpBF16>), dim3(256), dim3(256), 0, s, src, plane, (__bf16*)dst);
+    else                  hipLaunchKernelGGL((pack_qkv_frag_kernel<OpF16>), dim3(256), dim3(256), 0, s, src, plane, (_Float16*)dst);
+    return hipGetLastError();
+}
+
 template <class P>
 __global__ void cvt16_kernel(const typename P::elem* src, float* dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,17 +21,19 @@ int main(int argc, char** argv) {
     std::vector<float> bias(768), rc((size_t)T * 16), rsn((size_t)T * 16);
     for (auto& v : bias) v = frand() * 0.1f;
     for (size_t i = 0; i < rc.size(); ++i) { rc[i] = cosf(0.001f * i); rsn[i] = sinf(0.001f * i); }
+    std::vector<_Float16> wfr(w.size());
+    for (int co = 0; co < 768; ++co) for (int ci = 0; ci < C; ++ci) wfr[qkv_frag_index(co / 256, co % 256, ci)] = w[(size_t)co * C + ci];
     void *dh, *dw, *db, *dq, *dk, *dv, *dz, *dsink, *drc, *drs;
     CK(hipMalloc(&dh, h.size() * 2)); CK(hipMalloc(&dw, w.size() * 2)); CK(hipMalloc(&db, 768 * 4));
     CK(hipMalloc(&dq, (size_t)NMAX * T * C * 2)); CK(hipMalloc(&dk, (size_t)NMAX * T * C * 2)); CK(hipMalloc(&dv, (size_t)NMAX * Tp * C * 2));
     CK(hipMalloc(&dz, 256)); CK(hipMemset(dz, 0, 256)); CK(hipMalloc(&dsink, 65536)); CK(hipMalloc(&drc, rc.size() * 4)); CK(hipMalloc(&drs, rc.size() * 4));
-    CK(hipMemcpy(dh, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dh, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, wfr.data(), wfr.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, bias.data(), 768 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(drc, rc.data(), rc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(drs, rsn.data(), rc.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int N : {64, 16}) {
         ConvGemmArgs a; memset(&a, 0, sizeof(a));
-        a.a0 = dh; a.c0 = C; a.a0_mod = N; a.w = dw; a.bias = (const float*)db; a.cout = 768; a.T = T; a.n_items = N;
+        a.a0 = dh; a.c0 = C; a.a0_mod = N; a.w = dw; a.w_frag = dw; a.bias = (const float*)db; a.cout = 768; a.T = T; a.n_items = N;
         a.q = dq; a.k = dk; a.vt = dv; a.rope_cos = (const float*)drc; a.rope_sin = (const float*)drs; a.Tp = Tp; a.qscale = 0.18f; a.n_heads = H;
         a.zeros = dz; a.sink = dsink;
         const int tiles_f = (T + 63) / 64;
@@ -60,7 +62,7 @@ int main(int argc, char** argv) {
     {   // loop anatomy (var 64: s_memtime stamps; ticks of the 100 MHz constant-rate counter -> ns)
         ConvGemmArgs a; memset(&a, 0, sizeof(a));
         const int N = 64, tiles_f = (T + 63) / 64; int L = 85 / tiles_f; if (L < 1) L = 1;
-        a.a0 = dh; a.c0 = C; a.a0_mod = N; a.w = dw; a.bias = (const float*)db; a.cout = 768; a.T = T; a.n_items = N;
+        a.a0 = dh; a.c0 = C; a.a0_mod = N; a.w = dw; a.w_frag = dw; a.bias = (const float*)db; a.cout = 768; a.T = T; a.n_items = N;
         a.q = dq; a.k = dk; a.vt = dv; a.rope_cos = (const float*)drc; a.rope_sin = (const float*)drs; a.Tp = Tp; a.qscale = 0.18f; a.n_heads = H;
         a.zeros = dz; a.sink = dsink;
         unsigned long long* dd; CK(hipMalloc(&dd, 64 * 2 * 8 * 8)); CK(hipMemset(dd, 0, 64 * 2 * 8 * 8)); a.dbg = dd;
