@@ -162,7 +162,7 @@ CLASS_KERNEL = {
     "ffn_conv2": "ffn_fused_kernel<st::Op{DT}, 0, 0>",        # the whole FFN since round 4 (conv_1 + SiLU + conv_2 in one launch)
     "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
     "attention": "attention_kernel<st::Op{DT}, false>",
-    "qkv_rope": "conv_gemm2_kernel<st::Op{DT}, 1, 3, 256, 128, 4, 2, 1>",
+    "qkv_rope": "qkv_ws_kernel<st::Op{DT}, 0>",               # weight-stationary persistent kernel (qkv_ws.hip)
     "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4, 2>",
 }
 
@@ -452,7 +452,7 @@ def main():
                                          "into a launch's event-bracketed duration"},
             "whole_solve_tflops": falg * B_PER_GPU * T_batch / (elapsed / args.steps) / 1e12 * world,
             "solve_parts": int(os.environ.get("ST_SPLIT", "-1")),
-            "solve_parts_note": "-1 = library default: batches >= 24000 (CFG-doubled) frames run as two part-batch launch sequences on two streams, >= 48000 with B >= 32 as four",
+            "solve_parts_note": "-1 = library default: batches >= 24000 (CFG-doubled) frames run as two part-batch launch sequences on two streams (four only with the generic q/k/v tile, ST_QKV_WS=0)",
             "whole_solve_hbm": (lambda b: None if b is None else {
                 "bytes_per_solve_pmc": b, "achieved": b / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS})(pmc_solve_bytes() if N_STEPS == 10 else None),

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Interleaved A/B of two engine configurations inside ONE process (developer tool): each configuration = a set of ST_* variables
-read at st_create; the headline solve (B=32 x T=1000, 10 Euler steps, CFG) alternates between the two engines so that clock /
-thermal drift hits both alike.     usage: python tools/ab_engines.py "ST_FUSED_FFN=1" "ST_FUSED_FFN=2" [rounds] [per_round]"""
+read at st_create (and visible at solve time: ST_SPLIT); the headline solve (B=32 x T=1000, 10 Euler steps, CFG) alternates between the two engines so that clock /
+thermal drift hits both alike.  ONLY for configurations with the same number of solve parts: two engines' part streams share the
+process's hardware queues, and a 4-part engine next to a 2-part one measured 30.7 ms instead of its 24.4 -- compare part counts in
+separate processes, alternating (tools/r04b_session10.sh).     usage: python tools/ab_engines.py "ST_FUSED_FFN=1" "ST_FUSED_FFN=2" [rounds] [per_round]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
