@@ -356,6 +356,7 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
             ConvGemmArgs a = cargs(e, e->qkv[i], N, T, B);
             a.a0 = A.h1; a.c0 = C; a.q = A.q; a.k = A.k; a.vt = A.vt; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
             a.Tp = Tp; a.n_heads = H; a.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
+            if ((int)e->qkv_frag.size() == e->L) a.w_frag = e->qkv_frag[i];      // weight-stationary kernel on big batches (bit-identical; re-packed with the other forward weights)
             HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
         }
         {
