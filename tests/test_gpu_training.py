@@ -510,12 +510,20 @@ def test_backward_of_replaced_activations_fails_loudly(sd):
         lc.backward()
 
 
-def test_optimizer_steps_repack_in_place_without_reallocation(sd):
+@pytest.mark.parametrize("qkv_ws", [False, True])
+def test_optimizer_steps_repack_in_place_without_reallocation(sd, monkeypatch, qkv_ws):
     """Every optimizer step bumps the parameters' version counters (train.py:82).  The engine reads the fp32 tensors
     where torch keeps them (st_bind_param) and re-packs its 16-bit copies on the stream (st_repack): device bytes and
-    the time-step count stay put, and the result equals a fresh decoder loaded with the updated weights bit for bit."""
+    the time-step count stay put, and the result equals a fresh decoder loaded with the updated weights bit for bit.
+    qkv_ws: the weight-stationary q/k/v kernel forced at this small size (it reads its own fragment-ordered copy of the
+    weight, re-packed by the same job list: PackJob kind 4) against a fresh decoder on the generic tile."""
     from stabletts_amd.flow_matching import CFMDecoder
+    if qkv_ws:
+        monkeypatch.setenv("ST_QKV_WS_MIN_TILES", "1")
     dec = _decoder(sd, "f16", train=True)
+    dec.estimator.engine()
+    if qkv_ws:
+        monkeypatch.setenv("ST_QKV_WS", "0")          # every engine created from here on: the generic tile
     opt = torch.optim.AdamW(dec.parameters(), lr=1e-3)
     inp = make_inputs(2, 64, seed=71, lengths=[64, 50])
     x1 = make_inputs(2, 64, seed=72)["z"].cuda()
