@@ -448,7 +448,7 @@ def main():
                          "launches_sampled": p["launches"], "sample_stride": PROFILE_STRIDE, "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": p["flops_per_launch"],
                          "sampled_over": f"{args.steps} single-sequence solves (ST_SPLIT=1, {single_seq_ms:.2f} ms each) run right after "
-                                         "the timed region, whose concurrent part sequences (up to four streams) would fold the other parts' kernels "
+                                         "the timed region, whose concurrent part sequences (two streams by default) would fold the other parts' kernels "
                                          "into a launch's event-bracketed duration"},
             "whole_solve_tflops": falg * B_PER_GPU * T_batch / (elapsed / args.steps) / 1e12 * world,
             "solve_parts": int(os.environ.get("ST_SPLIT", "-1")),
