@@ -110,7 +110,8 @@ struct st_engine {
     unsigned skip_mask = 0;             // developer tool (ST_SKIP_CLASSES, bit = profile class): launches of these classes of run_estimator are NOT issued -- what a
                                         // class costs the solve with its parts overlapping on four streams (tools/ab_engines.py); results are garbage
     int qkv_ws_min_tiles = 400;         // ... when the launch has at least this many 64-frame tiles (>= 5 per persistent block)
-    int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip); ST_QKV_WS=0: the generic conv tile
+    int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip): 1 = eight waves, one block per CU,
+                                        // 2 = four waves, two blocks per CU; ST_QKV_WS=0: the generic conv tile
     int oproj_rc = 0;                   // out projection of big grids on row-complete 256 x 128 tiles (G2_RC) instead of 256 x 256 (ST_OPROJ_RC=1: A/B runs)
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
