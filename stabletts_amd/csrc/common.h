@@ -198,6 +198,12 @@ __device__ __forceinline__ void glds16bo(const void* gsrc, unsigned lds_off) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
+// the 4-byte-per-lane form (64 lanes x 4 B = 256 B at lds_off + 4 lane): for fp32 rows whose start is only dword-aligned
+__device__ __forceinline__ void glds4bo(const void* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
 // wave-uniform 64-bit pointer held in SGPRs
 __device__ __forceinline__ const unsigned char* sgpr_ptr64(const void* p) {
     const uintptr_t v = (uintptr_t)p;

@@ -137,6 +137,13 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         if (e->qkv_ws == 2) b.flags |= GF_QWS4;
         return launch_qkv_ws(e->dt, b, s);
     }
+    // the out projection (+ LayerNorm_2) of big grids in the same style (oproj_ws.hip; bit-identical)
+    if (epi == EPI_RESGATE && taps == 1 && e->oproj_ws && e->sink && a.w_frag && a.ln_h16 && !a.ln_film && a.cout == 256 && a.c0 == 256 &&
+        !a.c1 && !a.c2 && !a.out16 && !a.res32 && !a.branch32 && !a.out32_readonly && a.out32 &&
+        (int64_t)a.n_items * ((T + 31) / 32) >= e->oproj_ws_min_tiles) {
+        ConvGemmArgs b = a; b.sink = e->sink;
+        return launch_oproj_ws(e->dt, b, s);
+    }
     int cfg;
     if (big_tiles(e, a)) cfg = (e->phased && taps == 3) ? G2_PHASED : (epi == EPI_QKV && e->qkv_rc1) ? G2_RC1 : G2_BIG;
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
@@ -486,6 +493,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.a0 = p.ao16; a.c0 = C; a.mask = mask; a.gate = ada_i + 2 * C; a.gate_stride = 6 * C; a.out32 = p.X;
             a.ln_h16 = h2buf; a.ln_film = nullptr; a.ln_film_mod = 1;
             a.ln_ada = ada_i; a.ln_ada_stride = 6 * C; a.ln_shift_off = 3 * C; a.ln_scale_off = 4 * C; a.ln_mask_out = 1;
+            if ((int)e->oproj_frag.size() == L && !cap) a.w_frag = e->oproj_frag[i];
             ProfScope ps(e, s, PC_OPROJ, conv_flops(p, e->oproj[i], N));
             if (!(e->skip_mask >> PC_OPROJ & 1)) HIPCHK(e, gemm(e, 1, EPI_RESGATE, a, s));
         }
@@ -959,6 +967,8 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
     if (const char* v = getenv("ST_QKV_WS_MIN_TILES")) e->qkv_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_OPROJ_RC")) e->oproj_rc = atoi(v);
+    if (const char* v = getenv("ST_OPROJ_WS")) e->oproj_ws = atoi(v);
+    if (const char* v = getenv("ST_OPROJ_WS_MIN_TILES")) e->oproj_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)
     if (const char* v = getenv("ST_SMALL_GRID")) {      // 0: none of the small-grid variants (split-K convs, 64-frame tiles,
         if (atoi(v) == 0) {                               // key-split attention): results independent of the batch composition
@@ -1227,6 +1237,12 @@ int pack_all(st_engine* e, hipStream_t s) {
             ++r;
         }
         if ((rc = pack(e->oproj[i], b + "attn.conv_o.weight", P(e, b + "attn.conv_o.bias"), C, C, C, 1, 0, C, C, false))) return rc;
+        if (frag) {      // the weight-stationary out-projection kernel's copy (oproj_ws.hip): plane 0 of the same fragment order
+            if ((int)e->oproj_frag.size() != L) e->oproj_frag.assign(L, nullptr);
+            if (!e->oproj_frag[i] && (rc = dev_alloc(e, &e->oproj_frag[i], (size_t)C * C * 2))) return rc;
+            HIPCHK(e, launch_pack_qkv_frag(e->dt, P(e, b + "attn.conv_o.weight"), 0, e->oproj_frag[i], s));
+            pk_push(PL, PackJob{P(e, b + "attn.conv_o.weight"), e->oproj_frag[i], 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u}, (size_t)C * C);
+        }
         if ((rc = pack(e->ffn1[i], b + "mlp.conv_1.weight", P(e, b + "mlp.conv_1.bias"), F, F, C, K, 0, C, C, false))) return rc;
         if ((rc = pack(e->ffn2[i], b + "mlp.conv_2.weight", P(e, b + "mlp.conv_2.bias"), C, C, F, K, 0, F, F, false))) return rc;
         if (e->kind == 0 && C == 256 && K == 3 && F % 256 == 0 && F <= 2048) {      // the fused FFN kernel's weight stream (ffn_fused.h)

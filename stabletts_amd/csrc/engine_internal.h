@@ -70,6 +70,7 @@ struct st_engine {
     std::vector<sthost::Conv> pre;              // 3 prenet convs
     sthost::Conv inx, inc, fin;                 // in_proj x-part / cond-part, final_proj
     std::vector<sthost::Conv> lsc, qkv, oproj, ffn1, ffn2;
+    std::vector<void*> oproj_frag;      // per block: the out-projection weight in fragment order (oproj_ws.hip)
     std::vector<void*> qkv_frag;        // per block: the q/k/v weight in fragment order (qkv_ws.hip); empty if unsupported
     std::vector<void*> ffn_stream;      // per block: conv_1 + conv_2 weights as the fused FFN kernel's stream (ffn_fused.h); empty if unsupported
     std::vector<void*> owned;           // device allocations to free
@@ -112,6 +113,8 @@ struct st_engine {
     int qkv_ws_min_tiles = 400;         // ... when the launch has at least this many 64-frame tiles (>= 5 per persistent block)
     int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip): 1 = eight waves, one block per CU,
                                         // 2 = four waves, two blocks per CU; ST_QKV_WS=0: the generic conv tile
+    int oproj_ws = 0;                   // out projection of big grids as the weight-stationary persistent kernel (oproj_ws.hip); ST_OPROJ_WS=1
+    int oproj_ws_min_tiles = 1000;      // ... from this many 32-frame tiles per launch
     int oproj_rc = 0;                   // out projection of big grids on row-complete 256 x 128 tiles (G2_RC) instead of 256 x 256 (ST_OPROJ_RC=1: A/B runs)
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)

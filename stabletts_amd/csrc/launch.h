@@ -95,6 +95,10 @@ hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F,
 // Fused q / k / v projection + RoPE of big grids as a weight-stationary persistent kernel (qkv_ws.hip): same arguments and results
 // (bit for bit) as launch_conv_gemm2_*(G2_RC*, 1, EPI_QKV, ...); needs hidden = 256, 4 heads, a.sink.
 hipError_t launch_qkv_ws(int dtype, const ConvGemmArgs& a, hipStream_t s);
+// The attention out-projection + gate + residual + LayerNorm_2 + modulate of big grids as a weight-stationary persistent kernel
+// (oproj_ws.hip): same arguments and results (bit for bit) as launch_conv_gemm2_*(G2_BIG, 1, EPI_RESGATE, ...) with ln_h16 set, no
+// FiLM, the residual updated in place; needs hidden = 256, a.w_frag (plane 0 of a launch_pack_qkv_frag copy), a.sink.
+hipError_t launch_oproj_ws(int dtype, const ConvGemmArgs& a, hipStream_t s);
 // plane (0 q, 1 k, 2 v) of the fragment-ordered weight copy that kernel reads: src = fp32 conv weight (256, 256, 1) of the plane,
 // dst = the whole 3 x 256 x 256 16-bit buffer (common.h: qkv_frag_index).  PackJob kind 4 (row_off = 256 * plane) is the same map.
 hipError_t launch_pack_qkv_frag(int dtype, const float* src, int plane, void* dst, hipStream_t s);

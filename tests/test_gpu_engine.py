@@ -216,6 +216,30 @@ def test_weight_stationary_qkv_is_bit_identical_to_the_generic_tile(sd, cfg_para
         assert torch.equal(torch.as_tensor(got["old"][k]), torch.as_tensor(got["new"][k])), k
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_weight_stationary_out_projection_is_bit_identical_to_the_generic_tile(sd, cfg_params, monkeypatch, dtype):
+    """oproj_ws_kernel (out projection + gate + residual + LayerNorm_2 + modulate as a persistent kernel: weight in registers,
+    attention output / residual rows / per-item constants / frame mask all by LDS-DMA one 32-frame tile ahead, the residual stream
+    updated in place) against conv_gemm2_kernel<EPI_RESGATE>: whole solves bit for bit -- T not a multiple of 32, ragged work
+    lists with holes, a length-1 row, masks, more items than a block's list stride, repeated."""
+    kw = _kw(cfg_params, 3.0)
+    old = _fresh(sd, monkeypatch, dtype, ST_OPROJ_WS="0", ST_SMALL_GRID="0")
+    new = _fresh(sd, monkeypatch, dtype, ST_OPROJ_WS="1", ST_OPROJ_WS_MIN_TILES="1", ST_SMALL_GRID="0")
+    cases = [(2, 64, [64, 33]), (1, 65, [65]), (3, 253, [253, 252, 1]), (2, 700, [700, 255]), (4, 1000, [1000, 873, 640, 377]),
+             (9, 130, [130, 7, 129, 64, 65, 1, 128, 100, 130]), (32, 1000, None)]
+    for B, T, lengths in cases:
+        inp = make_inputs(B, T, seed=40 + T, lengths=lengths) if lengths else make_inputs(B, T, seed=0, ragged=True)
+        ref = _solve(old, inp, 2, "euler", kw)
+        for _ in range(3):
+            out = _solve(new, inp, 2, "euler", kw)
+            assert torch.equal(out, ref), (B, T, float((out - ref).abs().max()))
+    inp = make_inputs(3, 400, seed=61, lengths=[400, 399, 17])
+    t = torch.tensor([0.1, 0.5, 0.9])
+    args = (t.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+    with torch.no_grad():
+        assert torch.equal(new.estimator(*args), old.estimator(*args))
+
+
 @pytest.mark.parametrize("F", [512, 768, 2048])
 def test_fused_ffn_other_filter_widths(cfg_params, monkeypatch, F):
     """The fused kernel walks the intermediate in 256-channel chunks (2, 3, 8 of them here instead of the 31M model's 4); its
