@@ -163,7 +163,7 @@ CLASS_KERNEL = {
     "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
     "attention": "attention_kernel<st::Op{DT}, false>",
     "qkv_rope": "qkv_ws_kernel<st::Op{DT}, 0>",               # weight-stationary persistent kernel (qkv_ws.hip)
-    "out_proj": "conv_gemm2_kernel<st::Op{DT}, 1, 2, 256, 256, 2, 4, 2>",
+    "out_proj": "oproj_ws_kernel<st::Op{DT}>",                # weight-stationary persistent kernel (oproj_ws.hip)
 }
 
 

@@ -113,7 +113,7 @@ struct st_engine {
     int qkv_ws_min_tiles = 400;         // ... when the launch has at least this many 64-frame tiles (>= 5 per persistent block)
     int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip): 1 = eight waves, one block per CU,
                                         // 2 = four waves, two blocks per CU; ST_QKV_WS=0: the generic conv tile
-    int oproj_ws = 0;                   // out projection of big grids as the weight-stationary persistent kernel (oproj_ws.hip); ST_OPROJ_WS=1
+    int oproj_ws = 1;                   // out projection of big grids as the weight-stationary persistent kernel (oproj_ws.hip; default); ST_OPROJ_WS=0: the generic 256 x 256 tile
     int oproj_ws_min_tiles = 1000;      // ... from this many 32-frame tiles per launch
     int oproj_rc = 0;                   // out projection of big grids on row-complete 256 x 128 tiles (G2_RC) instead of 256 x 256 (ST_OPROJ_RC=1: A/B runs)
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)

@@ -11,12 +11,14 @@
 //                       residual rows x_1 32 x 1 KiB fp32                                        4 pieces per wave
 //                       the item's gate / shift / scale rows 3 x 1 KiB (waves 0..2), the frame mask of the 32 frames (wave 3, 4-byte
 //                       pieces: the row is only dword-aligned), zero page -> sink KiB (waves 4..7)      1 piece per wave
-//   iteration i:  wait(tile i) . barrier A . issue tile i+1 (7 pieces) . 16 x (read + MFMA) . park acc -> stage . barrier B .
-//                 row walk: 4 rows per wave -- x_2 = x_1 + gate ((acc + b) mask) -> store (1 KiB), LayerNorm over the 256 channels
-//                 (DPP / permlane sums), modulate, mask -> 16-bit store (512 B)                  8 stores per wave
-//   `s_waitcnt vmcnt(8)` at the top retires everything but the 8 stores of the previous tile; RAW / WAR as in qkv_ws.hip (ring
-//   slot (i+1) % 2 held tile i-1, last read in the row walk of iteration i-1, before each wave's arrival at barrier A of iteration
-//   i; the stage is rewritten after barrier A of iteration i+1).
+//   iteration i:  wait(tile i) . barrier A . issue tile i+2 (7 pieces) . 16 x (read + MFMA) . x_2 = x_1 + gate ((acc + b) mask) written
+//                 INTO the staged residual rows (lane = frame; they double as the transposition stage, 260-float pitch) . barrier B .
+//                 row walk: 4 rows per wave (lane = 4 channels) -- x_2 -> store (1 KiB), LayerNorm over the 256 channels (DPP /
+//                 permlane sums), modulate, mask -> 16-bit store (512 B)                           8 stores per wave
+//   THREE ring slots, two tiles (106 KB) in flight per CU: with one tile ahead the kernel sat at the generic tile's 4.4 TB/s
+//   (54 KB in flight / 2.7 us of loaded latency = 20 GB/s per CU).  `s_waitcnt vmcnt(23)` at the top retires everything but
+//   stores i-2, pieces i+1, stores i-1; RAW / WAR as in qkv_ws.hip (ring slot (i+2) % 3 held tile i-1, last read in the row walk of
+//   iteration i-1, before each wave's arrival at barrier A of iteration i).
 // No ordinary load sits inside the loop (even a wave-uniform one is issued as a vector load and guarded by a compiler-generated
 // vmcnt(0) that would wait for the pieces just issued): the items' frame limits are parked in LDS up front.  The row arithmetic is g2_rows'
 // (EPI_RESGATE + LayerNorm branch, conv_gemm2_impl.h) expression for expression: results are bit-identical to the generic tile.
@@ -26,10 +28,10 @@
 
 namespace st {
 
-constexpr int kOwsAo = 32 * 512, kOwsX = 32 * 1024, kOwsConst = 5120;                 // per ring slot: operand tile, residual rows, gate / shift / scale rows, mask KiB, sink KiB
-constexpr int kOwsSlot = kOwsAo + kOwsX + kOwsConst;                                   // 54,272 B
-constexpr int kOwsStage = 32 * 260 * 4;                                                // parked accumulators [frame][256 + 4] fp32
-constexpr int kOwsLds = 2 * kOwsSlot + kOwsStage + 256;                                // 142,080 B (+ the items' frame limits)
+constexpr int kOwsAo = 32 * 512, kOwsXPitch = 1040, kOwsX = 32 * kOwsXPitch, kOwsConst = 3 * 1024 + 256;
+constexpr int kOwsSlot = kOwsAo + kOwsX + kOwsConst;      // operand tile, residual rows (260-float pitch), gate / shift / scale rows, 32 mask values: 52,992 B
+constexpr int kOwsRing = 3;
+constexpr int kOwsLds = kOwsRing * kOwsSlot + 1024 + 256;      // + one sink KiB + the items' frame limits: 160,256 B
 
 #define ST_RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -64,14 +66,13 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
         todo &= todo - 1;
         return first + j * L;
     };
-    int ncur = pop_item(), n1 = pop_item();
+    int ncur = pop_item(), n1 = pop_item(), n2 = pop_item();
 
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)smem);
     const unsigned char* zeros = (const unsigned char*)g.zeros;
-    float* stage = (float*)(smem + 2 * kOwsSlot);
     // last needed frame of the block's items, parked in LDS (entry j = item first + j L): a load inside the loop -- even a
     // wave-uniform one, hipcc issues it as a vector load -- would put a compiler-generated vmcnt(0) into the pipeline
-    int* tlimT = (int*)(smem + 2 * kOwsSlot + kOwsStage);
+    int* tlimT = (int*)(smem + kOwsRing * kOwsSlot + 1024);
     if (wave == 0) {
         const int n = first + lane * L;
         int tl = T;
@@ -79,7 +80,7 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
         tlimT[lane] = tl;
     }
 
-    // ---- LDS-DMA of one tile: 2 operand pieces (chunk w >> 1, rows 16 (w & 1) + 8 k ..), 4 residual rows (4 w + k), 1 constant row
+    // ---- LDS-DMA of one tile: 2 operand pieces (chunk w >> 1, rows 16 (w & 1) + 8 k ..), 4 residual rows (4 w + k), 1 constant piece
     unsigned voffA[2]; bool vrowA[2]; unsigned voffX[4]; bool vrowX[4];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -103,7 +104,7 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
         for (int k = 0; k < 2; ++k)
             glds16bo((unit && vrowA[k]) ? ab + voffA[k] : zeros, base + (unsigned)((wave >> 1) * 4096 + (wave & 1) * 2048 + k * 1024));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) glds16bo((unit && vrowX[k]) ? xb + voffX[k] : zeros, base + (unsigned)(kOwsAo + (wave * 4 + k) * 1024));
+        for (int k = 0; k < 4; ++k) glds16bo((unit && vrowX[k]) ? xb + voffX[k] : zeros, base + (unsigned)(kOwsAo + (wave * 4 + k) * kOwsXPitch));
         {   // waves 0, 1, 2: the item's gate / adaLN shift / adaLN scale rows; wave 3: the frame mask of the tile's 32 frames (a row
             // that is only dword-aligned: 4-byte pieces, frames past T clamped like the generic epilogue); waves 4..7: zero page -> sink
             const float* ad = g.ln_ada + (size_t)nn * g.ln_ada_stride;
@@ -114,22 +115,24 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
             } else {
                 const float* src = wave == 0 ? g.gate + (size_t)nn * g.gate_stride : wave == 1 ? ad + g.ln_shift_off : ad + g.ln_scale_off;
                 const unsigned char* p = (unit && wave < 3) ? (const unsigned char*)src + lane * 16 : zeros;
-                glds16bo(p, base + (unsigned)(kOwsAo + kOwsX + (wave < 3 ? wave * 1024 : 4 * 1024)));
+                glds16bo(p, wave < 3 ? base + (unsigned)(kOwsAo + kOwsX + wave * 1024) : lds0 + (unsigned)(kOwsRing * kOwsSlot));
             }
         }
     };
     issue_tile(ncur, 0);
+    issue_tile(n1, 1);
 
-    // ---- the wave's weights (fragment-ordered copy, plane 0) and per-lane constants of the row walk (lane = 4 channels)
+    // ---- the wave's weights (fragment-ordered copy, plane 0) and constants
     vec8 wf[16];
     {
         const unsigned char* wfrag = (const unsigned char*)g.w_frag + ((size_t)wave * 16 * 64 + lane) * 16;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) wf[ks] = as_vec8<P>(*(const uint4*)(wfrag + ks * 1024));
     }
-    const int ch = lane * 4;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias) bias4 = *(const float4*)(g.bias + ch);
+    const int ch = lane * 4;      // the lane's channels in the row walk
+    float4 bias4[4];              // bias of the lane's accumulator channels 32 w + 8 q4 + 4 hi .. + 3
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) bias4[q4] = g.bias ? *(const float4*)(g.bias + wave * 32 + 8 * q4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned radr[4];
 #pragma unroll
     for (int ksl = 0; ksl < 4; ++ksl) radr[ksl] = (unsigned)(l31 * 128 + (((ksl * 2 + hi) ^ ((l31 >> 1) & 7)) << 4));
@@ -138,18 +141,24 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
     const bool mout = g.ln_mask_out;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(wf[ks]));      // every ordinary load retired before the loop (qkv_ws.hip)
-    asm volatile("" : "+v"(bias4.x), "+v"(bias4.y), "+v"(bias4.z), "+v"(bias4.w));
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) asm volatile("" : "+v"(bias4[q4].x), "+v"(bias4[q4].y), "+v"(bias4[q4].z), "+v"(bias4[q4].w));
 
     int slot = 0;
     for (int i = 0; ; ++i) {
         __builtin_amdgcn_sched_barrier(0);
-        if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // younger than tile i's pieces: the 8 stores of tile i-1
+        if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (tile 1's pieces too: once)
+        else if (i == 1) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");      // younger than tile 1's pieces: tile 2's 7 pieces, the 8 stores of tile 0
+        else asm volatile("s_waitcnt vmcnt(23)" ::: "memory");                  // younger than tile i's pieces: stores i-2, pieces i+1, stores i-1
         ST_RAW_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
-        issue_tile(n1, slot ^ 1);
+        {
+            int s2 = slot + 2; if (s2 >= kOwsRing) s2 -= kOwsRing;
+            issue_tile(n2, s2);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned base = lds0 + (unsigned)(slot * kOwsSlot);
+        unsigned char* slotp = smem + slot * kOwsSlot;
         // ---- 32 channels x 32 frames x K 256, k-steps in order (the generic tile's order), accumulator from zero like g2_init_acc
         f32x16_t acc;
 #pragma unroll
@@ -175,33 +184,41 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- park: [frame][channel] fp32 (lane = frame l31, registers = channels 8 q4 + 4 hi + e of the wave's 32)
+        // ---- the residual update IN the staged rows: x_2[frame][channel] = x_1 + gate ((acc + b) mask); lane = frame l31, registers =
+        // channels 8 q4 + 4 hi + e of the wave's 32 -- the residual rows (260-float pitch) double as the transposition stage
+        {
+            const float* gateT = (const float*)(slotp + kOwsAo + kOwsX);
+            const float m = hasmask ? ((const float*)(slotp + kOwsAo + kOwsX + 3 * 1024))[l31] : 1.0f;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-            *(float4*)(stage + l31 * 260 + wave * 32 + 8 * q4 + 4 * hi) = make_float4(acc[4 * q4 + 0], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c0 = wave * 32 + 8 * q4 + 4 * hi;
+                float* xp = (float*)(slotp + kOwsAo + l31 * kOwsXPitch) + c0;
+                const float4 xin = *(const float4*)xp;
+                const float4 gt = *(const float4*)(gateT + c0);
+                float4 v;
+                v.x = xin.x + gt.x * ((acc[4 * q4 + 0] + bias4[q4].x) * m); v.y = xin.y + gt.y * ((acc[4 * q4 + 1] + bias4[q4].y) * m);
+                v.z = xin.z + gt.z * ((acc[4 * q4 + 2] + bias4[q4].z) * m); v.w = xin.w + gt.w * ((acc[4 * q4 + 3] + bias4[q4].w) * m);
+                *(float4*)xp = v;
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         ST_RAW_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- row walk: rows 4 w .. 4 w + 3 of the tile, lane = channels 4 lane .. + 3 (g2_rows: EPI_RESGATE + LayerNorm branch)
+        // ---- row walk: rows 4 w .. 4 w + 3 of the tile, lane = channels 4 lane .. + 3 (g2_rows: the LayerNorm branch of EPI_RESGATE)
         {
-            const unsigned char* cst = smem + slot * kOwsSlot + kOwsAo + kOwsX;
-            const float4 gate = *(const float4*)(cst + lane * 16);
+            const unsigned char* cst = slotp + kOwsAo + kOwsX;
             const float4 sh = *(const float4*)(cst + 1024 + lane * 16);
             const float4 sc = *(const float4*)(cst + 2048 + lane * 16);
             const int tlim = tlimT[(ncur - first) / L];
-            const float* mtile = (const float*)(cst + 3 * 1024);      // the tile's 32 mask values (zeros when there is no mask: see below)
+            const float* mtile = (const float*)(cst + 3 * 1024);
             float4 v[4]; float m[4]; bool ok[4]; int tt[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = wave * 4 + u;
-                const int t = t0 + r;
-                tt[u] = t; ok[u] = t < tlim;
+                tt[u] = t0 + r; ok[u] = t0 + r < tlim;
                 m[u] = hasmask ? mtile[r] : 1.0f;
-                const float4 a = *(const float4*)(stage + r * 260 + ch);
-                const float4 xin = *(const float4*)(smem + slot * kOwsSlot + kOwsAo + r * 1024 + lane * 16);
-                v[u].x = xin.x + gate.x * ((a.x + bias4.x) * m[u]); v[u].y = xin.y + gate.y * ((a.y + bias4.y) * m[u]);
-                v[u].z = xin.z + gate.z * ((a.z + bias4.z) * m[u]); v[u].w = xin.w + gate.w * ((a.w + bias4.w) * m[u]);
+                v[u] = *(const float4*)(slotp + kOwsAo + r * kOwsXPitch + lane * 16);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -227,8 +244,8 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
             }
         }
         if (n1 >= g.n_items) break;
-        ncur = n1; n1 = pop_item();
-        slot ^= 1;
+        ncur = n1; n1 = n2; n2 = pop_item();
+        if (++slot == kOwsRing) slot = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA piece may land after the block has given its LDS back
 }
