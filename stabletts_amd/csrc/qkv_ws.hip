@@ -38,8 +38,10 @@
 namespace st {
 
 constexpr int kQwsTile = 64 * 512, kQwsRing = 2, kQwsPitch = 144, kQwsImage = 256 * kQwsPitch;      // 32,768 / 36,864 B
-constexpr int kQwsRope = 2 * 64 * 16 * 4;                                                              // cos, sin rows of the block's 64 frames
-constexpr int kQwsLds = kQwsRing * kQwsTile + 2 * kQwsImage + kQwsRope;                                // 147,456 B
+// cos, sin rows of the block's 64 frames, 16 floats each at a pitch of 20: with 16 the epilogue's float4 reads (lane = frame) are
+// 4-way bank conflicts (16 instead of 4 LDS cycles per ds_read_b128; SQ_LDS_BANK_CONFLICT exceeded the kernel's busy LDS cycles)
+constexpr int kQwsRopePitch = 20, kQwsRope = 2 * 64 * kQwsRopePitch * 4;
+constexpr int kQwsLds = kQwsRing * kQwsTile + 2 * kQwsImage + kQwsRope;                                // 149,504 B
 
 #define ST_RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -140,7 +142,7 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
         const int fl = (tid & 255) >> 2, q = tid & 3;
         const int tl = t0 + fl < T ? t0 + fl : T - 1;
         const float4 v = *(const float4*)((tid < 256 ? g.rope_cos : g.rope_sin) + (size_t)tl * 16 + 4 * q);
-        *(float4*)(ropeT + (tid < 256 ? 0 : 1024) + fl * 16 + 4 * q) = v;
+        *(float4*)(ropeT + (tid < 256 ? 0 : 64 * kQwsRopePitch) + fl * kQwsRopePitch + 4 * q) = v;
     }
     const float sc = plane == 0 ? g.qscale : 1.0f;
     // B-fragment offsets inside a chunk image (row = frame l31 of fragment 0; fragment 1 = + 32 rows: same swizzle term)
@@ -266,8 +268,8 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
                 if (rope) {
 #pragma unroll
                     for (int q4 = 0; q4 < 2; ++q4) {
-                        const float4 cs = *(const float4*)(ropeT + fl * 16 + 8 * q4 + 4 * hi);
-                        const float4 sn = *(const float4*)(ropeT + 1024 + fl * 16 + 8 * q4 + 4 * hi);
+                        const float4 cs = *(const float4*)(ropeT + fl * kQwsRopePitch + 8 * q4 + 4 * hi);
+                        const float4 sn = *(const float4*)(ropeT + 64 * kQwsRopePitch + fl * kQwsRopePitch + 8 * q4 + 4 * hi);
                         const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -328,8 +330,8 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
 // lock step; two independent blocks on a CU put one block's vector / store phases beside the other's MFMAs.  Per tile and wave:
 // 4 LDS-DMA pieces, 16 fragment reads (0.5 per MFMA), 32 MFMAs, 4 row stores -- the same counted-wait protocol.  Every wave now
 // carries the same share of the RoPE arithmetic (dims 0..31 of ITS head).
-constexpr int kQws4Tile = 32 * 512, kQws4Image = 256 * 80, kQws4Rope = 2 * 32 * 16 * 4;
-constexpr int kQws4Lds = 2 * kQws4Tile + 2 * kQws4Image + kQws4Rope + 1024;      // 78,848 B (+ the plane's bias)
+constexpr int kQws4Tile = 32 * 512, kQws4Image = 256 * 80, kQws4Rope = 2 * 32 * kQwsRopePitch * 4;
+constexpr int kQws4Lds = 2 * kQws4Tile + 2 * kQws4Image + kQws4Rope + 1024;      // 79,872 B (+ the plane's bias); two blocks = 159,744 B
 
 template <class P, int VAR>
 __global__ __launch_bounds__(256, 2)
@@ -407,7 +409,7 @@ void qkv_ws4_kernel(const ConvGemmArgs g, int L) {
         const int fl = (tid & 127) >> 2, q = tid & 3;
         const int tl = t0 + fl < T ? t0 + fl : T - 1;
         const float4 v = *(const float4*)((tid < 128 ? g.rope_cos : g.rope_sin) + (size_t)tl * 16 + 4 * q);
-        *(float4*)(ropeT + (tid < 128 ? 0 : 512) + fl * 16 + 4 * q) = v;
+        *(float4*)(ropeT + (tid < 128 ? 0 : 32 * kQwsRopePitch) + fl * kQwsRopePitch + 4 * q) = v;
     }
     const float sc = plane == 0 ? g.qscale : 1.0f;
     unsigned radr[4];
@@ -511,8 +513,8 @@ void qkv_ws4_kernel(const ConvGemmArgs g, int L) {
         if constexpr (!V) {      // q / k: image [head][frame][64] (pitch 144 B); the wave's head, fragment a = dims 32 a .. + 32
 #pragma unroll
             for (int q4 = 0; q4 < 2; ++q4) {      // RoPE in place on fragment 0 (dims 0..31 of the wave's head)
-                const float4 cs = *(const float4*)(ropeT + l31 * 16 + 8 * q4 + 4 * hi);
-                const float4 sn = *(const float4*)(ropeT + 512 + l31 * 16 + 8 * q4 + 4 * hi);
+                const float4 cs = *(const float4*)(ropeT + l31 * kQwsRopePitch + 8 * q4 + 4 * hi);
+                const float4 sn = *(const float4*)(ropeT + 32 * kQwsRopePitch + l31 * kQwsRopePitch + 8 * q4 + 4 * hi);
                 const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
