@@ -190,7 +190,8 @@ def test_weight_stationary_qkv_is_bit_identical_to_the_generic_tile(sd, cfg_para
     old = _fresh(sd, monkeypatch, dtype, ST_QKV_WS="0", ST_SMALL_GRID="0")
     new = _fresh(sd, monkeypatch, dtype, ST_QKV_WS="1", ST_QKV_WS_MIN_TILES="1", ST_SMALL_GRID="0")
     cases = [(2, 64, [64, 33]), (1, 65, [65]), (3, 253, [253, 252, 1]), (2, 700, [700, 255]), (4, 1000, [1000, 873, 640, 377]),
-             (9, 130, [130, 7, 129, 64, 65, 1, 128, 100, 130]), (32, 1000, None)]
+             (9, 130, [130, 7, 129, 64, 65, 1, 128, 100, 130]), (32, 1000, None),
+             (65, 2000, None)]      # 130 items > 64 x the list stride the grid rule would pick: stride from the 64-bit mask, grid > 256 blocks
     for B, T, lengths in cases:
         inp = make_inputs(B, T, seed=40 + T, lengths=lengths) if lengths else make_inputs(B, T, seed=0, ragged=True)
         ref = _solve(old, inp, 2, "euler", kw)
@@ -226,7 +227,8 @@ def test_weight_stationary_out_projection_is_bit_identical_to_the_generic_tile(s
     old = _fresh(sd, monkeypatch, dtype, ST_OPROJ_WS="0", ST_SMALL_GRID="0")
     new = _fresh(sd, monkeypatch, dtype, ST_OPROJ_WS="1", ST_OPROJ_WS_MIN_TILES="1", ST_SMALL_GRID="0")
     cases = [(2, 64, [64, 33]), (1, 65, [65]), (3, 253, [253, 252, 1]), (2, 700, [700, 255]), (4, 1000, [1000, 873, 640, 377]),
-             (9, 130, [130, 7, 129, 64, 65, 1, 128, 100, 130]), (32, 1000, None)]
+             (9, 130, [130, 7, 129, 64, 65, 1, 128, 100, 130]), (32, 1000, None),
+             (65, 2000, None)]      # 130 items > 64 x the list stride the grid rule would pick: stride from the 64-bit mask, grid > 256 blocks
     for B, T, lengths in cases:
         inp = make_inputs(B, T, seed=40 + T, lengths=lengths) if lengths else make_inputs(B, T, seed=0, ragged=True)
         ref = _solve(old, inp, 2, "euler", kw)
