@@ -1,0 +1,265 @@
+// PROTOTYPE (developer tool, not part of the library): the fused FFN on Winograd F(2,3) along the frame axis, f16 operands only.
+// See DESIGN.md section 7 ("A work reduction that the parity bar admits") for why and for the budgets; wino_loop.hip for the inner loop.
+//
+// Block = 8 waves, one tile of 126 output frames of one item (128 u rows, 130 h rows: the shipped kernel's geometry).  Differences:
+//   * areas hold RAW rows in the pair-interleaved layout (row r -> storage row 2q + (e ^ (q & 1)), slot c ^ ((q >> 1) & 7), q = r >> 1,
+//     e = r & 1); a wave forms the four transformed B fragments of a frame PAIR (rows 2i .. 2i + 3) with 16 v_pk_add_f16;
+//   * wave w owns 32 channels (conv_1: hidden channels 32 w .. of the chunk, conv_2: output channels 32 w ..) x ALL 64 pairs: every
+//     weight fragment is read by exactly one wave, so each wave keeps a PRIVATE ring of 9 fragments (3 k-steps x planes U0, U1, U3; the
+//     fourth plane U2 = U0 + U3 - U1 is formed in registers) filled by its own LDS-DMA, 3 k-steps ahead, counted with its own vmcnt --
+//     no barrier belongs to the weight stream.  Barriers remain every 4 k-steps (hand-over of the areas between h and u);
+//   * per k-step and wave: 3 A + 8 B fragment reads, 40 packed adds, 8 MFMAs (direct: 12 reads, 12 MFMAs), 4 LDS-DMA pieces issued
+//     (3 weight fragments of k-step + 3, 1 h piece or a padding piece -> sink), `s_waitcnt vmcnt(9)` at the top;
+//   * accumulators: M[4 products][2 pair fragments] (128 registers, conv_1 then conv_2 of a chunk) + Y (64, conv_2's outputs).
+// Weight stream: [chunk][stage][k-step][wave][plane] 1-KiB fragments (lane-linear), see pack_wino_stream() in ffn_wino_bench.hip.
+#pragma once
+#include "../../stabletts_amd/csrc/ffn_fused.h"
+
+namespace st {
+
+constexpr int kWnRingW = 9 * 1024;
+constexpr int kWnOffRing = 4 * kFfnArea, kWnOffBias = kWnOffRing + 8 * kWnRingW, kWnOffSink = kWnOffBias + 8192;
+constexpr int kWnOffTab = kWnOffSink + 1024;        // per-thread h-piece source offsets [3][512] (0xFFFFFFFF = outside [0, T)) + the tile's 128 u-row mask values
+constexpr int kWnLds = kWnOffTab + 3 * 512 * 4 + 512;      // 159,232 B
+
+typedef _Float16 wn_h2 __attribute__((ext_vector_type(2)));
+struct WnFrag { wn_h2 v[4]; };
+__device__ __forceinline__ WnFrag wn_frag(uint4 u) { return __builtin_bit_cast(WnFrag, u); }
+__device__ __forceinline__ f16x8_t wn_v8(WnFrag f) { return __builtin_bit_cast(f16x8_t, f); }
+__device__ __forceinline__ WnFrag wn_sub(WnFrag a, WnFrag b) { WnFrag r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] - b.v[i]; return r; }
+__device__ __forceinline__ WnFrag wn_add(WnFrag a, WnFrag b) { WnFrag r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+
+template <int ABL> __device__ __forceinline__ f32x16_t wn_mma(f16x8_t a, f16x8_t b, f32x16_t c) {
+    if constexpr (ABL & 16) { asm volatile("" :: "v"(a), "v"(b)); return c; } else return OpF16::mfma(a, b, c);
+}
+
+// ABL (ablations, results garbage): 1 = no epilogue, 2 = no LDS-DMA inside the k-steps, 4 = no barriers after the k-step groups,
+// 8 = no output transform / SiLU step, 16 = no MFMAs, 32 = no top-of-step wait
+template <int ABL>
+__global__ __launch_bounds__(512, 1)
+void ffn_wino_kernel(const ConvGemmArgs g) {
+    using P = OpF16;
+    constexpr int FV = kFfnFusedFrames, AREA = kFfnArea;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int T = g.T;
+    const int nchunks = g.cmid >> 8, nsteps = nchunks * 32;
+
+    const int total = g.n_items * g.tiles_f;
+    const int per_xcd = gridDim.x >> 3;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    const int tf = lin % g.tiles_f, n = lin / g.tiles_f;
+    const int t0 = tf * FV;
+    if (g.t_lim && t0 >= g.t_lim[n % g.t_lim_mod]) return;
+
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)smem);
+    const unsigned char* h_s = sgpr_ptr64((const unsigned char*)g.a0 + (size_t)(n % g.a0_mod) * T * 512);
+    const unsigned char* w_s = sgpr_ptr64(g.w);
+    const unsigned char* zeros = (const unsigned char*)g.zeros;
+
+    // h pieces of this wave: storage rows 8 pi .. + 8 of an area, pi = wave, wave + 8 and 16 (piece 16 by every wave: same bytes); the
+    // per-lane source offsets live in LDS (three registers otherwise -- the loop has none to spare)
+    unsigned* htab = (unsigned*)(smem + kWnOffTab);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pi = (k < 2) ? wave + 8 * k : 16;
+        const int srow = pi * 8 + (lane >> 3), slot = lane & 7;
+        const int q = srow >> 1, e = (srow & 1) ^ (q & 1), r = 2 * q + e, c = slot ^ ((q >> 1) & 7);
+        const int t = t0 - 2 + r;
+        htab[k * 512 + tid] = (t >= 0 && t < T) ? (unsigned)(t * 512 + c * 16) : 0xFFFFFFFFu;
+    }
+    const unsigned voffL = (unsigned)lane * 16u;
+    unsigned bbase[4];      // raw row 2 i + e of pair i = l31 (pair fragment 1: + 8192), k-step ks of an area: ^ (ks << 5), area: + a * AREA
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = l31 + (e >> 1), e1 = e & 1;
+        const int srow = 2 * q + (e1 ^ (q & 1)), gsw = hi ^ ((q >> 1) & 7);
+        bbase[e] = lds0 + (unsigned)(srow * 128 + (gsw << 4));
+        asm volatile("" : "+v"(bbase[e]));
+    }
+    const unsigned ringb = lds0 + (unsigned)(kWnOffRing + wave * kWnRingW) + voffL;
+    float* mkT = (float*)(smem + kWnOffTab + 3 * 512 * 4);      // mask of u row r (frame t0 - 1 + r), 0 outside [0, T)
+    if (tid < 128) {
+        const float* mrow = g.mask ? g.mask + (size_t)(n % g.mask_mod) * T : nullptr;
+        const int t = t0 - 1 + tid;
+        const bool in = (t >= 0 && t < T);
+        const float mv = mrow ? mrow[in ? t : 0] : 1.0f;
+        mkT[tid] = in ? mv : 0.0f;
+    }
+
+    auto issueH = [&](int area, int k) {
+        const unsigned dst = lds0 + (unsigned)(area * AREA + ((k < 2) ? wave + 8 * k : 16) * 1024);
+        int tidh = threadIdx.x; asm volatile("" : "+v"(tidh));
+        const unsigned vo = htab[k * 512 + tidh];
+        glds16bo(vo != 0xFFFFFFFFu ? h_s + area * 128 + vo : zeros, dst);
+    };
+    auto issueDummy = [&]() { glds16bo(zeros, lds0 + (unsigned)kWnOffSink); };
+    unsigned soff = 0;      // ring offset of the k-step being read = the one the k-step + 3 is issued into
+    int gs = 0;             // global k-step index
+    auto issueW = [&]() {
+        if (gs + 3 < nsteps) {
+            const unsigned char* sb = w_s + (size_t)(gs + 3) * 24576 + (size_t)wave * 3072;
+            const unsigned d = lds0 + (unsigned)(kWnOffRing + wave * kWnRingW) + soff;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) glds16o(sb + p * 1024, voffL, d + p * 1024);
+        } else {
+            issueDummy(); issueDummy(); issueDummy();
+        }
+    };
+
+    // ---- prologue: h chunks 0..2, the weight fragments of k-steps 0..2, conv_1 bias
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) issueH(a, k);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const unsigned char* sb = w_s + (size_t)s3 * 24576 + (size_t)wave * 3072;
+        const unsigned d = lds0 + (unsigned)(kWnOffRing + wave * kWnRingW + s3 * 3072);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) glds16o(sb + p * 1024, voffL, d + p * 1024);
+    }
+    if (wave < (g.cmid >> 8)) glds16o(sgpr_ptr64(g.bias1) + (size_t)wave * 1024, voffL, lds0 + (unsigned)kWnOffBias + (unsigned)wave * 1024u);
+    ST_DMA_WAIT(0);
+    __syncthreads();
+
+    f32x16_t M[4][2], Y[2][2];
+#pragma unroll
+    for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[e2][b][r] = 0.0f;
+
+    // one k-step: AR = area, KS = k-step inside the area (compile-time), aux = this k-step's fourth LDS-DMA piece
+#define WN_STEP(AR, KS, AUX)                                                                                         \
+    {                                                                                                                \
+        if constexpr (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("" ::: "memory"); \
+        const unsigned wad = ringb + soff;                                                                           \
+        const WnFrag U0 = wn_frag(lds_read16(wad)), U1 = wn_frag(lds_read16(wad + 1024)), U3 = wn_frag(lds_read16(wad + 2048)); \
+        WnFrag d[4];                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = wn_frag(lds_read16((bbase[e] ^ (unsigned)((KS) << 5)) + (AR) * AREA)); \
+        const WnFrag U2 = wn_sub(wn_add(U0, U3), U1);                                                                \
+        {                                                                                                            \
+            const WnFrag V0 = wn_sub(d[0], d[2]), V1 = wn_add(d[1], d[2]), V2 = wn_sub(d[2], d[1]), V3 = wn_sub(d[1], d[3]); \
+            M[0][0] = wn_mma<ABL>(wn_v8(U0), wn_v8(V0), M[0][0]);                                                        \
+            M[1][0] = wn_mma<ABL>(wn_v8(U1), wn_v8(V1), M[1][0]);                                                        \
+            M[2][0] = wn_mma<ABL>(wn_v8(U2), wn_v8(V2), M[2][0]);                                                        \
+            M[3][0] = wn_mma<ABL>(wn_v8(U3), wn_v8(V3), M[3][0]);                                                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = wn_frag(lds_read16((bbase[e] ^ (unsigned)((KS) << 5)) + (AR) * AREA + 8192)); \
+        /* the ring slot's fragments are in registers (they fed the MFMAs above): k-step + 3 may land in it */       \
+        if constexpr (!(ABL & 2)) { issueW(); AUX; }                                                                 \
+        {                                                                                                            \
+            const WnFrag V0 = wn_sub(d[0], d[2]), V1 = wn_add(d[1], d[2]), V2 = wn_sub(d[2], d[1]), V3 = wn_sub(d[1], d[3]); \
+            M[0][1] = wn_mma<ABL>(wn_v8(U0), wn_v8(V0), M[0][1]);                                                        \
+            M[1][1] = wn_mma<ABL>(wn_v8(U1), wn_v8(V1), M[1][1]);                                                        \
+            M[2][1] = wn_mma<ABL>(wn_v8(U2), wn_v8(V2), M[2][1]);                                                        \
+            M[3][1] = wn_mma<ABL>(wn_v8(U3), wn_v8(V3), M[3][1]);                                                        \
+        }                                                                                                            \
+        soff += 3072; if (soff == 9216) soff = 0;                                                                    \
+        gs += 1;                                                                                                     \
+    }
+#define WN_BARRIER() { if constexpr (!(ABL & 4)) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } }
+
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const bool lastc = (c + 1 == nchunks);
+        // ---- conv_1: M1 starts from the bias (it enters both outputs of a pair once), the other products from zero
+        int tidb = threadIdx.x; asm volatile("" : "+v"(tidb));      // lane-derived values are re-derived where they are used: kept live
+        const int hib = (tidb >> 5) & 1;                              // across the k-steps they cost scratch (and scratch loads count in vmcnt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 bv = *(const float4*)(smem + kWnOffBias + (c * 256 + wave * 32 + 8 * q4 + 4 * hib) * 4);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                M[1][b][4 * q4 + 0] = bv.x; M[1][b][4 * q4 + 1] = bv.y; M[1][b][4 * q4 + 2] = bv.z; M[1][b][4 * q4 + 3] = bv.w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { M[0][b][4 * q4 + e] = 0.0f; M[2][b][4 * q4 + e] = 0.0f; M[3][b][4 * q4 + e] = 0.0f; }
+            }
+        }
+        WN_STEP(0, 0, issueH(3, 0)) WN_STEP(0, 1, issueH(3, 1)) WN_STEP(0, 2, issueH(3, 2)) WN_STEP(0, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(1, 0, issueDummy()) WN_STEP(1, 1, issueDummy()) WN_STEP(1, 2, issueDummy()) WN_STEP(1, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(2, 0, issueDummy()) WN_STEP(2, 1, issueDummy()) WN_STEP(2, 2, issueDummy()) WN_STEP(2, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(3, 0, issueDummy()) WN_STEP(3, 1, issueDummy()) WN_STEP(3, 2, issueDummy()) WN_STEP(3, 3, issueDummy()) WN_BARRIER()
+        // ---- every wave is done with h: output transform, SiLU, mask, 16-bit rounding -> u rows 2 i, 2 i + 1 of area wave >> 1
+        if constexpr (!(ABL & 8)) {
+        int tids = threadIdx.x; asm volatile("" : "+v"(tids));
+        const int l31s = tids & 31, his = (tids >> 5) & 1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int i = b * 32 + l31s;
+            const unsigned usw = (unsigned)((i >> 1) & 7);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const unsigned rowb = lds0 + (unsigned)((wave >> 1) * AREA + (2 * i + (e2 ^ (i & 1))) * 128 + his * 8);
+                const float m = mkT[2 * i + e2];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q4 + e;
+                        const float v = e2 == 0 ? (M[0][b][r] + M[1][b][r]) + M[2][b][r] : (M[1][b][r] - M[2][b][r]) - M[3][b][r];
+                        y[e] = silu_fast(v) * m;
+                    }
+                    const uint2 pv = pack4<P>(y[0], y[1], y[2], y[3]);
+                    const unsigned addr = rowb + ((((unsigned)((wave & 1) * 4 + q4)) ^ usw) << 4);
+                    typedef unsigned __attribute__((ext_vector_type(2))) u32x2_raw;
+                    *(__attribute__((address_space(3))) u32x2_raw*)(uintptr_t)addr = u32x2_raw{pv.x, pv.y};
+                }
+            }
+        }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WN_BARRIER()
+        // ---- conv_2 of this chunk's 256 channels; the areas it has finished with are refilled with h for the next chunk
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) M[p][b][r] = 0.0f;
+#define WN_REFILL(A, K) { if (!lastc) issueH(A, K); else issueDummy(); }
+        WN_STEP(0, 0, issueDummy()) WN_STEP(0, 1, issueDummy()) WN_STEP(0, 2, issueDummy()) WN_STEP(0, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(1, 0, WN_REFILL(0, 0)) WN_STEP(1, 1, WN_REFILL(0, 1)) WN_STEP(1, 2, WN_REFILL(0, 2)) WN_STEP(1, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(2, 0, WN_REFILL(1, 0)) WN_STEP(2, 1, WN_REFILL(1, 1)) WN_STEP(2, 2, WN_REFILL(1, 2)) WN_STEP(2, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(3, 0, WN_REFILL(2, 0)) WN_STEP(3, 1, WN_REFILL(2, 1)) WN_STEP(3, 2, WN_REFILL(2, 2)) WN_STEP(3, 3, issueDummy()) WN_BARRIER()
+#undef WN_REFILL
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Y[0][b][r] += (M[0][b][r] + M[1][b][r]) + M[2][b][r];
+                Y[1][b][r] += (M[1][b][r] - M[2][b][r]) - M[3][b][r];
+            }
+    }
+#undef WN_STEP
+#undef WN_BARRIER
+    ST_DMA_WAIT(0);
+    __syncthreads();
+    if constexpr (ABL & 1) {
+        asm volatile("" :: "v"(Y[0][0]), "v"(Y[0][1]), "v"(Y[1][0]), "v"(Y[1][1]));
+        return;
+    }
+    float* stage = (float*)smem;
+    int tide = threadIdx.x; asm volatile("" : "+v"(tide));
+    const int l31e = tide & 31, hie = (tide >> 5) & 1, lanee = tide & 63;
+    g2_epilogue_core<P, EPI_RESGATE, 256, 128, 8, 1>([&](int fbase) {
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int fl = fbase + 2 * (b * 32 + l31e) + e2;
+                    const int ch = wave * 32 + 8 * q4 + 4 * hie;
+                    *(float4*)(stage + fl * 260 + ch) = make_float4(Y[e2][b][4 * q4 + 0], Y[e2][b][4 * q4 + 1], Y[e2][b][4 * q4 + 2], Y[e2][b][4 * q4 + 3]);
+                }
+    }, stage, g, n, t0, FV, 0, wave, lanee);
+}
+
+}  // namespace st
