@@ -29,6 +29,23 @@ __device__ __forceinline__ f16x8_t wn_v8(WnFrag f) { return __builtin_bit_cast(f
 __device__ __forceinline__ WnFrag wn_sub(WnFrag a, WnFrag b) { WnFrag r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] - b.v[i]; return r; }
 __device__ __forceinline__ WnFrag wn_add(WnFrag a, WnFrag b) { WnFrag r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
 
+// fourth LDS-DMA piece of k-step position q of a chunk (0..15 conv_1, 16..31 conv_2): an h piece in conv_1's first three k-steps
+// (area 3) and, unless this is the last chunk, in k-steps 1..3 of conv_2's sub-chunks 1..3 (the next chunk's areas 0..2)
+constexpr int wn_aux(int q, bool last) { return q < 16 ? (q < 3) : (!last && (q - 16) >= 4 && ((q - 16) & 3) < 3); }
+// pieces that may stay outstanding at the top of position p: everything issued after the weight fragments of k-step p (3 k-steps earlier)
+constexpr int wn_allowed(int p, bool last) {
+    int n = 6;
+    for (int k = 1; k <= 3; ++k) { const int q = p - k; n += q >= 0 ? wn_aux(q, last) : wn_aux(q + 32, false); }
+    return n;
+}
+template <int N> __device__ __forceinline__ void wn_wait() {
+    static_assert(N >= 6 && N <= 9, "vmcnt immediate");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+}
+
 template <int ABL> __device__ __forceinline__ f32x16_t wn_mma(f16x8_t a, f16x8_t b, f32x16_t c) {
     if constexpr (ABL & 16) { asm volatile("" :: "v"(a), "v"(b)); return c; } else return OpF16::mfma(a, b, c);
 }
@@ -135,31 +152,23 @@ void ffn_wino_kernel(const ConvGemmArgs g) {
             for (int r = 0; r < 16; ++r) Y[e2][b][r] = 0.0f;
 
     // one k-step: AR = area, KS = k-step inside the area (compile-time), aux = this k-step's fourth LDS-DMA piece
-#define WN_STEP(AR, KS, AUX)                                                                                         \
+#define WN_STEP(AR, KS, POS, AUX)                                                                                    \
     {                                                                                                                \
-        if constexpr (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("" ::: "memory"); \
+        if constexpr (!(ABL & 32)) { if (lastc) wn_wait<wn_allowed((POS), true)>(); else wn_wait<wn_allowed((POS), false)>(); } else asm volatile("" ::: "memory"); \
         const unsigned wad = ringb + soff;                                                                           \
         const WnFrag U0 = wn_frag(lds_read16(wad)), U1 = wn_frag(lds_read16(wad + 1024)), U3 = wn_frag(lds_read16(wad + 2048)); \
-        WnFrag d[4];                                                                                                 \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = wn_frag(lds_read16((bbase[e] ^ (unsigned)((KS) << 5)) + (AR) * AREA)); \
         const WnFrag U2 = wn_sub(wn_add(U0, U3), U1);                                                                \
-        {                                                                                                            \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                              \
+            WnFrag d[4];                                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = wn_frag(lds_read16((bbase[e] ^ (unsigned)((KS) << 5)) + (AR) * AREA + b * 8192)); \
             const WnFrag V0 = wn_sub(d[0], d[2]), V1 = wn_add(d[1], d[2]), V2 = wn_sub(d[2], d[1]), V3 = wn_sub(d[1], d[3]); \
-            M[0][0] = wn_mma<ABL>(wn_v8(U0), wn_v8(V0), M[0][0]);                                                        \
-            M[1][0] = wn_mma<ABL>(wn_v8(U1), wn_v8(V1), M[1][0]);                                                        \
-            M[2][0] = wn_mma<ABL>(wn_v8(U2), wn_v8(V2), M[2][0]);                                                        \
-            M[3][0] = wn_mma<ABL>(wn_v8(U3), wn_v8(V3), M[3][0]);                                                        \
+            M[0][b] = wn_mma<ABL>(wn_v8(U0), wn_v8(V0), M[0][b]);                                                    \
+            M[1][b] = wn_mma<ABL>(wn_v8(U1), wn_v8(V1), M[1][b]);                                                    \
+            M[2][b] = wn_mma<ABL>(wn_v8(U2), wn_v8(V2), M[2][b]);                                                    \
+            M[3][b] = wn_mma<ABL>(wn_v8(U3), wn_v8(V3), M[3][b]);                                                    \
         }                                                                                                            \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) d[e] = wn_frag(lds_read16((bbase[e] ^ (unsigned)((KS) << 5)) + (AR) * AREA + 8192)); \
         /* the ring slot's fragments are in registers (they fed the MFMAs above): k-step + 3 may land in it */       \
         if constexpr (!(ABL & 2)) { issueW(); AUX; }                                                                 \
-        {                                                                                                            \
-            const WnFrag V0 = wn_sub(d[0], d[2]), V1 = wn_add(d[1], d[2]), V2 = wn_sub(d[2], d[1]), V3 = wn_sub(d[1], d[3]); \
-            M[0][1] = wn_mma<ABL>(wn_v8(U0), wn_v8(V0), M[0][1]);                                                        \
-            M[1][1] = wn_mma<ABL>(wn_v8(U1), wn_v8(V1), M[1][1]);                                                        \
-            M[2][1] = wn_mma<ABL>(wn_v8(U2), wn_v8(V2), M[2][1]);                                                        \
-            M[3][1] = wn_mma<ABL>(wn_v8(U3), wn_v8(V3), M[3][1]);                                                        \
-        }                                                                                                            \
         soff += 3072; if (soff == 9216) soff = 0;                                                                    \
         gs += 1;                                                                                                     \
     }
@@ -181,10 +190,10 @@ void ffn_wino_kernel(const ConvGemmArgs g) {
                 for (int e = 0; e < 4; ++e) { M[0][b][4 * q4 + e] = 0.0f; M[2][b][4 * q4 + e] = 0.0f; M[3][b][4 * q4 + e] = 0.0f; }
             }
         }
-        WN_STEP(0, 0, issueH(3, 0)) WN_STEP(0, 1, issueH(3, 1)) WN_STEP(0, 2, issueH(3, 2)) WN_STEP(0, 3, issueDummy()) WN_BARRIER()
-        WN_STEP(1, 0, issueDummy()) WN_STEP(1, 1, issueDummy()) WN_STEP(1, 2, issueDummy()) WN_STEP(1, 3, issueDummy()) WN_BARRIER()
-        WN_STEP(2, 0, issueDummy()) WN_STEP(2, 1, issueDummy()) WN_STEP(2, 2, issueDummy()) WN_STEP(2, 3, issueDummy()) WN_BARRIER()
-        WN_STEP(3, 0, issueDummy()) WN_STEP(3, 1, issueDummy()) WN_STEP(3, 2, issueDummy()) WN_STEP(3, 3, issueDummy()) WN_BARRIER()
+        WN_STEP(0, 0, 0, issueH(3, 0)) WN_STEP(0, 1, 1, issueH(3, 1)) WN_STEP(0, 2, 2, issueH(3, 2)) WN_STEP(0, 3, 3, ) WN_BARRIER()
+        WN_STEP(1, 0, 4, ) WN_STEP(1, 1, 5, ) WN_STEP(1, 2, 6, ) WN_STEP(1, 3, 7, ) WN_BARRIER()
+        WN_STEP(2, 0, 8, ) WN_STEP(2, 1, 9, ) WN_STEP(2, 2, 10, ) WN_STEP(2, 3, 11, ) WN_BARRIER()
+        WN_STEP(3, 0, 12, ) WN_STEP(3, 1, 13, ) WN_STEP(3, 2, 14, ) WN_STEP(3, 3, 15, ) WN_BARRIER()
         // ---- every wave is done with h: output transform, SiLU, mask, 16-bit rounding -> u rows 2 i, 2 i + 1 of area wave >> 1
         if constexpr (!(ABL & 8)) {
         int tids = threadIdx.x; asm volatile("" : "+v"(tids));
@@ -223,11 +232,11 @@ void ffn_wino_kernel(const ConvGemmArgs g) {
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) M[p][b][r] = 0.0f;
-#define WN_REFILL(A, K) { if (!lastc) issueH(A, K); else issueDummy(); }
-        WN_STEP(0, 0, issueDummy()) WN_STEP(0, 1, issueDummy()) WN_STEP(0, 2, issueDummy()) WN_STEP(0, 3, issueDummy()) WN_BARRIER()
-        WN_STEP(1, 0, WN_REFILL(0, 0)) WN_STEP(1, 1, WN_REFILL(0, 1)) WN_STEP(1, 2, WN_REFILL(0, 2)) WN_STEP(1, 3, issueDummy()) WN_BARRIER()
-        WN_STEP(2, 0, WN_REFILL(1, 0)) WN_STEP(2, 1, WN_REFILL(1, 1)) WN_STEP(2, 2, WN_REFILL(1, 2)) WN_STEP(2, 3, issueDummy()) WN_BARRIER()
-        WN_STEP(3, 0, WN_REFILL(2, 0)) WN_STEP(3, 1, WN_REFILL(2, 1)) WN_STEP(3, 2, WN_REFILL(2, 2)) WN_STEP(3, 3, issueDummy()) WN_BARRIER()
+#define WN_REFILL(A, K) { if (!lastc) issueH(A, K); }
+        WN_STEP(0, 0, 16, ) WN_STEP(0, 1, 17, ) WN_STEP(0, 2, 18, ) WN_STEP(0, 3, 19, ) WN_BARRIER()
+        WN_STEP(1, 0, 20, WN_REFILL(0, 0)) WN_STEP(1, 1, 21, WN_REFILL(0, 1)) WN_STEP(1, 2, 22, WN_REFILL(0, 2)) WN_STEP(1, 3, 23, ) WN_BARRIER()
+        WN_STEP(2, 0, 24, WN_REFILL(1, 0)) WN_STEP(2, 1, 25, WN_REFILL(1, 1)) WN_STEP(2, 2, 26, WN_REFILL(1, 2)) WN_STEP(2, 3, 27, ) WN_BARRIER()
+        WN_STEP(3, 0, 28, WN_REFILL(2, 0)) WN_STEP(3, 1, 29, WN_REFILL(2, 1)) WN_STEP(3, 2, 30, WN_REFILL(2, 2)) WN_STEP(3, 3, 31, ) WN_BARRIER()
 #undef WN_REFILL
 #pragma unroll
         for (int b = 0; b < 2; ++b)
