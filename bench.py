@@ -159,12 +159,21 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
 # kernel that implements each profiled class on the default path (for the PMC traffic lookup)
 CLASS_KERNEL = {
     "ffn_conv1": "conv_gemm_phased3_kernel<st::Op{DT}, 0, false>",
-    "ffn_conv2": "ffn_fused_kernel<st::Op{DT}, 0, 0>",        # the whole FFN since round 4 (conv_1 + SiLU + conv_2 in one launch)
+    "ffn_conv2": "ffn_fused_kernel<st::Op{DT}, 0, 0>",        # the whole FFN since round 4 (conv_1 + SiLU + conv_2 in one launch); f16: CLASS_KERNEL_F16
     "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
     "attention": "attention_kernel<st::Op{DT}, false>",
     "qkv_rope": "qkv_ws_kernel<st::Op{DT}, 0>",               # weight-stationary persistent kernel (qkv_ws.hip)
     "out_proj": "oproj_ws_kernel<st::Op{DT}>",                # weight-stationary persistent kernel (oproj_ws.hip)
 }
+
+
+CLASS_KERNEL_F16 = {"ffn_conv2": "ffn_wino_kernel<0>"}       # f16 default: the fused FFN on Winograd F(2,3) (ffn_wino.h); ST_FUSED_FFN=1 = the direct kernel
+
+
+def class_kernel(cls, dtype):
+    if dtype != "bf16" and os.environ.get("ST_FUSED_FFN", "3") == "3" and cls in CLASS_KERNEL_F16:
+        return CLASS_KERNEL_F16[cls]
+    return CLASS_KERNEL.get(cls, "").replace("{DT}", "BF16" if dtype == "bf16" else "F16")
 
 
 def _pmc_table():
@@ -193,7 +202,7 @@ def pmc_traffic(cls, dtype):
     table, _ = _pmc_table()
     if table is None:
         return None
-    want = CLASS_KERNEL.get(cls, "").replace("{DT}", "BF16" if dtype == "bf16" else "F16")
+    want = class_kernel(cls, dtype)
     for name, v in table.items():
         if want and want in name and "fetch_bytes_per_launch" in v:
             return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
@@ -442,11 +451,14 @@ def main():
                          "valid_frames": valid_frames_total, "padded_T_this_rank": T_batch},
             "parity": "f16 operands (default, this line unless --dtype bf16) meet north_star's 1e-3 on the displacement metric and per "
                       "evaluation (tests/test_gpu_parity.py, gates 7e-4); bf16 operands measure ~4e-3 (other_dtype)",
-            "roofline": {"bound": "mfma", "kernel": (CLASS_KERNEL.get(dom, "conv_gemm2_kernel").replace("{DT}", "BF16" if args.dtype == "bf16" else "F16") + f" [{dom}]"), "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ((class_kernel(dom, args.dtype) or "conv_gemm2_kernel") + f" [{dom}]"), "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic(dom, args.dtype), "traffic_unit": "HBM bytes per launch (PMC)",
                          "launches_sampled": p["launches"], "sample_stride": PROFILE_STRIDE, "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": p["flops_per_launch"],
+                         **({"flops_note": "algorithmic = the direct convolutions' multiply-adds (SURVEY 8d); ffn_wino_kernel executes 2/3 of them as MFMAs "
+                                           "(Winograd F(2,3) along the frame axis, DESIGN.md section 4): its matrix-pipe utilisation is 2/3 of frac"}
+                            if "ffn_wino" in class_kernel(dom, args.dtype) else {}),
                          "sampled_over": f"{args.steps} single-sequence solves (ST_SPLIT=1, {single_seq_ms:.2f} ms each) run right after "
                                          "the timed region, whose concurrent part sequences (two streams by default) would fold the other parts' kernels "
                                          "into a launch's event-bracketed duration"},

@@ -265,6 +265,24 @@ __host__ __device__ __forceinline__ void ffn_stream_index(size_t idx, int stage,
     *dst_off = (size_t)c * (48u * 8192u) + (size_t)((stage & 1) * 24 + sl) * 8192u + (idx & 8191);
 }
 
+// Weight stream of the Winograd F(2,3) fused FFN (ffn_wino.h): element idx of stage `stage` (0 = conv_1 (F, 256, 3), 1 = conv_2 (256, F, 3))
+// -> offset of tap 0 of its (row, input channel) in the fp32 source, offset in the stream, plane (0: g0, 1: (g0 + g1 + g2) / 2, 2: g2).
+// Stream = [chunk][stage][k-step 16][wave 8][plane 3] fragments of 512 elements, lane-linear: lane (l31, hi) holds row 32 wave + l31,
+// k slots 16 k-step + 8 hi .. + 8.
+__host__ __device__ __forceinline__ void ffn_wino_index(size_t idx, int stage, int F, size_t* src_off, size_t* dst_off, int* plane) {
+    const int e = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
+    size_t t = idx >> 9;
+    const int p = (int)(t % 3); t /= 3;
+    const int w8 = (int)(t & 7), k = (int)((t >> 3) & 15), c = (int)(t >> 7);
+    const int row = 32 * w8 + (ln & 31), kk = 16 * k + 8 * (ln >> 5) + e;
+    *src_off = stage == 0 ? ((size_t)(c * 256 + row) * 256 + kk) * 3 : ((size_t)row * F + c * 256 + kk) * 3;
+    *dst_off = (((((size_t)(c * 2 + stage) * 16 + k) * 8 + w8) * 3 + p) << 9) + (size_t)ln * 8 + e;
+    *plane = p;
+}
+__host__ __device__ __forceinline__ float ffn_wino_plane(const float* g3, int plane) {
+    return plane == 0 ? g3[0] : plane == 1 ? (g3[0] + g3[1] + g3[2]) * 0.5f : g3[2];
+}
+
 // Fragment-ordered copy of the fused q/k/v weight for qkv_ws.hip: element (output channel co of plane `plane`, input channel ci) ->
 // [plane][wave = co / 32][k-step = ci / 16][lane = (ci % 16 / 8) * 32 + co % 32][ci % 8]: a wave's 16 MFMA fragments are 16
 // consecutive 1-KiB pieces, lane-linear.

@@ -518,6 +518,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             else if (!cap) a.out32_readonly = 1;
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N) + (fused ? conv_flops(p, e->ffn1[i], N) : 0.0));
             if (e->skip_mask >> PC_FFN2 & 1) {}
+            else if (fused && e->fused_ffn == 3) HIPCHK(e, launch_ffn_wino_f16(a, s));
             else if (fused && e->fused_ffn == 2) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused16_bf16(a, s) : launch_ffn_fused16_f16(a, s));
             else if (fused) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused_bf16(a, s) : launch_ffn_fused_f16(a, s));
             else HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
@@ -962,6 +963,8 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
     if (const char* v = getenv("ST_FUSED_FFN")) e->fused_ffn = atoi(v);
+    if (e->fused_ffn < 0) e->fused_ffn = e->dt == DT_F16 ? 3 : 1;
+    if (e->fused_ffn == 3 && e->dt != DT_F16) e->fused_ffn = 1;      // the Winograd form forms its operands with packed f16 adds
     if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);
     if (const char* v = getenv("ST_SKIP_CLASSES")) e->skip_mask = (unsigned)strtoul(v, nullptr, 0);      // developer tool: results are garbage
     if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
@@ -1250,6 +1253,11 @@ int pack_all(st_engine* e, hipStream_t s) {
             if (!e->ffn_stream[i] && (rc = dev_alloc(e, &e->ffn_stream[i], (size_t)2 * F * C * K * 2))) return rc;
             for (int st = 0; st < 2; ++st) {
                 const float* src = P(e, b + (st ? "mlp.conv_2.weight" : "mlp.conv_1.weight"));
+                if (e->fused_ffn == 3) {      // ffn_wino.h: three transformed planes per tap triple
+                    HIPCHK(e, launch_pack_ffn_wino(src, st, F, e->ffn_stream[i], s));
+                    pk_push(PL, PackJob{src, e->ffn_stream[i], 5, F, 0, 0, 0, 0, 0, 0, 0, 0, st, 0u}, (size_t)F * C * K);
+                    continue;
+                }
                 const int stg = st | (e->fused_ffn == 2 ? 2 : 0);      // bit 1: fragments of the 16x16x32 kernel
                 HIPCHK(e, launch_pack_ffn_stream(e->dt, src, stg, F, e->ffn_stream[i], s));
                 pk_push(PL, PackJob{src, e->ffn_stream[i], 3, F, 0, 0, 0, 0, 0, 0, 0, 0, stg, 0u}, (size_t)F * C * K);

@@ -118,7 +118,9 @@ struct st_engine {
     int oproj_rc = 0;                   // out projection of big grids on row-complete 256 x 128 tiles (G2_RC) instead of 256 x 256 (ST_OPROJ_RC=1: A/B runs)
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
-    int fused_ffn = 1;                  // FFN of big grids as ONE kernel, the intermediate kept in LDS: 2 = on 16x16x32 MFMA fragments (ffn_fused16.h),
+    int fused_ffn = -1;                 // FFN of big grids as ONE kernel, the intermediate kept in LDS.  -1 = default: 3 with f16 operands, 1 with bf16.
+                                        // 3 = Winograd F(2,3) along the frames (ffn_wino.h; f16 only, NOT bit-identical to the others: rounded sums as
+                                        // operands, a third fewer MFMAs), 2 = on 16x16x32 MFMA fragments (ffn_fused16.h),
                                         // 1 = on 32x32x16 (ffn_fused.h, bit-identical to the two-kernel path), ST_FUSED_FFN=0: two kernels.  Read at st_create.
     int phased = 1;                     // k = 3 convs on 256-wide tiles use the phased K loop (conv_gemm_phased.h); ST_PHASED=0: A/B runs
     int splitk_max = kSplitKMax, splitk_min_stages = 4;

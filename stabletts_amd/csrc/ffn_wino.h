@@ -1,5 +1,7 @@
-// PROTOTYPE (developer tool, not part of the library): the fused FFN on Winograd F(2,3) along the frame axis, f16 operands only.
-// See DESIGN.md section 7 ("A work reduction that the parity bar admits") for why and for the budgets; wino_loop.hip for the inner loop.
+// The fused FFN (ffn_fused.h) on Winograd F(2,3) along the frame axis: two output frames from four input frames with 4 instead of 6
+// products per (cout, cin) -- a third fewer MFMAs in a power-limited loop.  f16 operands only (packed f16 adds form the transformed
+// operands); OPT-IN (ST_FUSED_FFN=3): results are NOT bit-identical to the direct kernels (rounded sums as operands: +0.2e-4 on the
+// one-evaluation error; tools/winograd_numerics.py, tools/micro/wino_loop.hip, tools/micro/ffn_wino_bench.hip).
 //
 // Block = 8 waves, one tile of 126 output frames of one item (128 u rows, 130 h rows: the shipped kernel's geometry).  Differences:
 //   * areas hold RAW rows in the pair-interleaved layout (row r -> storage row 2q + (e ^ (q & 1)), slot c ^ ((q >> 1) & 7), q = r >> 1,
@@ -11,9 +13,9 @@
 //   * per k-step and wave: 3 A + 8 B fragment reads, 40 packed adds, 8 MFMAs (direct: 12 reads, 12 MFMAs), 4 LDS-DMA pieces issued
 //     (3 weight fragments of k-step + 3, 1 h piece or a padding piece -> sink), `s_waitcnt vmcnt(9)` at the top;
 //   * accumulators: M[4 products][2 pair fragments] (128 registers, conv_1 then conv_2 of a chunk) + Y (64, conv_2's outputs).
-// Weight stream: [chunk][stage][k-step][wave][plane] 1-KiB fragments (lane-linear), see pack_wino_stream() in ffn_wino_bench.hip.
+// Weight stream: [chunk][stage][k-step][wave][plane U0, U1, U3] 1-KiB fragments, lane-linear (common.h: ffn_wino_index).
 #pragma once
-#include "../../stabletts_amd/csrc/ffn_fused.h"
+#include "ffn_fused.h"
 
 namespace st {
 
@@ -269,6 +271,26 @@ void ffn_wino_kernel(const ConvGemmArgs g) {
                     *(float4*)(stage + fl * 260 + ch) = make_float4(Y[e2][b][4 * q4 + 0], Y[e2][b][4 * q4 + 1], Y[e2][b][4 * q4 + 2], Y[e2][b][4 * q4 + 3]);
                 }
     }, stage, g, n, t0, FV, 0, wave, lanee);
+}
+
+static hipError_t launch_ffn_wino_impl(const ConvGemmArgs& a, hipStream_t s) {
+    static bool attr_done_dev[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+    if (!attr_done_dev[dev_]) {
+        hipError_t e = hipFuncSetAttribute((const void*)ffn_wino_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kWnLds);
+        if (e != hipSuccess) return e;
+        attr_done_dev[dev_] = true;
+    }
+    if (!a.zeros || !a.w || !a.bias1 || a.cout != 256 || a.c0 != 256 || a.c1 || a.c2 || (a.cmid & 255) || a.cmid < 256 || a.cmid > 2048 ||
+        a.ksplit > 1 || a.w_item_stride || a.branch32) return hipErrorInvalidValue;
+    ConvGemmArgs b = a;
+    b.tiles_f = (a.T + kFfnFusedFrames - 1) / kFfnFusedFrames;
+    b.tiles_c = 1;
+    const int total = b.n_items * b.tiles_f;
+    const int grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL((ffn_wino_kernel<0>), dim3(grid), dim3(512), kWnLds, s, b);
+    return hipGetLastError();
 }
 
 }  // namespace st

@@ -92,6 +92,8 @@ hipError_t launch_ffn_fused16_f16(const ConvGemmArgs& a, hipStream_t s);
 // A-fragments of 1 KiB stored lane-linear (fragment (ksl, a8): rows a8*32.., k-step 2*kp+ksl).  stage 0: src = conv_1 weight
 // (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).  stage | 2: the 16x16x32 kernel's fragments (common.h: ffn_stream_index).
 hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F, void* dst, hipStream_t s);
+hipError_t launch_pack_ffn_wino(const float* src, int stage, int F, void* dst, hipStream_t s);      // ffn_wino.h's stream (f16)
+hipError_t launch_ffn_wino_f16(const ConvGemmArgs& a, hipStream_t s);                                   // Winograd F(2,3) fused FFN, f16 operands only
 // Fused q / k / v projection + RoPE of big grids as a weight-stationary persistent kernel (qkv_ws.hip): same arguments and results
 // (bit for bit) as launch_conv_gemm2_*(G2_RC*, 1, EPI_QKV, ...); needs hidden = 256, 4 heads, a.sink.
 hipError_t launch_qkv_ws(int dtype, const ConvGemmArgs& a, hipStream_t s);
@@ -185,7 +187,8 @@ hipError_t launch_cvt16_to_f32(int dtype, const void* src, float* dst, int64_t n
 // One launch for a whole list of packing jobs (the ~100 launch_pack_weight / launch_pack_weight_t calls and ~60 bias copies of a
 // re-pack after an optimizer step are each a few microseconds of launch latency: 0.75 ms per training step as separate launches).
 // kind 0: launch_pack_weight's mapping, kind 1: launch_pack_weight_t's (train_launch.h), kind 2: fp32 copy of `cout` elements,
-// kind 3: launch_pack_ffn_stream's (lo = stage, cout = F), kind 4: launch_pack_qkv_frag's (row_off = 256 * plane).
+// kind 3: launch_pack_ffn_stream's (lo = stage, cout = F), kind 4: launch_pack_qkv_frag's (row_off = 256 * plane),
+// kind 5: launch_pack_ffn_wino's (lo = stage, cout = F).
 // blk0 = first 256-thread block of the job in the merged grid (jobs sorted by blk0).
 struct PackJob { const float* src; void* dst; int kind, cout, cin_total, K, ci_off, ci_cnt, row_off, cin_p, col_off, slice_w, lo; unsigned blk0; };
 hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsigned nblocks, hipStream_t s);

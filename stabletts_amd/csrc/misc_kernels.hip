@@ -500,6 +500,20 @@ hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F,
     return hipGetLastError();
 }
 
+// weight stream of the Winograd fused FFN (common.h: ffn_wino_index; f16 only)
+__global__ void pack_ffn_wino_kernel(const float* src, int stage, int F, _Float16* dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)F * 256 * 3) return;
+    size_t so, dof; int pl;
+    ffn_wino_index(idx, stage, F, &so, &dof, &pl);
+    dst[dof] = (_Float16)ffn_wino_plane(src + so, pl);
+}
+hipError_t launch_pack_ffn_wino(const float* src, int stage, int F, void* dst, hipStream_t s) {
+    const size_t total = (size_t)F * 256 * 3;
+    hipLaunchKernelGGL(pack_ffn_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, stage, F, (_Float16*)dst);
+    return hipGetLastError();
+}
+
 // fragment-ordered q/k/v weight (common.h: qkv_frag_index)
 template <class P>
 __global__ void pack_qkv_frag_kernel(const float* src, int plane, typename P::elem* dst) {

@@ -669,6 +669,11 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* jobs, int
         size_t so, dof;
         ffn_stream_index(idx, j.lo, j.cout, &so, &dof);
         ((typename P::elem*)j.dst)[dof] = to16<P>(j.src[so]);
+    } else if (j.kind == 5) {       // pack_ffn_wino_kernel (misc_kernels.hip): lo = stage, cout = F; f16 engines only
+        if (idx >= (size_t)j.cout * 256 * 3) return;
+        size_t so, dof; int pl;
+        ffn_wino_index(idx, j.lo, j.cout, &so, &dof, &pl);
+        ((typename P::elem*)j.dst)[dof] = to16<P>(ffn_wino_plane(j.src + so, pl));
     } else if (j.kind == 4) {       // pack_qkv_frag_kernel (misc_kernels.hip): row_off = 256 * plane
         if (idx >= 256 * 256) return;
         ((typename P::elem*)j.dst)[qkv_frag_index(j.row_off >> 8, (int)(idx >> 8), (int)(idx & 255))] = to16<P>(j.src[idx]);

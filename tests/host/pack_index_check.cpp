@@ -1,6 +1,6 @@
 // Host-side check of the weight-layout index maps of stabletts_amd/csrc/common.h (compiled by tests/test_pack_index.py with
 // hipcc --cuda-host-only; no GPU): ffn_stream_index (both MFMA shapes, both stages) and qkv_frag_index must be bijections onto
-// their buffers, and every source element must be hit exactly once.
+// their buffers, and every source element must be hit exactly once; ffn_wino_index likewise (three planes per tap triple).
 #include <cstdio>
 #include <vector>
 #include "../../stabletts_amd/csrc/common.h"
@@ -36,6 +36,27 @@ int main() {
                     bad += frag != (size_t)((plane * 8 + co / 32) * 16 + ci / 16) || lane != (size_t)(((ci >> 3) & 1) * 32 + (co & 31)) || e != (size_t)(ci & 7);
                 }
         for (unsigned char c : dst) bad += c != 1;
+    }
+    // ffn_wino_index (the Winograd fused FFN's stream): per stage every (row, input channel) tap triple is used for exactly the three
+    // planes, the two stages fill the stream exactly once, a wave's three fragments of a k-step are consecutive KiB, lane-linear
+    for (int F : {256, 512, 1024, 2048}) {
+        const size_t n = (size_t)F * 256 * 3;
+        std::vector<unsigned char> dst(2 * n, 0);
+        for (int stage = 0; stage < 2; ++stage) {
+            std::vector<unsigned char> planes(n / 3, 0);
+            for (size_t idx = 0; idx < n; ++idx) {
+                size_t so, dof; int pl;
+                st::ffn_wino_index(idx, stage, F, &so, &dof, &pl);
+                if (so % 3 || so + 2 >= n || dof >= 2 * n || pl < 0 || pl > 2) { ++bad; continue; }
+                planes[so / 3] |= (unsigned char)(1 << pl); ++dst[dof];
+                const size_t frag = dof >> 9;                       // = (((chunk * 2 + stage) * 16 + k-step) * 8 + wave) * 3 + plane
+                bad += (int)(frag % 3) != pl || (int)((frag / 3 / 8 / 16) & 1) != stage;
+            }
+            for (unsigned char c : planes) bad += c != 7;
+        }
+        for (unsigned char c : dst) bad += c != 1;
+        const float g3[3] = {1.0f, 2.0f, 4.0f};
+        bad += st::ffn_wino_plane(g3, 0) != 1.0f || st::ffn_wino_plane(g3, 1) != 3.5f || st::ffn_wino_plane(g3, 2) != 4.0f;
     }
     printf("bad %d\n", bad);
     return bad != 0;

@@ -242,6 +242,71 @@ def test_weight_stationary_out_projection_is_bit_identical_to_the_generic_tile(s
         assert torch.equal(new.estimator(*args), old.estimator(*args))
 
 
+def test_winograd_fused_ffn_matches_the_direct_kernel_within_its_rounding(sd, cfg_params, monkeypatch):
+    """ffn_wino_kernel (the f16 default on big grids: F(2,3) along the frame axis -- raw pair-interleaved rows, transformed operands
+    formed with packed f16 adds, the fourth weight plane derived in registers, wave-private weight rings with per-position wait
+    counts) against the direct fused kernel (ST_FUSED_FFN=1, itself bit-identical to the two-kernel path): NOT bit-identical by
+    construction -- its operands are rounded sums -- but within a few 1e-4 of the solve's displacement (the oracle-level cost is
+    +0.6e-4, tools/parity_c2.py), at tile-edge lengths, ragged with tile skipping, a length-1 row, the headline shape, and
+    bit-REPRODUCIBLE run to run (a miscounted vmcnt or a missing barrier shows as run-to-run differences).  bf16 engines keep
+    the direct kernel whatever the variable says."""
+    kw = _kw(cfg_params, 3.0)
+    old = _fresh(sd, monkeypatch, "f16", ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN="1", ST_SMALL_GRID="0")
+    new = _fresh(sd, monkeypatch, "f16", ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN="3", ST_SMALL_GRID="0")
+    worst = 0.0
+    for B, T, lengths in ((2, 126, [126, 100]), (1, 127, [127]), (3, 253, [253, 252, 1]), (2, 700, [700, 255]), (4, 1000, [1000, 873, 640, 377]),
+                          (32, 1000, None)):
+        inp = make_inputs(B, T, seed=60 + T, lengths=lengths) if lengths else make_inputs(B, T, seed=0, ragged=True)
+        ref = _solve(old, inp, 4, "euler", kw)
+        out = _solve(new, inp, 4, "euler", kw)
+        for _ in range(2):
+            assert torch.equal(_solve(new, inp, 4, "euler", kw), out), (B, T)
+        assert torch.isfinite(out).all()
+        pad = ~inp["mask"].bool().expand_as(out)
+        assert torch.equal(out[pad], inp["z"][pad])                     # padded frames untouched, exactly
+        d = float((out - ref).abs().max() / (ref - inp["z"]).abs().max())
+        worst = max(worst, d)
+        assert 0.0 < d < 5e-4, (B, T, d)                                # different arithmetic (not 0), same function
+    print(f"Winograd vs direct fused FFN, solve displacement: worst {worst:.2e}")
+    # one evaluation with a per-item t
+    inp = make_inputs(3, 400, seed=61, lengths=[400, 399, 17])
+    t = torch.tensor([0.1, 0.5, 0.9])
+    args = (t.cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+    with torch.no_grad():
+        a, b = new.estimator(*args), old.estimator(*args)
+    assert float((a - b).abs().max() / b.abs().max()) < 5e-4
+    # bf16: the variable is ignored (packed f16 adds form the operands)
+    b1 = _fresh(sd, monkeypatch, "bf16", ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN="1", ST_SMALL_GRID="0")
+    b3 = _fresh(sd, monkeypatch, "bf16", ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN="3", ST_SMALL_GRID="0")
+    inp = make_inputs(2, 300, seed=5, lengths=[300, 211])
+    assert torch.equal(_solve(b3, inp, 2, "euler", kw), _solve(b1, inp, 2, "euler", kw))
+
+
+@pytest.mark.parametrize("F", [512, 768, 2048])
+def test_winograd_fused_ffn_other_filter_widths(cfg_params, monkeypatch, F):
+    """2, 3 and 8 chunks of 256 intermediate channels instead of the 31M model's 4 (stream length, bias area, `last chunk` waits)."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    cfg = oracle.DecoderConfig(filter_channels=F)
+    sdf = oracle.make_state_dict(777, cfg)
+    kw = _kw(cfg_params, 2.0)
+    decs = []
+    for fused in ("1", "3"):
+        for k, v in dict(ST_BIG_MIN_BLOCKS="1", ST_FUSED_FFN=fused, ST_SMALL_GRID="0").items():
+            monkeypatch.setenv(k, v)
+        d = CFMDecoder(128, 128, 256, 128, F, 4, 6, 3, 0.1, 256)
+        d.estimator.load_state_dict(sdf)
+        d = d.to("cuda:0"); d.estimator.engine()
+        decs.append(d)
+    for k in ("ST_BIG_MIN_BLOCKS", "ST_FUSED_FFN", "ST_SMALL_GRID"):
+        monkeypatch.delenv(k)
+    inp = make_inputs(3, 380, seed=33, lengths=[380, 251, 127])
+    ref = _solve(decs[0], inp, 2, "euler", kw)
+    out = _solve(decs[1], inp, 2, "euler", kw)
+    assert torch.equal(_solve(decs[1], inp, 2, "euler", kw), out)
+    d = float((out - ref).abs().max() / (ref - inp["z"]).abs().max())
+    assert 0.0 < d < 5e-4, d
+
+
 @pytest.mark.parametrize("F", [512, 768, 2048])
 def test_fused_ffn_other_filter_widths(cfg_params, monkeypatch, F):
     """The fused kernel walks the intermediate in 256-channel chunks (2, 3, 8 of them here instead of the 31M model's 4); its

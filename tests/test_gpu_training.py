@@ -510,14 +510,20 @@ def test_backward_of_replaced_activations_fails_loudly(sd):
         lc.backward()
 
 
-@pytest.mark.parametrize("qkv_ws", [False, True])
+@pytest.mark.parametrize("qkv_ws", [False, True, "big_tiles"])
 def test_optimizer_steps_repack_in_place_without_reallocation(sd, monkeypatch, qkv_ws):
     """Every optimizer step bumps the parameters' version counters (train.py:82).  The engine reads the fp32 tensors
     where torch keeps them (st_bind_param) and re-packs its 16-bit copies on the stream (st_repack): device bytes and
     the time-step count stay put, and the result equals a fresh decoder loaded with the updated weights bit for bit.
     qkv_ws: the weight-stationary q/k/v kernel forced at this small size (it reads its own fragment-ordered copy of the
-    weight, re-packed by the same job list: PackJob kind 4) against a fresh decoder on the generic tile."""
+    weight, re-packed by the same job list: PackJob kind 4) against a fresh decoder on the generic tile.
+    "big_tiles": both engines on the big-grid kernels at this small size (ST_BIG_MIN_BLOCKS=1) -- the evaluation goes through the
+    fused Winograd FFN, whose weight stream (three transformed planes per tap triple) is re-packed by PackJob kind 5."""
     from stabletts_amd.flow_matching import CFMDecoder
+    big = qkv_ws == "big_tiles"
+    qkv_ws = qkv_ws is True
+    if big:
+        monkeypatch.setenv("ST_BIG_MIN_BLOCKS", "1")
     if qkv_ws:
         monkeypatch.setenv("ST_QKV_WS_MIN_TILES", "1")
     dec = _decoder(sd, "f16", train=True)

@@ -35,3 +35,9 @@ def test_fragment_layouts_are_bank_conflict_free():
                   for wf in range(2) for b in range(4) for tap in range(3) for kp in range(2))
         assert w16 == want
     assert sorted(m.rowmap(n) for n in range(16)) == list(range(16))
+    # the Winograd fused FFN's raw rows: lane i reads row 2 i + e; pair-interleaved storage is conflict-free, the plain layout is not
+    for lay, want in ((m.swz, 2), (m.pair_interleaved, 1)):
+        ww = max(m.worst(lambda l: lay(2 * (32 * b + (l & 31)) + e, 2 * ks + (l >> 5))) for b in range(2) for e in range(4) for ks in range(4))
+        assert ww == want
+    pos = {m.pair_interleaved(r, c) for r in range(136) for c in range(8)}
+    assert len(pos) == 136 * 8 and max(pos) < 136 * 128

@@ -8,6 +8,8 @@ row.  The operand images are [row][64 channels] with 128-byte rows and the 16-by
 * 32x32x16 B-fragment (conv kernels, ffn_fused.h, qkv_ws.hip): lane l reads chunk 2 ks + (l >> 5) of row base + (l & 31).
 * 16x16x32 B-fragment (ffn_fused16.h): lane l reads chunk 4 kp + (l >> 4) of row base + tap + ROWMAP(l & 15); with the
   identity map every odd tap is a 2-way conflict, ROWMAP (8 even rows for one k-group, 8 odd rows for the other) is free.
+* Winograd raw rows (ffn_wino.h): lane l reads chunk 2 ks + (l >> 5) of row 2 (32 b + (l & 31)) + e, e = 0..3: a two-row stride, 2-way
+  conflicts in the plain layout, free in the pair-interleaved one.
 * the fp32 park of the 16x16x32 accumulators ([frame][260] float4 stores, 8 contiguous lanes per group, 32 banks).
 """
 G = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
@@ -33,7 +35,17 @@ def swz(row, chunk):
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
 
 
+def pair_interleaved(row, chunk):
+    """Raw-row layout of the Winograd fused FFN (ffn_wino.h): row r -> storage row 2 q + (e ^ (q & 1)), 16-byte slot chunk ^ ((q >> 1) & 7)
+    with q = r >> 1, e = r & 1 -- lane i of a B-fragment read takes row 2 i + e (a frame PAIR per lane), stride two rows."""
+    q, e = row >> 1, row & 1
+    return (2 * q + (e ^ (q & 1))) * 128 + ((chunk ^ ((q >> 1) & 7)) << 4)
+
+
 if __name__ == "__main__":
+    for name, lay in (("plain", swz), ("pair-interleaved", pair_interleaved)):
+        ww = max(worst(lambda l: lay(2 * (32 * b + (l & 31)) + e, 2 * ks + (l >> 5))) for b in range(2) for e in range(4) for ks in range(4))
+        print("Winograd raw-row reads (row 2 i + e),", name, "layout: worst", ww, "-way")
     w32 = max(worst(lambda l: swz(base + tap + (l & 31), 2 * ks + (l >> 5))) for base in (0, 32, 64, 96) for tap in range(3) for ks in range(4))
     print("32x32x16 B-fragment reads, all taps / k-steps: worst", w32, "-way")
     for name, rm in (("identity", lambda n: n), ("ROWMAP", rowmap)):

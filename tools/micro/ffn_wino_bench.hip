@@ -1,4 +1,4 @@
-// PROTOTYPE harness for tools/micro/ffn_wino.h: the Winograd F(2,3) fused FFN against the shipped fused kernel at the headline launch
+// Harness for stabletts_amd/csrc/ffn_wino.h: the Winograd F(2,3) fused FFN against the shipped fused kernel at the headline launch
 // shape -- outputs compared with a tolerance (the formulation is not bit-identical: DESIGN.md section 7), both timed interleaved.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value ffn_wino_bench.hip -o ffn_wino_bench ; run: ./ffn_wino_bench [N T fill]
 #include <hip/hip_runtime.h>
@@ -7,7 +7,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
-#include "ffn_wino.h"
+#include "../../stabletts_amd/csrc/ffn_wino.h"
 
 using namespace st;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
