@@ -282,9 +282,10 @@ def test_winograd_fused_ffn_matches_the_direct_kernel_within_its_rounding(sd, cf
     assert torch.equal(_solve(b3, inp, 2, "euler", kw), _solve(b1, inp, 2, "euler", kw))
 
 
-@pytest.mark.parametrize("F", [512, 768, 2048])
+@pytest.mark.parametrize("F", [256, 512, 768, 2048])
 def test_winograd_fused_ffn_other_filter_widths(cfg_params, monkeypatch, F):
-    """2, 3 and 8 chunks of 256 intermediate channels instead of the 31M model's 4 (stream length, bias area, `last chunk` waits)."""
+    """1, 2, 3 and 8 chunks of 256 intermediate channels instead of the 31M model's 4 (stream length, bias area, `last chunk` waits;
+    one chunk: the first chunk is also the last)."""
     from stabletts_amd.flow_matching import CFMDecoder
     cfg = oracle.DecoderConfig(filter_channels=F)
     sdf = oracle.make_state_dict(777, cfg)
