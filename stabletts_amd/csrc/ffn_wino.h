@@ -1,18 +1,32 @@
-// The fused FFN (ffn_fused.h) on Winograd F(2,3) along the frame axis: two output frames from four input frames with 4 instead of 6
-// products per (cout, cin) -- a third fewer MFMAs in a power-limited loop.  f16 operands only (packed f16 adds form the transformed
-// operands); OPT-IN (ST_FUSED_FFN=3): results are NOT bit-identical to the direct kernels (rounded sums as operands: +0.2e-4 on the
-// one-evaluation error; tools/winograd_numerics.py, tools/micro/wino_loop.hip, tools/micro/ffn_wino_bench.hip).
+// The fused FFN (ffn_fused.h) on Winograd F(2,3) along the frame axis: the two outputs of a frame PAIR from four input rows with 4
+// instead of 6 products per (cout, cin) -- a third fewer MFMAs in a power-limited loop:
+//   y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   m = ( g0 (d0 - d2),  (g0 + g1 + g2)/2 (d1 + d2),  (g0 - g1 + g2)/2 (d2 - d1),  g2 (d1 - d3) ).
+// f16 operands only (packed f16 adds form the transformed operands) and the DEFAULT with them on the grids that take the fused
+// kernel (ST_FUSED_FFN=1: the direct kernel).  NOT bit-identical to the direct kernels -- its operands are rounded sums: config 2
+// as benchmarked, solve displacement vs the fp32 oracle 2.97e-4 -> 3.57e-4 (gate 7e-4); tools/winograd_numerics.py,
+// tools/parity_c2.py, tools/micro/wino_loop.hip, tools/micro/ffn_wino_bench.hip.  The transformed activation operands are sums of two
+// values: the intermediate overflows f16 at |u| > 32,752 (reported like any overflow, st_output_status).
 //
-// Block = 8 waves, one tile of 126 output frames of one item (128 u rows, 130 h rows: the shipped kernel's geometry).  Differences:
+// Block = 8 waves, one tile of 126 output frames of one item (128 u rows, 130 h rows, 256-channel chunks, the same epilogue: the
+// direct kernel's geometry).  Differences:
 //   * areas hold RAW rows in the pair-interleaved layout (row r -> storage row 2q + (e ^ (q & 1)), slot c ^ ((q >> 1) & 7), q = r >> 1,
-//     e = r & 1); a wave forms the four transformed B fragments of a frame PAIR (rows 2i .. 2i + 3) with 16 v_pk_add_f16;
+//     e = r & 1: lane i's read of row 2i + e is conflict-free for ds_read_b128's lane groups, tools/lds_bank_check.py); a wave forms
+//     the four transformed B fragments of 32 pairs (rows 2i .. 2i + 3) from four raw fragments with 16 v_pk_add_f16;
 //   * wave w owns 32 channels (conv_1: hidden channels 32 w .. of the chunk, conv_2: output channels 32 w ..) x ALL 64 pairs: every
 //     weight fragment is read by exactly one wave, so each wave keeps a PRIVATE ring of 9 fragments (3 k-steps x planes U0, U1, U3; the
-//     fourth plane U2 = U0 + U3 - U1 is formed in registers) filled by its own LDS-DMA, 3 k-steps ahead, counted with its own vmcnt --
-//     no barrier belongs to the weight stream.  Barriers remain every 4 k-steps (hand-over of the areas between h and u);
-//   * per k-step and wave: 3 A + 8 B fragment reads, 40 packed adds, 8 MFMAs (direct: 12 reads, 12 MFMAs), 4 LDS-DMA pieces issued
-//     (3 weight fragments of k-step + 3, 1 h piece or a padding piece -> sink), `s_waitcnt vmcnt(9)` at the top;
-//   * accumulators: M[4 products][2 pair fragments] (128 registers, conv_1 then conv_2 of a chunk) + Y (64, conv_2's outputs).
+//     fourth plane U2 = U0 + U3 - U1 is formed in registers) filled by its own LDS-DMA 3 k-steps ahead and counted with its own vmcnt:
+//       RAW  the fragments of k-step k were issued in k-step k - 3; the wait at the top of k allows exactly the pieces issued after
+//            them (3 weight pieces per k-step + an h piece where the plan has one: wn_allowed, 6..9, compile-time per position)
+//       WAR  k-step k + 3 lands in the slot k-step k was read from; it is issued at the END of k-step k, after the MFMAs that consumed
+//            those fragments (data dependence)
+//     no barrier belongs to the weight stream.  Barriers remain after every 4 k-steps: the hand-over of an area between h and u, and
+//     the cross-wave visibility of refilled h (a wave's own wait covers only its own pieces; every refill is issued >= 4 k-steps and
+//     one barrier before its first reader -- see the plan at the WN_STEP rows);
+//   * per k-step and wave: 3 A + 8 B fragment reads, 40 packed adds, 8 MFMAs (direct: 12 reads, 12 MFMAs);
+//   * accumulators: M[4 products][2 pair fragments] (128 registers, conv_1 then conv_2 of a chunk; conv_1's m1 starts from the bias,
+//     which both outputs contain once) + Y (64, conv_2's outputs, transformed chunk by chunk).  255 VGPRs: the per-lane h-piece offsets
+//     and the tile's mask values live in LDS, lane indices are re-derived at their use sites (kept live across the k-steps they cost
+//     scratch -- and scratch loads count in vmcnt).
 // Weight stream: [chunk][stage][k-step][wave][plane U0, U1, U3] 1-KiB fragments, lane-linear (common.h: ffn_wino_index).
 #pragma once
 #include "ffn_fused.h"
