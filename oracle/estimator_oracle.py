@@ -73,6 +73,8 @@ def attention(q, k, v, mask, n_heads=4, drop=None, subst=None):
     vh = v.view(B, n_heads, dh, T).transpose(2, 3)
     qh = rope(qh, int(dh * 0.5))
     kh = rope(kh, int(dh * 0.5))
+    if callable(subst):      # (tools/qk_rounding_sensitivity.py: a function of THIS forward's q, k, v, e.g. their f16 rounding)
+        subst = subst(qh, kh, vh)
     if subst is not None:
         # test hook (tests/test_gpu_training.py): evaluate the attention AT the given post-RoPE values (the native
         # forward's own 16-bit q, k, v) while gradients keep flowing through this graph -- a straight-through

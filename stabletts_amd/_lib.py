@@ -296,9 +296,14 @@ class Engine:
                                                     ptr(grad_c), ctypes.c_void_p(stream)))
 
     def param_part(self, name):
-        r = self.lib.st_train_param_part(self.handle, name.encode())
-        if r < 0:
-            raise NativeError(r, f"st_train_param_part({name})")
+        """Backward part (0, 1, 2) that produces the gradient of parameter `name` (a function of the name only: cached)."""
+        cache = self.__dict__.setdefault("_param_part", {})
+        r = cache.get(name)
+        if r is None:
+            r = self.lib.st_train_param_part(self.handle, name.encode())
+            if r < 0:
+                raise NativeError(r, f"st_train_param_part({name})")
+            cache[name] = r
         return r
 
     def param_grad(self, name, dst, stream):

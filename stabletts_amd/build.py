@@ -19,7 +19,7 @@ LIB = os.environ.get("ST_BUILD_OUT") or os.path.join(HERE, "libstabletts_hip.so"
 OBJ = os.path.join(HERE, "csrc", "build") if not os.environ.get("ST_BUILD_OUT") else LIB + ".obj"
 SOURCES = ["engine.cpp", "engine_train.cpp", "engine_vocos.cpp", "vocos_kernels.hip", "conv_gemm2_bf16.hip", "conv_gemm2_f16.hip", "ffn_fused_bf16.hip", "ffn_fused_f16.hip", "ffn_wino_f16.hip", "qkv_ws.hip", "oproj_ws.hip",
            "attention.hip", "attention_bwd.hip", "train_kernels.hip", "wgrad_tn.hip", "misc_kernels.hip", "align_kernels.hip", "adaptive_ode.hip"]
-HEADERS = ["common.h", "launch.h", "train_launch.h", "vocos_launch.h", "engine_internal.h", "conv_gemm2_impl.h", "conv_gemm_phased.h", "conv_gemm2_inst.h", "ffn_fused.h", "ffn_fused16.h", "ffn_wino.h", os.path.join("..", "..", "include", "stabletts_hip.h")]
+HEADERS = ["common.h", "launch.h", "train_launch.h", "vocos_launch.h", "engine_internal.h", "conv_gemm2_impl.h", "conv_gemm_phased.h", "conv_gemm2_inst.h", "ffn_fused.h", "ffn_wino.h", os.path.join("..", "..", "include", "stabletts_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-Rpass-analysis=kernel-resource-usage"]
 # per-source flags: the attention kernels keep their fp32 row-sum adds scalar (common.h: add_f32_scalar)

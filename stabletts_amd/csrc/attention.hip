@@ -31,6 +31,9 @@
 #include "launch.h"
 
 // ablation builds of the inference kernel (tools/ab_attention_ablation.sh): the softmax without its exps / row sums / maxima
+#if (defined(ST_ABL_NOEXP) || defined(ST_ABL_NOSUM)) && !defined(ST_DEVTOOLS)
+#error "ST_ABL_* (ablation builds: results are garbage) need -DST_DEVTOOLS"
+#endif
 #ifdef ST_ABL_NOEXP
 constexpr bool kAblNoExp = true;
 #else

@@ -246,20 +246,17 @@ __device__ __forceinline__ unsigned drop_ffn_hash(const D& d, unsigned long long
     return drop_mix32(((unsigned)d.seed ^ ((unsigned)(i >> 1) * 0x9E3779B1u)) + (unsigned)(d.seed >> 32));
 }
 
-// Fused-FFN weight stream (launch.h: launch_pack_ffn_stream; ffn_fused.h / ffn_fused16.h consume it): element idx of one stage's
+// Fused-FFN weight stream (launch.h: launch_pack_ffn_stream; ffn_fused.h consumes it): element idx of one stage's
 // F*256*3 values -> source offset in the fp32 conv weight and destination offset in the stream (16-bit elements).  hidden = 256
-// hard-wired.  stage bit 0 = conv_1 / conv_2, bit 1 = fragments of the 16x16x32 MFMA (ffn_fused16.h) instead of 32x32x16.
+// hard-wired.  stage = 0: conv_1, 1: conv_2.
 //   idx = ((c*24 + sl)*16 + f)*512 + lane*8 + e;  sl = (ci, tap, kp) = ci*6 + tap*2 + kp
-//   32x32x16: f = ksl*8 + a8, row r = a8*32 + (lane&31), cin kk = ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e
-//   16x16x32: f = wq*4 + a,   row r = f*16 + (lane&15),  cin kk = ci*64 + kp*32 + (lane>>4)*8 + e
+//   f = ksl*8 + a8, row r = a8*32 + (lane&31), cin kk = ci*64 + (2kp+ksl)*16 + (lane>>5)*8 + e      (32x32x16 A fragments)
 //   conv_1 (F, 256, 3): source (c*256 + r, kk, tap);  conv_2 (256, F, 3): source (r, c*256 + kk, tap)
 __host__ __device__ __forceinline__ void ffn_stream_index(size_t idx, int stage, int F, size_t* src_off, size_t* dst_off) {
     const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), f = (int)((idx >> 9) & 15);
     const int sl = (int)((idx >> 13) % 24), c = (int)(idx / (24u * 8192u));
     const int ci = sl / 6, tap = (sl % 6) >> 1, kp = sl & 1;
-    int r, kk;
-    if (stage & 2) { r = f * 16 + (lane & 15); kk = ci * 64 + kp * 32 + (lane >> 4) * 8 + e; }
-    else           { r = (f & 7) * 32 + (lane & 31); kk = ci * 64 + (2 * kp + (f >> 3)) * 16 + (lane >> 5) * 8 + e; }
+    const int r = (f & 7) * 32 + (lane & 31), kk = ci * 64 + (2 * kp + (f >> 3)) * 16 + (lane >> 5) * 8 + e;
     if ((stage & 1) == 0) *src_off = ((size_t)(c * 256 + r) * 256 + kk) * 3 + tap;
     else                  *src_off = ((size_t)r * F + c * 256 + kk) * 3 + tap;
     *dst_off = (size_t)c * (48u * 8192u) + (size_t)((stage & 1) * 24 + sl) * 8192u + (idx & 8191);

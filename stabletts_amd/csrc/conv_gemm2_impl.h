@@ -170,8 +170,7 @@ __device__ __forceinline__ void g2_rows(const ConvGemmArgs& g, const G2Consts& k
 // LDS-staged epilogue shared by the gen-2 kernels.  fvalid = number of valid frame columns of the tile
 // (BF, or BF-2 for the 3-buffer k=3 kernel whose activation tile includes its own halo).
 // `park(fbase)` stores the calling wave's accumulator tile into `stage` as [frame][channel] fp32, frame rows from fbase on (row
-// pitch BC + 4 words): the only part that depends on the MFMA shape the K loop used (g2_epilogue: 32x32x16 fragments; the
-// fused FFN's 16x16x32 variant brings its own, ffn_fused16.h).
+// pitch BC + 4 words): the only part that depends on the accumulator layout of the K loop (g2_epilogue: 32x32x16 fragments).
 template <class P, int EPI, int BC, int BF, int WC, int WF, class Park>
 __device__ __forceinline__ void g2_epilogue_core(Park park, float* stage, const ConvGemmArgs& g,
                                                  int n, int t0, int fvalid, int cbase, int wave, int lane) {

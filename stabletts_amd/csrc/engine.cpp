@@ -134,7 +134,6 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
     if (epi == EPI_QKV && e->qkv_ws && e->sink && a.w_frag && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
         (int64_t)a.n_items * ((T + 63) / 64) >= e->qkv_ws_min_tiles) {      // (per LAUNCH: a block needs a handful of tiles to amortise its weight load)
         ConvGemmArgs b = a; b.sink = e->sink;
-        if (e->qkv_ws == 2) b.flags |= GF_QWS4;
         return launch_qkv_ws(e->dt, b, s);
     }
     // the out projection (+ LayerNorm_2) of big grids in the same style (oproj_ws.hip; bit-identical)
@@ -519,7 +518,6 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             ProfScope ps(e, s, PC_FFN2, conv_flops(p, e->ffn2[i], N) + (fused ? conv_flops(p, e->ffn1[i], N) : 0.0));
             if (e->skip_mask >> PC_FFN2 & 1) {}
             else if (fused && e->fused_ffn == 3) HIPCHK(e, launch_ffn_wino_f16(a, s));
-            else if (fused && e->fused_ffn == 2) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused16_bf16(a, s) : launch_ffn_fused16_f16(a, s));
             else if (fused) HIPCHK(e, e->dt == DT_BF16 ? launch_ffn_fused_bf16(a, s) : launch_ffn_fused_f16(a, s));
             else HIPCHK(e, gemm(e, 3, EPI_RESGATE, a, s));
         }
@@ -963,10 +961,15 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     if (const char* mb = getenv("ST_BIG_MIN_BLOCKS")) e->big_min_blocks = atoi(mb);
     if (const char* v = getenv("ST_PHASED")) e->phased = atoi(v);
     if (const char* v = getenv("ST_FUSED_FFN")) e->fused_ffn = atoi(v);
-    if (e->fused_ffn < 0) e->fused_ffn = e->dt == DT_F16 ? 3 : 1;
-    if (e->fused_ffn == 3 && e->dt != DT_F16) e->fused_ffn = 1;      // the Winograd form forms its operands with packed f16 adds
+    // Default = the direct fused kernel, bit-identical to the two-kernel path.  Round 5 put the Winograd form on trial with O(1) adaLN
+    // gates at B = 32 x T = 1000 (tools/parity_trained.py): one evaluation 8.8e-4 against the direct kernel's 7.3e-4 -- too close to the
+    // 1e-3 bar for a 1.45 % gain, so it is opt-in (ST_FUSED_FFN=3; f16 only: it forms its operands with packed f16 adds).
+    if (e->fused_ffn < 0 || e->fused_ffn > 3 || e->fused_ffn == 2) e->fused_ffn = 1;
+    if (e->fused_ffn == 3 && e->dt != DT_F16) e->fused_ffn = 1;
     if (const char* v = getenv("ST_RAGGED_SKIP")) e->ragged_skip = atoi(v);
-    if (const char* v = getenv("ST_SKIP_CLASSES")) e->skip_mask = (unsigned)strtoul(v, nullptr, 0);      // developer tool: results are garbage
+#ifdef ST_DEVTOOLS      // developer builds only (ST_BUILD_DEFS=-DST_DEVTOOLS): a shipping library must not return garbage because of an environment variable
+    if (const char* v = getenv("ST_SKIP_CLASSES")) e->skip_mask = (unsigned)strtoul(v, nullptr, 0);
+#endif
     if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
     if (const char* v = getenv("ST_QKV_WS_MIN_TILES")) e->qkv_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_OPROJ_RC")) e->oproj_rc = atoi(v);
@@ -1258,9 +1261,8 @@ int pack_all(st_engine* e, hipStream_t s) {
                     pk_push(PL, PackJob{src, e->ffn_stream[i], 5, F, 0, 0, 0, 0, 0, 0, 0, 0, st, 0u}, (size_t)F * C * K);
                     continue;
                 }
-                const int stg = st | (e->fused_ffn == 2 ? 2 : 0);      // bit 1: fragments of the 16x16x32 kernel
-                HIPCHK(e, launch_pack_ffn_stream(e->dt, src, stg, F, e->ffn_stream[i], s));
-                pk_push(PL, PackJob{src, e->ffn_stream[i], 3, F, 0, 0, 0, 0, 0, 0, 0, 0, stg, 0u}, (size_t)F * C * K);
+                HIPCHK(e, launch_pack_ffn_stream(e->dt, src, st, F, e->ffn_stream[i], s));
+                pk_push(PL, PackJob{src, e->ffn_stream[i], 3, F, 0, 0, 0, 0, 0, 0, 0, 0, st, 0u}, (size_t)F * C * K);
             }
         }
     }

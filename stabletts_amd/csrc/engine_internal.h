@@ -108,20 +108,20 @@ struct st_engine {
     // from ST_BIG_MIN_BLOCKS at st_create (tests force either tile family with it)
     void* adams_buf = nullptr; size_t adams_bytes = 0;     // extra state buffers of the implicit Adams solver (allocated at its first use)
     int big_min_blocks = 192;
-    unsigned skip_mask = 0;             // developer tool (ST_SKIP_CLASSES, bit = profile class): launches of these classes of run_estimator are NOT issued -- what a
+    unsigned skip_mask = 0;             // developer tool, -DST_DEVTOOLS builds only (ST_SKIP_CLASSES, bit = profile class): launches of these classes of run_estimator are NOT issued -- what a
                                         // class costs the solve with its parts overlapping on four streams (tools/ab_engines.py); results are garbage
     int qkv_ws_min_tiles = 400;         // ... when the launch has at least this many 64-frame tiles (>= 5 per persistent block)
-    int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip): 1 = eight waves, one block per CU,
-                                        // 2 = four waves, two blocks per CU; ST_QKV_WS=0: the generic conv tile
+    int qkv_ws = 1;                     // fused q/k/v projection of big grids as the weight-stationary persistent kernel (qkv_ws.hip; default);
+                                        // ST_QKV_WS=0: the generic conv tile
     int oproj_ws = 1;                   // out projection of big grids as the weight-stationary persistent kernel (oproj_ws.hip; default); ST_OPROJ_WS=0: the generic 256 x 256 tile
     int oproj_ws_min_tiles = 1000;      // ... from this many 32-frame tiles per launch
     int oproj_rc = 0;                   // out projection of big grids on row-complete 256 x 128 tiles (G2_RC) instead of 256 x 256 (ST_OPROJ_RC=1: A/B runs)
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
-    int fused_ffn = -1;                 // FFN of big grids as ONE kernel, the intermediate kept in LDS.  -1 = default: 3 with f16 operands, 1 with bf16.
-                                        // 3 = Winograd F(2,3) along the frames (ffn_wino.h; f16 only, NOT bit-identical to the others: rounded sums as
-                                        // operands, a third fewer MFMAs), 2 = on 16x16x32 MFMA fragments (ffn_fused16.h),
-                                        // 1 = on 32x32x16 (ffn_fused.h, bit-identical to the two-kernel path), ST_FUSED_FFN=0: two kernels.  Read at st_create.
+    int fused_ffn = -1;                 // FFN of big grids as ONE kernel, the intermediate kept in LDS.  -1 = default = 1: the direct kernel on 32x32x16 MFMA
+                                        // (ffn_fused.h, bit-identical to the two-kernel path); ST_FUSED_FFN=3 (opt-in, f16 only): Winograd F(2,3) along the frames
+                                        // (ffn_wino.h: a third fewer MFMAs, -1.45 % per solve, NOT bit-identical -- rounded sums as operands, +20 % error, half the
+                                        // f16 range for the intermediate); ST_FUSED_FFN=0: two kernels.  Read at st_create.
     int phased = 1;                     // k = 3 convs on 256-wide tiles use the phased K loop (conv_gemm_phased.h); ST_PHASED=0: A/B runs
     int splitk_max = kSplitKMax, splitk_min_stages = 4;
     int small_tiles = 256;              // conv launches of <= this many 128x128 tiles use the 64-frame tile variants (0: never)

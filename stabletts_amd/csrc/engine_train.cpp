@@ -46,6 +46,7 @@ struct TrainState {
     float* grad_flat = nullptr; int64_t grad_numel = 0;
     float* gbase = nullptr;
     int next_part = 0; int64_t part_serial = 0;   // st_train_backward_part: the part expected next of the backward of forward #part_serial
+    bool own_grads_valid = false;                 // grad_flat holds the gradients of the LAST backward (false while / after a backward that wrote into a caller's buffer)
     // activation + scratch arena of the last train_forward
     char* ws = nullptr; size_t ws_cap = 0;
     int B = 0, T = 0, Tp = 0;
@@ -440,6 +441,7 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
     }
     ts->have_fwd = true;
     ts->serial += 1;
+    ts->gbase = ts->grad_flat; ts->next_part = 0;      // a pruned / abandoned multi-part backward of the previous forward leaves no state behind
     return ST_OK;
 }
 
@@ -811,9 +813,10 @@ int st_train_backward(st_engine* e, int64_t serial, int B_, int T_, const float*
     if (!grad_out) return e->fail(ST_ERR_INVALID, "null tensor pointer");
     HIPCHK(e, hipSetDevice(e->device));
     TrainState* ts = e->train;
-    ts->gbase = ts->grad_flat; ts->next_part = 0;
+    ts->gbase = ts->grad_flat; ts->next_part = 0; ts->own_grads_valid = false;
     for (int part = 0; part < 3; ++part)
         if ((rc = bwd_part(e, ts, part, grad_out, grad_x, grad_mu, grad_c, (hipStream_t)stream))) return rc;
+    ts->own_grads_valid = true;
     return ST_OK;
 }
 
@@ -828,7 +831,7 @@ int st_train_backward_part(st_engine* e, int64_t serial, int B_, int T_, int par
         if (grad_flat && grad_numel != ts->grad_numel)
             return e->fail(ST_ERR_INVALID, "st_train_backward_part: grad_numel must be st_train_grad_numel()");
         ts->gbase = grad_flat ? grad_flat : ts->grad_flat;
-        ts->part_serial = serial;
+        ts->part_serial = serial; ts->own_grads_valid = false;
     } else if (ts->next_part != part || ts->part_serial != serial) {
         return e->fail(ST_ERR_STATE, "st_train_backward_part: parts run in order 0, 1, 2 of ONE backward (expected part " +
                        std::to_string(ts->next_part) + ")");
@@ -836,7 +839,7 @@ int st_train_backward_part(st_engine* e, int64_t serial, int B_, int T_, int par
     HIPCHK(e, hipSetDevice(e->device));
     if ((rc = bwd_part(e, ts, part, grad_out, grad_x, grad_mu, grad_c, (hipStream_t)stream))) { ts->next_part = 0; return rc; }
     ts->next_part = part == 2 ? 0 : part + 1;
-    if (part == 2) ts->gbase = ts->grad_flat;
+    if (part == 2) { ts->own_grads_valid = ts->gbase == ts->grad_flat; ts->gbase = ts->grad_flat; }
     return ST_OK;
 }
 
@@ -863,6 +866,7 @@ int st_param_grads_flat(st_engine* e, float* dst, int64_t numel, void* stream) {
     if (!e || !dst) return ST_ERR_INVALID;
     if (!e->train || !e->train->grad_flat) return e->fail(ST_ERR_STATE, "no training state");
     if (numel != e->train->grad_numel) return e->fail(ST_ERR_INVALID, "st_param_grads_flat: numel must be the sum of all parameter sizes");
+    if (!e->train->own_grads_valid) return e->fail(ST_ERR_STATE, "st_param_grads_flat: the last backward did not complete into the engine's own gradient buffer (it wrote into the caller's, or was abandoned)");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemcpyAsync(dst, e->train->grad_flat, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return ST_OK;
@@ -875,6 +879,7 @@ int st_param_grad(st_engine* e, const char* name, float* dst, int64_t numel, voi
     auto pit = e->params.find(name);
     if (it == e->train->grads.end() || pit == e->params.end()) return e->fail(ST_ERR_INVALID, std::string("unknown parameter: ") + name);
     if (pit->second.numel() != numel) return e->fail(ST_ERR_INVALID, std::string("size mismatch for gradient of ") + name);
+    if (!e->train->own_grads_valid) return e->fail(ST_ERR_STATE, "st_param_grad: the last backward did not complete into the engine's own gradient buffer (it wrote into the caller's, or was abandoned)");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemcpyAsync(dst, it->second, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return ST_OK;

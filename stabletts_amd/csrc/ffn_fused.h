@@ -373,6 +373,9 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
     g2_epilogue<P, EPI_RESGATE, 256, 128, 4, 2>(acc2, (float*)smem, g, n, t0, FV, 0, wc + 4 * wf, lane);
 }
 
+#if defined(ST_FFN_ABL) && !defined(ST_DEVTOOLS)
+#error "ST_FFN_ABL (ablation builds: results are garbage) needs -DST_DEVTOOLS"
+#endif
 #ifndef ST_FFN_ABL
 #define ST_FFN_ABL 0
 #endif

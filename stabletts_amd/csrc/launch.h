@@ -14,7 +14,7 @@ enum { DT_BF16 = 0, DT_F16 = 1 };
 enum { EPI_ACT16 = 0, EPI_F32 = 1, EPI_RESGATE = 2, EPI_QKV = 3,
        EPI_GELU16 = 4,     // EPI_ACT16 with exact-erf GELU in place of SiLU (Vocos pwconv1, module.py:38-39)
        EPI_SILU = 5 };     // training FFN (k = 3, phased kernel only): EPI_F32 + the SiLU / dropout step fused, see act16 / dact16
-enum { GF_SILU = 1, GF_MASK = 2, GF_QWS4 = 4 };      // GF_QWS4: launch_qkv_ws on its 4-wave / two-blocks-per-CU cut
+enum { GF_SILU = 1, GF_MASK = 2 };
 
 struct ConvGemmArgs {
     const void* a0; const void* a1;   // activation sources [items][T][c0], [items][T][c1]
@@ -84,13 +84,10 @@ hipError_t launch_splitk_finish_f16(int epi, const ConvGemmArgs& a, const float*
 constexpr int kFfnFusedFrames = 126;      // output frames per block (128 u rows = the tile + conv_2's halo)
 hipError_t launch_ffn_fused_bf16(const ConvGemmArgs& a, hipStream_t s);
 hipError_t launch_ffn_fused_f16(const ConvGemmArgs& a, hipStream_t s);
-// the same kernel on 16x16x32 MFMA fragments (ffn_fused16.h; weight stream packed with stage bit 1 set)
-hipError_t launch_ffn_fused16_bf16(const ConvGemmArgs& a, hipStream_t s);
-hipError_t launch_ffn_fused16_f16(const ConvGemmArgs& a, hipStream_t s);
 // Weight stream of the fused FFN kernel, in the order the kernel consumes it: for each 256-channel chunk c of the intermediate
 // width, 24 conv_1 slabs (cin chunk, tap, k-step pair) then 24 conv_2 slabs (u sub-chunk, tap, k-step pair); a slab = 16 MFMA
 // A-fragments of 1 KiB stored lane-linear (fragment (ksl, a8): rows a8*32.., k-step 2*kp+ksl).  stage 0: src = conv_1 weight
-// (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).  stage | 2: the 16x16x32 kernel's fragments (common.h: ffn_stream_index).
+// (F, 256, 3); stage 1: src = conv_2 weight (256, F, 3).  (common.h: ffn_stream_index)
 hipError_t launch_pack_ffn_stream(int dtype, const float* src, int stage, int F, void* dst, hipStream_t s);
 hipError_t launch_pack_ffn_wino(const float* src, int stage, int F, void* dst, hipStream_t s);      // ffn_wino.h's stream (f16)
 hipError_t launch_ffn_wino_f16(const ConvGemmArgs& a, hipStream_t s);                                   // Winograd F(2,3) fused FFN, f16 operands only

@@ -409,8 +409,10 @@ __global__ __launch_bounds__(256) void cfm_loss_prep_kernel(const float* x1, con
     if (blockIdx.x == 0 && threadIdx.x == 0) t_out[b] = t;
     const float cz = 1.0f - one_minus_sigma * t;      // y = (1 - (1 - sigma) t) z + t x1 (:93), u = x1 - (1 - sigma) z (:96)
     const int64_t base = (int64_t)b * per_item;
+    // float4 path only where all four ADDRESSES are 16-byte aligned (the tensors may be views at any element offset)
+    const bool al16 = ((((uintptr_t)(x1 + base)) | ((uintptr_t)(z + base)) | ((uintptr_t)(y + base)) | ((uintptr_t)(u + base))) & 15) == 0;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < per_item; i += (int64_t)gridDim.x * blockDim.x * 4) {
-        if (i + 4 <= per_item && ((base + i) & 3) == 0) {
+        if (i + 4 <= per_item && al16) {
             const float4 a = *(const float4*)(x1 + base + i), n = *(const float4*)(z + base + i);
             *(float4*)(y + base + i) = make_float4(cz * n.x + t * a.x, cz * n.y + t * a.y, cz * n.z + t * a.z, cz * n.w + t * a.w);
             *(float4*)(u + base + i) = make_float4(a.x - one_minus_sigma * n.x, a.y - one_minus_sigma * n.y, a.z - one_minus_sigma * n.z, a.w - one_minus_sigma * n.w);

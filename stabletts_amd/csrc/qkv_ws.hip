@@ -323,243 +323,6 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
 #undef QWS_STAMP
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same kernel re-cut for TWO RESIDENT BLOCKS per CU: 4 waves, wave w owns head w (64 channels = 2 x 16 fragments = 128 VGPRs),
-// 32-frame tiles (16 KiB, two slots), images of 20 KiB (two buffers), RoPE rows of 32 frames: 76 KiB of LDS, <= 256 VGPRs.  Within
-// one block the phases of a tile are serial (stores -> reads + MFMAs -> epilogue arithmetic) and its two waves per SIMD move in
-// lock step; two independent blocks on a CU put one block's vector / store phases beside the other's MFMAs.  Per tile and wave:
-// 4 LDS-DMA pieces, 16 fragment reads (0.5 per MFMA), 32 MFMAs, 4 row stores -- the same counted-wait protocol.  Every wave now
-// carries the same share of the RoPE arithmetic (dims 0..31 of ITS head).
-constexpr int kQws4Tile = 32 * 512, kQws4Image = 256 * 80, kQws4Rope = 2 * 32 * kQwsRopePitch * 4;
-constexpr int kQws4Lds = 2 * kQws4Tile + 2 * kQws4Image + kQws4Rope + 1024;      // 79,872 B (+ the plane's bias); two blocks = 159,744 B
-
-template <class P, int VAR>
-__global__ __launch_bounds__(256, 2)
-void qkv_ws4_kernel(const ConvGemmArgs g, int L) {
-    constexpr int var = VAR;
-    using vec8 = typename P::vec8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int T = g.T, H = g.n_heads, Tp = g.Tp;
-    const int tiles_f = Tp >> 5;      // the v plane is written up to Tp (zero tail)
-
-    const int per_xcd = gridDim.x >> 3;
-    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lin >= 3 * tiles_f * L) return;
-    const int plane = lin % 3, grp = lin / 3;
-    const int tf = grp % tiles_f, first = grp / tiles_f;
-    const int t0 = tf * 32;
-
-    unsigned long long todo;
-    {
-        const int n = first + lane * L;
-        bool need = n < g.n_items;
-        if (need && g.t_lim) need = t0 < g.t_lim[n % g.t_lim_mod];
-        todo = __ballot(need);
-    }
-    if (todo == 0) return;
-    auto pop_item = [&]() {
-        if (todo == 0) return g.n_items;
-        const int j = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        return first + j * L;
-    };
-    int ncur = pop_item(), n1 = pop_item();
-
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)smem);
-    const unsigned char* zeros = (const unsigned char*)g.zeros;
-    unsigned char* stage0 = smem + 2 * kQws4Tile;
-
-    // LDS-DMA: 16 pieces of 8 rows x 128 B per tile; wave w moves channel chunk w (rows 8 k .. 8 k + 7, k = 0..3)
-    unsigned voff[4]; bool vrow[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int row = k * 8 + (lane >> 3);
-        vrow[k] = t0 + row < T;
-        voff[k] = (unsigned)((t0 + row) * 512 + wave * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
-    }
-    auto issue_tile = [&](int n, int slot) {
-        const bool unit = n < g.n_items;
-        const unsigned char* hb = (const unsigned char*)g.a0 + (size_t)((unit ? n : 0) % g.a0_mod) * T * 512;
-        const unsigned dst = lds0 + (unsigned)(slot * kQws4Tile + wave * 4096);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) glds16bo((unit && vrow[k]) ? hb + voff[k] : zeros, dst + k * 1024);
-    };
-    issue_tile(ncur, 0);
-
-    vec8 wf[2][16];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const unsigned char* wfrag = (const unsigned char*)g.w_frag + ((size_t)(plane * 8 + 2 * wave + a) * 16 * 64 + lane) * 16;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) wf[a][ks] = as_vec8<P>(*(const uint4*)(wfrag + ks * 1024));
-    }
-    const bool vplane = plane == 2;
-    // bias: the plane's 256 values parked in LDS (the accumulators start from it every tile; as two 16-register C operands it cost the
-    // kernel its last registers: 24 spilled).  v plane (lane = channel): one value per fragment.
-    float* biasT = (float*)(smem + 2 * kQws4Tile + 2 * kQws4Image + kQws4Rope);
-    biasT[tid] = g.bias ? g.bias[plane * 256 + tid] : 0.0f;
-    float bv[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) bv[a] = g.bias ? g.bias[plane * 256 + wave * 64 + a * 32 + l31] : 0.0f;
-    float* ropeT = (float*)(smem + 2 * kQws4Tile + 2 * kQws4Image);
-    if (plane < 2) {
-        const int fl = (tid & 127) >> 2, q = tid & 3;
-        const int tl = t0 + fl < T ? t0 + fl : T - 1;
-        const float4 v = *(const float4*)((tid < 128 ? g.rope_cos : g.rope_sin) + (size_t)tl * 16 + 4 * q);
-        *(float4*)(ropeT + (tid < 128 ? 0 : 32 * kQwsRopePitch) + fl * kQwsRopePitch + 4 * q) = v;
-    }
-    const float sc = plane == 0 ? g.qscale : 1.0f;
-    unsigned radr[4];
-#pragma unroll
-    for (int ksl = 0; ksl < 4; ++ksl) radr[ksl] = (unsigned)(l31 * 128 + (((ksl * 2 + hi) ^ ((l31 >> 1) & 7)) << 4));
-    unsigned char* sink = (unsigned char*)g.sink + (size_t)(blockIdx.x & 63) * 1024 + lane * 16;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(wf[a][ks]));
-        asm volatile("" : "+v"(bv[a]));
-    }
-    auto run_tiles = [&](auto vtag) {
-    constexpr bool V = decltype(vtag)::value;
-    auto store_rows = [&](int n_of, int ib) {
-        unsigned char* stage = stage0 + ib * kQws4Image;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2 += 2) {      // (two rows in flight: four cost the kernel its last registers)
-            uint4 rv[2]; unsigned char* rp[2];
-            if constexpr (!V) {      // 4 heads x 32 frames = 128 rows of 128 B, 8 rows per instruction
-                unsigned char* dst = (unsigned char*)(plane == 0 ? g.q : g.k);
-                const int rsub = lane >> 3, seg = lane & 7;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int rowid = ((k2 + k) * 4 + wave) * 8 + rsub;
-                    const int hd = rowid >> 5, f = rowid & 31;
-                    rv[k] = *(const uint4*)(stage + rowid * kQwsPitch + seg * 16);
-                    unsigned char* p = dst + (((size_t)n_of * H + hd) * T + t0 + f) * 128 + seg * 16;
-                    rp[k] = t0 + f < T ? p : sink;
-                }
-            } else {                 // 256 channel rows x 64 B, 16 rows per instruction
-                const int rsub = lane >> 2, seg = lane & 3;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int ch = ((k2 + k) * 4 + wave) * 16 + rsub;
-                    rv[k] = *(const uint4*)(stage + ch * 80 + seg * 16);
-                    const int tcol = t0 + seg * 8;
-                    unsigned char* p = (unsigned char*)g.vt + ((((size_t)n_of * H + (ch >> 6)) * 64 + (ch & 63)) * Tp + tcol) * 2;
-                    rp[k] = tcol < Tp ? p : sink;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if constexpr ((var & 2)) asm volatile("" :: "v"(rv[k].x), "v"(rv[k].y), "v"(rv[k].z), "v"(rv[k].w));
-                else store_row16(rp[k], rv[k]);
-            }
-        }
-    };
-    int slot = 0, nprev = g.n_items, last_ib = 0;
-    for (int i = 0; ; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (i <= 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if constexpr ((var & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        ST_RAW_BARRIER();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_tile(n1, slot ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i > 0) store_rows(nprev, (i - 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned char* stage = stage0 + (i & 1) * kQws4Image;
-        f32x16_t acc[2];
-        {
-            const unsigned base = lds0 + (unsigned)(slot * kQws4Tile);
-            unsigned ad[4];
-#pragma unroll
-            for (int ksl = 0; ksl < 4; ++ksl) ad[ksl] = base + radr[ksl];
-            // fragments in steps of two k-steps (K = 32), the next step's two reads flying under this step's four MFMAs (two sets
-            // of 2 fragments: the whole-chunk double buffer of the 8-wave kernel does not fit beside 128 weight registers)
-            vec8 bf[2][2];
-            auto load_step = [&](int st, int set) {      // st = 0..7: chunk st >> 1, k-steps 2 (st & 1), + 1
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bf[set][j] = as_vec8<P>(lds_read16(ad[(st & 1) * 2 + j] + (st >> 1) * 4096));
-            };
-            load_step(0, 0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    float4 b4;
-                    if constexpr (V) b4 = make_float4(bv[a], bv[a], bv[a], bv[a]);
-                    else b4 = *(const float4*)(biasT + wave * 64 + a * 32 + 8 * q4 + 4 * hi);
-                    acc[a][4 * q4 + 0] = b4.x; acc[a][4 * q4 + 1] = b4.y; acc[a][4 * q4 + 2] = b4.z; acc[a][4 * q4 + 3] = b4.w;
-                }
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                if (st < 7) load_step(st + 1, (st + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if constexpr (V) acc[a] = P::mfma(bf[st & 1][j], wf[a][st * 2 + j], acc[a]);
-                        else acc[a] = P::mfma(wf[a][st * 2 + j], bf[st & 1][j], acc[a]);
-                    }
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if constexpr (!V) {      // q / k: image [head][frame][64] (pitch 144 B); the wave's head, fragment a = dims 32 a .. + 32
-#pragma unroll
-            for (int q4 = 0; q4 < 2; ++q4) {      // RoPE in place on fragment 0 (dims 0..31 of the wave's head)
-                const float4 cs = *(const float4*)(ropeT + l31 * kQwsRopePitch + 8 * q4 + 4 * hi);
-                const float4 sn = *(const float4*)(ropeT + 32 * kQwsRopePitch + l31 * kQwsRopePitch + 8 * q4 + 4 * hi);
-                const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x1 = acc[0][4 * q4 + e], x2 = acc[0][4 * (q4 + 2) + e];
-                    rope_rot(x1, x2, cc[e], ss[e]);
-                    acc[0][4 * q4 + e] = x1; acc[0][4 * (q4 + 2) + e] = x2;
-                }
-            }
-            unsigned char* row = stage + (wave * 32 + l31) * kQwsPitch + 4 * hi * 2;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    *(uint2*)(row + a * 64 + 16 * q4) = scale_pack4<P>(acc[a][4 * q4 + 0], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3], sc);
-        } else {                 // v: image [channel][32 frames] (pitch 80 B), key order of the P.V operand
-            const bool tail = t0 + 32 > T;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int f0 = 8 * q4 + 4 * hi;
-                    const int pos = (q4 >> 1) * 16 + hi * 8 + (q4 & 1) * 4;
-                    float v0 = acc[a][4 * q4 + 0], v1 = acc[a][4 * q4 + 1], v2 = acc[a][4 * q4 + 2], v3 = acc[a][4 * q4 + 3];
-                    if (tail) {
-                        v0 = t0 + f0 + 0 < T ? v0 : 0.0f; v1 = t0 + f0 + 1 < T ? v1 : 0.0f;
-                        v2 = t0 + f0 + 2 < T ? v2 : 0.0f; v3 = t0 + f0 + 3 < T ? v3 : 0.0f;
-                    }
-                    *(uint2*)(stage + (wave * 64 + a * 32 + l31) * 80 + pos * 2) = pack4<P>(v0, v1, v2, v3);
-                }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        nprev = ncur; last_ib = i & 1;
-        if (n1 >= g.n_items) break;
-        ncur = n1; n1 = pop_item();
-        slot ^= 1;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    ST_RAW_BARRIER();
-    __builtin_amdgcn_sched_barrier(0);
-    store_rows(nprev, last_ib);
-    };
-    if (vplane) run_tiles(std::true_type{}); else run_tiles(std::false_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 template <class P>
 static hipError_t launch_qkv_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     static bool attr_done_dev[64] = {};
@@ -572,22 +335,6 @@ static hipError_t launch_qkv_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     }
     if (!a.zeros || !a.sink || !a.w_frag || a.cout != 768 || a.c0 != 256 || a.c1 || a.c2 || a.n_heads != 4 || !a.q || !a.k || !a.vt ||
         !a.rope_cos || !a.rope_sin || a.Tp < ((a.T + 63) & ~63) || a.w_item_stride || a.ksplit > 1) return hipErrorInvalidValue;
-    if (a.flags & GF_QWS4) {      // four waves, two blocks per CU (ST_QKV_WS=2)
-        static bool attr4_done_dev[64] = {};
-        if (!attr4_done_dev[dev_]) {
-            hipError_t e = hipFuncSetAttribute((const void*)qkv_ws4_kernel<P, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kQws4Lds);
-            if (e != hipSuccess) return e;
-            attr4_done_dev[dev_] = true;
-        }
-        const int tiles_f = a.Tp / 32;
-        int L = 170 / tiles_f;
-        if (L < 1) L = 1;
-        if (L < (a.n_items + 63) / 64) L = (a.n_items + 63) / 64;
-        if (L > a.n_items) L = a.n_items;
-        const int grid = ((3 * tiles_f * L + 7) / 8) * 8;
-        hipLaunchKernelGGL((qkv_ws4_kernel<P, 0>), dim3(grid), dim3(256), kQws4Lds, s, a, L);
-        return hipGetLastError();
-    }
     const int tiles_f = (a.T + 63) / 64;
     int L = 85 / tiles_f;
     if (L < 1) L = 1;

@@ -28,12 +28,17 @@ from .estimator import Decoder
 
 class CFMDecoder(nn.Module):
     def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels, n_heads,
-                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="f16", check_finite=False):
+                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="f16", check_finite=None):
         super().__init__()
         # check_finite=True: every forward() asks the engine whether its output contains NaN / Inf (one stream
         # synchronisation per call) and raises -- f16 operands overflow at 65504, which an fp32 checkpoint may exceed; the
         # remedy is operand_dtype="bf16" (INTEGRATION.md section 2).  Off by default: serving loops enqueue solves back to back.
-        self.check_finite = check_finite
+        # Exception: with the opt-in Winograd FFN (ST_FUSED_FFN=3, f16) the FFN intermediate overflows at |u| > 32,752 -- half the
+        # range of the default kernels -- so the check is ON unless the caller turns it off explicitly.
+        if check_finite is None:
+            import os
+            check_finite = operand_dtype == "f16" and os.environ.get("ST_FUSED_FFN") == "3"
+        self.check_finite = bool(check_finite)
         self.noise_channels = noise_channels
         self.cond_channels = cond_channels
         self.hidden_channels = hidden_channels
@@ -88,8 +93,8 @@ class CFMDecoder(nn.Module):
             if self.check_finite and eng.output_nonfinite(stream):
                 raise FloatingPointError(
                     "stabletts_amd: the solve produced NaN / Inf.  With operand_dtype='f16' an activation beyond 65504 "
-                    "overflows its MFMA operand: construct the decoder with operand_dtype='bf16' (same range as fp32), or "
-                    "check the inputs.")
+                    "overflows its MFMA operand (beyond 32752 for the FFN intermediate under ST_FUSED_FFN=3, the opt-in Winograd "
+                    "kernel: unset it): construct the decoder with operand_dtype='bf16' (same range as fp32), or check the inputs.")
         return out
 
     def _solve_with_torchdiffeq(self, mu, mask, n_timesteps, temperature, c, solver, cfg_kwargs, z):

@@ -1,5 +1,5 @@
 // Host-side check of the weight-layout index maps of stabletts_amd/csrc/common.h (compiled by tests/test_pack_index.py with
-// hipcc --cuda-host-only; no GPU): ffn_stream_index (both MFMA shapes, both stages) and qkv_frag_index must be bijections onto
+// hipcc --cuda-host-only; no GPU): ffn_stream_index (both stages) and qkv_frag_index must be bijections onto
 // their buffers, and every source element must be hit exactly once; ffn_wino_index likewise (three planes per tap triple).
 #include <cstdio>
 #include <vector>
@@ -8,14 +8,14 @@
 int main() {
     int bad = 0;
     for (int F : {256, 512, 1024, 2048})
-        for (int shape = 0; shape < 2; ++shape) {
+        {
             const size_t n = (size_t)F * 256 * 3;
             std::vector<unsigned char> dst(2 * n, 0);
             for (int stage = 0; stage < 2; ++stage) {
                 std::vector<unsigned char> src(n, 0);
                 for (size_t idx = 0; idx < n; ++idx) {
                     size_t so, dof;
-                    st::ffn_stream_index(idx, stage | (shape << 1), F, &so, &dof);
+                    st::ffn_stream_index(idx, stage, F, &so, &dof);
                     if (so >= n || dof >= 2 * n) { ++bad; continue; }
                     ++src[so]; ++dst[dof];
                 }

@@ -315,11 +315,12 @@ def oracle_trajectories(sd):
 def test_training_trajectory_matches_the_fp32_oracle(sd, oracle_trajectories, lr):
     """Config 5's end-to-end statement: K = 12 AdamW steps through the NATIVE forward / backward (f16 operands, the shipping
     type; in-place weight updates re-packed on the stream) against the same K steps through the fp32 oracle on the same
-    draws.  Per step the loss must agree to 1e-3; after K steps EVERY parameter tensor -- conv_q / conv_k, whose single-step
-    gradient is ill-conditioned at random init, included -- must sit within 2e-3 of the oracle's (max |d| / max |ref|), and the
-    accumulated UPDATE theta_K - theta_0 of every tensor must point the same way (cosine; Adam normalises each element's step to
-    ~lr, so an element whose tiny gradient flips sign moves by 2 lr whatever the backward's accuracy: the max-norm of the update
-    difference is printed, the cosine is gated)."""
+    draws.  What is asserted: per step the loss agrees to 1e-3; after K steps the accumulated UPDATE theta_K - theta_0 of EVERY
+    parameter tensor -- conv_q / conv_k, whose single-step gradient is ill-conditioned at random init, included -- points the
+    oracle's way (cosine >= 0.995) and no single element is more than 3 lr off the oracle's value.  (Not asserted, printed: the
+    max-norm difference of the parameters and of the updates -- Adam normalises each element's step to ~lr, so an element whose
+    tiny gradient flips sign moves by 2 lr per step whatever the backward's accuracy; for small-valued tensors that is up to 9e-3
+    of max |theta|)"""
     inp = oracle_trajectories["inp"]
     ref = oracle_trajectories["runs"][lr]
     dec = _decoder(sd, "f16")                      # eval mode: dropout off (the masks are covered by their own test)

@@ -1,5 +1,5 @@
-"""CPU check of the weight-layout index maps the kernels and the packers share (csrc/common.h: ffn_stream_index for both MFMA
-shapes, qkv_frag_index): compiled for the HOST with hipcc, no GPU."""
+"""CPU check of the weight-layout index maps the kernels and the packers share (csrc/common.h: ffn_stream_index, ffn_wino_index,
+qkv_frag_index): compiled for the HOST with hipcc, no GPU."""
 import os
 import shutil
 import subprocess
@@ -22,19 +22,14 @@ def test_weight_stream_and_fragment_maps_are_bijections(tmp_path):
 
 
 def test_fragment_layouts_are_bank_conflict_free():
-    """tools/lds_bank_check.py: the 32x32x16 B-fragment read, the 16x16x32 read under ROWMAP (and its 2-way conflict without it),
-    under the ds_read_b128 lane-group model of MI355X_MICROARCH.md."""
+    """tools/lds_bank_check.py: the 32x32x16 B-fragment read and the Winograd kernel's pair-interleaved raw rows under the
+    ds_read_b128 lane-group model of MI355X_MICROARCH.md."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("lds_bank_check", os.path.join(ROOT, "tools", "lds_bank_check.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     w32 = max(m.worst(lambda l: m.swz(base + tap + (l & 31), 2 * ks + (l >> 5))) for base in (0, 32, 64, 96) for tap in range(3) for ks in range(4))
     assert w32 == 1
-    for rm, want in ((lambda n: n, 2), (m.rowmap, 1)):
-        w16 = max(m.worst(lambda l: m.swz(wf * 64 + b * 16 + tap + rm(l & 15), 4 * kp + (l >> 4)))
-                  for wf in range(2) for b in range(4) for tap in range(3) for kp in range(2))
-        assert w16 == want
-    assert sorted(m.rowmap(n) for n in range(16)) == list(range(16))
     # the Winograd fused FFN's raw rows: lane i reads row 2 i + e; pair-interleaved storage is conflict-free, the plain layout is not
     for lay, want in ((m.swz, 2), (m.pair_interleaved, 1)):
         ww = max(m.worst(lambda l: lay(2 * (32 * b + (l & 31)) + e, 2 * ks + (l >> 5))) for b in range(2) for e in range(4) for ks in range(4))

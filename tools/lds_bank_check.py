@@ -6,18 +6,11 @@ MI355X_MICROARCH.md, LDS table); a group is conflict-free when its 16 x 16 B hit
 row.  The operand images are [row][64 channels] with 128-byte rows and the 16-byte chunk index XOR-swizzled by (row >> 1) & 7.
 
 * 32x32x16 B-fragment (conv kernels, ffn_fused.h, qkv_ws.hip): lane l reads chunk 2 ks + (l >> 5) of row base + (l & 31).
-* 16x16x32 B-fragment (ffn_fused16.h): lane l reads chunk 4 kp + (l >> 4) of row base + tap + ROWMAP(l & 15); with the
-  identity map every odd tap is a 2-way conflict, ROWMAP (8 even rows for one k-group, 8 odd rows for the other) is free.
 * Winograd raw rows (ffn_wino.h): lane l reads chunk 2 ks + (l >> 5) of row 2 (32 b + (l & 31)) + e, e = 0..3: a two-row stride, 2-way
   conflicts in the plain layout, free in the pair-interleaved one.
-* the fp32 park of the 16x16x32 accumulators ([frame][260] float4 stores, 8 contiguous lanes per group, 32 banks).
 """
 G = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
 GROUPS = G + [[x + 32 for x in g] for g in G]
-
-
-def rowmap(n):
-    return 2 * n if n < 4 else (2 * n - 7 if n < 12 else 2 * n - 16)
 
 
 def worst(addr_of_lane):
@@ -48,17 +41,3 @@ if __name__ == "__main__":
         print("Winograd raw-row reads (row 2 i + e),", name, "layout: worst", ww, "-way")
     w32 = max(worst(lambda l: swz(base + tap + (l & 31), 2 * ks + (l >> 5))) for base in (0, 32, 64, 96) for tap in range(3) for ks in range(4))
     print("32x32x16 B-fragment reads, all taps / k-steps: worst", w32, "-way")
-    for name, rm in (("identity", lambda n: n), ("ROWMAP", rowmap)):
-        w16 = max(worst(lambda l: swz(wf * 64 + b * 16 + tap + rm(l & 15), 4 * kp + (l >> 4)))
-                  for wf in range(2) for b in range(4) for tap in range(3) for kp in range(2))
-        print(f"16x16x32 B-fragment reads, row map {name}: worst {w16}-way")
-    wp = 0
-    for a in range(4):
-        for b in range(4):
-            for g0 in range(0, 64, 8):
-                slots = {}
-                for l in range(g0, g0 + 8):
-                    s = ((b * 16 + rowmap(l & 15)) * 260 + a * 16 + 4 * (l >> 4)) % 32 // 4
-                    slots[s] = slots.get(s, 0) + 1
-                wp = max(wp, max(slots.values()))
-    print("16x16x32 accumulator park (float4 stores):", wp, "-way")

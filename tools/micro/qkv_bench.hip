@@ -54,22 +54,6 @@ int main(int argc, char** argv) {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipGetLastError());
                 printf("N %2d L %2d grid %3d (%.1f tiles per block) var %2d : %6.1f us\n", N, L, grid, (double)N * tiles_f / (tiles_f * L), VAR, ms * 1000 / reps);
             };
-            {   // the 4-wave / two-blocks-per-CU cut (qkv_ws4_kernel)
-                CK(hipFuncSetAttribute((const void*)qkv_ws4_kernel<OpF16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kQws4Lds));
-                CK(hipFuncSetAttribute((const void*)qkv_ws4_kernel<OpF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kQws4Lds));
-                const int tf4 = Tp / 32; int L4 = 170 / tf4; if (L4 < 1) L4 = 1; if (L4 > N) L4 = N;
-                const int grid4 = ((3 * tf4 * L4 + 7) / 8) * 8;
-                for (int v = 0; v < 2; ++v) {
-                    const int reps = 20;
-                    auto go = [&]() { if (v == 0) hipLaunchKernelGGL((qkv_ws4_kernel<OpF16, 0>), dim3(grid4), dim3(256), kQws4Lds, s, a, L4);
-                                      else hipLaunchKernelGGL((qkv_ws4_kernel<OpF16, 2>), dim3(grid4), dim3(256), kQws4Lds, s, a, L4); };
-                    go(); CK(hipEventRecord(e0, s));
-                    for (int i = 0; i < reps; ++i) go();
-                    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
-                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipGetLastError());
-                    printf("N %2d 4-wave cut: L %2d grid %3d (%.1f 32-frame tiles per block) var %d : %6.1f us\n", N, L4, grid4, (double)N / L4, v * 2, ms * 1000 / reps);
-                }
-            }
             run(std::integral_constant<int, 0>{}); run(std::integral_constant<int, 2>{}); run(std::integral_constant<int, 4>{});
             run(std::integral_constant<int, 6>{}); run(std::integral_constant<int, 14>{}); run(std::integral_constant<int, 22>{});
             run(std::integral_constant<int, 30>{}); run(std::integral_constant<int, 38>{});
