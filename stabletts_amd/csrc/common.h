@@ -154,12 +154,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 // The trailing s_nop covers the store-data hazard that hipcc cannot see behind inline asm (guide 5.7).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+#if !defined(ST_ROW_STORE_POLICY) && defined(ST_ROW_STORE_POL)      // A/B builds: -DST_ROW_STORE_POL=n
+#if ST_ROW_STORE_POL == 1
+#define ST_ROW_STORE_POLICY "nt"
+#elif ST_ROW_STORE_POL == 2
+#define ST_ROW_STORE_POLICY "sc1 nt"
+#elif ST_ROW_STORE_POL == 3
+#define ST_ROW_STORE_POLICY "sc0 sc1"
+#elif ST_ROW_STORE_POL == 4
+#define ST_ROW_STORE_POLICY "sc0 sc1 nt"
+#endif
+#endif
+#ifndef ST_ROW_STORE_POLICY
+#define ST_ROW_STORE_POLICY "sc1"
+#endif
 __device__ __forceinline__ void store_row16(void* p, uint4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off " ST_ROW_STORE_POLICY "\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
 }
 __device__ __forceinline__ void store_row16(void* p, float4 v) { store_row16(p, __builtin_bit_cast(uint4, v)); }
 __device__ __forceinline__ void store_row8(void* p, uint2 v) {
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x2_t, v)) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off " ST_ROW_STORE_POLICY "\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x2_t, v)) : "memory");
+}
+
+// a residual row that this block reads exactly once (the epilogue's x rows): ST_NT_RES=1 loads it non-temporally (A/B switch)
+#ifndef ST_NT_RES
+#define ST_NT_RES 0
+#endif
+__device__ __forceinline__ float4 ld_row16_once(const float* p) {
+#if ST_NT_RES
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    const f32x4_nt v = __builtin_nontemporal_load((const f32x4_nt*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *(const float4*)p;
+#endif
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -197,6 +225,24 @@ __device__ __forceinline__ void glds16bo(const void* gsrc, unsigned lds_off) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+// The same piece with the NON-TEMPORAL hint, for activation rows that one block streams once (residual rows, attention output,
+// the FFN / long-skip operand tiles): they do not displace what the L2 is kept for -- weights every CU re-reads, K / V tiles shared
+// by a group's query tiles.  BUILD-TIME A/B SWITCH, OFF (-DST_NT_DMA=1 turns it on): round 5 measured it -1.1 % on the single-sequence
+// solve (q/k/v, out projection and attention gain), 0.0 % on the default two-part solve and +1.5 % (slower) on a ragged batch, paired
+// (profiles/r05_ab_nt_dma.txt).  Never for the q/k/v projection's tile, which the three plane blocks of an XCD read one after another
+// (there nt costs 8 %, profiles/r05_ab_store_policy.txt).
+#ifndef ST_NT_DMA
+#define ST_NT_DMA 0
+#endif
+__device__ __forceinline__ void glds16bo_nt(const void* gsrc, unsigned lds_off) {
+#if ST_NT_DMA
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+#else
+    glds16bo(gsrc, lds_off);
+#endif
 }
 // the 4-byte-per-lane form (64 lanes x 4 B = 256 B at lds_off + 4 lane): for fp32 rows whose start is only dword-aligned
 __device__ __forceinline__ void glds4bo(const void* gsrc, unsigned lds_off) {

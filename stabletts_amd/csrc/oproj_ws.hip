@@ -35,6 +35,17 @@ constexpr int kOwsLds = kOwsRing * kOwsSlot + 1024 + 256;      // + one sink KiB
 
 #define ST_RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// Developer ablations (-DST_DEVTOOLS -DST_OWS_VAR=bits; results are garbage unless 0 or 1): 1 = write-back instead of write-through row
+// stores, 2 = the fp32 x_2 rows go to the sink (no residual write traffic), 4 = the 16-bit operand rows go to the sink, 8 = the residual
+// rows are not fetched (zero page), 16 = the attention-output tile is not fetched, 32 = no MFMAs.
+#if defined(ST_OWS_VAR) && !defined(ST_DEVTOOLS)
+#error "ST_OWS_VAR (ablation builds: results are garbage) needs -DST_DEVTOOLS"
+#endif
+#ifndef ST_OWS_VAR
+#define ST_OWS_VAR 0
+#endif
+constexpr int kOwsVar = ST_OWS_VAR;
+
 template <class P>
 __global__ __launch_bounds__(512, 1)
 void oproj_ws_kernel(const ConvGemmArgs g, int L) {
@@ -102,9 +113,9 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
         const unsigned base = lds0 + (unsigned)(slot * kOwsSlot);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            glds16bo((unit && vrowA[k]) ? ab + voffA[k] : zeros, base + (unsigned)((wave >> 1) * 4096 + (wave & 1) * 2048 + k * 1024));
+            glds16bo_nt((unit && vrowA[k] && !(kOwsVar & 16)) ? ab + voffA[k] : zeros, base + (unsigned)((wave >> 1) * 4096 + (wave & 1) * 2048 + k * 1024));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) glds16bo((unit && vrowX[k]) ? xb + voffX[k] : zeros, base + (unsigned)(kOwsAo + (wave * 4 + k) * kOwsXPitch));
+        for (int k = 0; k < 4; ++k) glds16bo_nt((unit && vrowX[k] && !(kOwsVar & 8)) ? xb + voffX[k] : zeros, base + (unsigned)(kOwsAo + (wave * 4 + k) * kOwsXPitch));
         {   // waves 0, 1, 2: the item's gate / adaLN shift / adaLN scale rows; wave 3: the frame mask of the tile's 32 frames (a row
             // that is only dword-aligned: 4-byte pieces, frames past T clamped like the generic epilogue); waves 4..7: zero page -> sink
             const float* ad = g.ln_ada + (size_t)nn * g.ln_ada_stride;
@@ -179,7 +190,7 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int ksl = 0; ksl < 4; ++ksl) acc = P::mfma(wf[c * 4 + ksl], bf[c & 1][ksl], acc);
+                for (int ksl = 0; ksl < 4; ++ksl) { if constexpr (kOwsVar & 32) asm volatile("" :: "v"(bf[c & 1][ksl])); else acc = P::mfma(wf[c * 4 + ksl], bf[c & 1][ksl], acc); }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -223,7 +234,8 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float* p = g.out32 + ((size_t)ncur * T + tt[u]) * 256 + ch;
-                store_row16(ok[u] ? (void*)p : (void*)sink, v[u]);
+                void* dst = (ok[u] && !(kOwsVar & 2)) ? (void*)p : (void*)sink;
+                if constexpr (kOwsVar & 1) *(float4*)dst = v[u]; else store_row16(dst, v[u]);
             }
             float mean[4], var[4];
 #pragma unroll
@@ -240,7 +252,8 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
                 const float h0 = (v[u].x * rs * (1.0f + sc.x) + sh.x) * mm, h1 = (v[u].y * rs * (1.0f + sc.y) + sh.y) * mm;
                 const float h2 = (v[u].z * rs * (1.0f + sc.z) + sh.z) * mm, h3 = (v[u].w * rs * (1.0f + sc.w) + sh.w) * mm;
                 unsigned char* p = (unsigned char*)g.ln_h16 + (((size_t)ncur * T + tt[u]) * 256 + ch) * 2;
-                store_row8(ok[u] ? (void*)p : (void*)sink, pack4<P>(h0, h1, h2, h3));
+                void* dst = (ok[u] && !(kOwsVar & 4)) ? (void*)p : (void*)sink;
+                if constexpr (kOwsVar & 1) *(uint2*)dst = pack4<P>(h0, h1, h2, h3); else store_row8(dst, pack4<P>(h0, h1, h2, h3));
             }
         }
         if (n1 >= g.n_items) break;
@@ -263,6 +276,7 @@ static hipError_t launch_oproj_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     if (!a.zeros || !a.sink || !a.w_frag || a.cout != 256 || a.c0 != 256 || a.c1 || a.c2 || !a.out32 || !a.ln_h16 || a.ln_film || !a.ln_ada ||
         !a.gate || a.out16 || a.res32 || a.branch32 || a.out32_readonly || a.add32 || a.w_item_stride || a.ksplit > 1) return hipErrorInvalidValue;
     const int tiles_f = (a.T + 31) / 32;
+    // (block count: 192, 224 and 256 blocks measured the same inside the solve, paired -- profiles/r05_ab_attn_xcd_ws_blocks.txt)
     int L = 240 / tiles_f;
     if (L < 1) L = 1;
     if (L < (a.n_items + 63) / 64) L = (a.n_items + 63) / 64;      // a block's work list is a 64-bit mask

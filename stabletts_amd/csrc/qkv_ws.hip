@@ -323,13 +323,20 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
 #undef QWS_STAMP
 }
 
+#if defined(ST_QWS_VAR) && !defined(ST_DEVTOOLS)
+#error "ST_QWS_VAR (ablation builds: results are garbage) needs -DST_DEVTOOLS"
+#endif
+#ifndef ST_QWS_VAR
+#define ST_QWS_VAR 0
+#endif
+
 template <class P>
 static hipError_t launch_qkv_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     static bool attr_done_dev[64] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_done_dev[dev_]) {
-        hipError_t e = hipFuncSetAttribute((const void*)qkv_ws_kernel<P, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds);
+        hipError_t e = hipFuncSetAttribute((const void*)qkv_ws_kernel<P, ST_QWS_VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds);
         if (e != hipSuccess) return e;
         attr_done_dev[dev_] = true;
     }
@@ -341,7 +348,7 @@ static hipError_t launch_qkv_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     if (L < (a.n_items + 63) / 64) L = (a.n_items + 63) / 64;      // a block's work list is a 64-bit mask
     if (L > a.n_items) L = a.n_items;
     const int grid = ((3 * tiles_f * L + 7) / 8) * 8;
-    hipLaunchKernelGGL((qkv_ws_kernel<P, 0>), dim3(grid), dim3(512), kQwsLds, s, a, L);
+    hipLaunchKernelGGL((qkv_ws_kernel<P, ST_QWS_VAR>), dim3(grid), dim3(512), kQwsLds, s, a, L);
     return hipGetLastError();
 }
 

@@ -20,8 +20,12 @@ fs, fc = oracle.make_cfg_params(4321)
 g = {k: v.cuda() for k, v in make_inputs(32, 1000, seed=0, ragged=RAGGED).items() if k != "lengths"}
 kw = dict(fake_speaker=fs.cuda(), fake_content=fc.cuda(), cfg_strength=3.0)
 decs = []
+from stabletts_amd import _lib as _stlib
+_default_lib = _stlib.LIB_PATH
 for c in cfgs:
     for k, v in c.items(): os.environ[k] = v
+    # a configuration may name its own build of the library (STABLETTS_HIP_LIB=path): an Engine keeps the CDLL it was created with
+    _stlib.LIB_PATH, _stlib._lib = c.get("STABLETTS_HIP_LIB", _default_lib), None
     d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256).cuda()
     d.estimator.load_state_dict(sd); d.estimator.engine()
     for k in c: del os.environ[k]
