@@ -162,7 +162,7 @@ def class_kernel(cls, dtype):
 
 def _pmc_table():
     """Committed rocprofv3 PMC passes of this same command (newest round first)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic_before_wino.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", name))), name
         except Exception:
