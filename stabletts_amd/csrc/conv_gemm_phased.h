@@ -36,6 +36,10 @@
 #include <type_traits>
 #include "conv_gemm2_impl.h"
 
+#ifndef ST_PRIO_PHASED
+#define ST_PRIO_PHASED 0      // 1: s_setprio 1 around the MFMA clusters (the round-4 form; without it the solve is 0.2-0.5 % faster per kernel family, paired: profiles/r05_ab_setprio.txt)
+#endif
+
 namespace st {
 
 #define ST_RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -175,7 +179,7 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
         for (int b = 0; b < FF; ++b) afr[b] = as_vec8<P>(lds_read16(aad + b * 4096));
     };
     auto mma = [&](bool first) {      // first: compile-time after unrolling (the first phase of the first chunk)
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (ST_PRIO_PHASED) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < FC; ++a)
 #pragma unroll
@@ -183,7 +187,7 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
                 if constexpr (BIAS_C) acc[a][b] = P::mfma(wfr[a], afr[b], first ? bt[a] : acc[a][b]);
                 else acc[a][b] = P::mfma(wfr[a], afr[b], acc[a][b]);
             }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (ST_PRIO_PHASED) __builtin_amdgcn_s_setprio(0);
     };
     // One phase = fragment reads (+ this phase's LDS-DMA issues), reads retired, 8 MFMAs, with ONE barrier: group 0 takes
     // it between its reads and its MFMAs, group 1 before its reads -- so between two barriers group 0 runs [M(p-1) R(p)]

@@ -76,7 +76,7 @@ template <int N> __device__ __forceinline__ void ffn_dma_wait() {
 //      read in the interval that ends with barrier #p).
 // ABL (developer ablations, tools only; results are garbage): 1 = no epilogue, 2 = no SiLU arithmetic, 4 = the weight stream
 //      re-reads its first slabs (cache-hot source), 8 = no top-of-phase waits, 16 = no LDS-DMA inside the loop, 32 = no MFMAs,
-//      64 = s_memtime stamps per phase segment (g.dbg).  VAR bit 2 = no s_setprio around the MFMAs, bit 3 = software-pipelined
+//      64 = s_memtime stamps per phase segment (g.dbg).  VAR bit 2 = s_setprio 1 around the MFMAs (the round-4 default; round 5: without it the solve is 0.4-0.8 % faster, paired -- profiles/r05_ab_setprio.txt), bit 3 = software-pipelined
 //      phases without the group stagger (FF_PHASE_P).
 template <class P, int ABL, int VAR>
 __global__ __launch_bounds__(512, 1)
@@ -241,7 +241,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
         FF_STAMP(2)                                                                              \
         ST_BARRIER_IF(ngrp);                                                                     \
         FF_STAMP(3)                                                                              \
-        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);                                 \
+        if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(1);                                 \
         FF_MMA(ACC, 0)                                                                           \
         if constexpr (PLACE) {                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -249,7 +249,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
         FF_MMA(ACC, 1)                                                                           \
-        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);                                 \
+        if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(0);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         roff += SLAB; if (roff == RING * SLAB) roff = 0;                                         \
         woff += SLAB; if (woff == RING * SLAB) woff = 0;                                         \
@@ -275,7 +275,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
         FF_LOAD_HALF(1, roff, AR, J, KP)                                                         \
         FF_ISSUE(LP)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);                                 \
+        if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(1);                                 \
         FF_MMA(ACC, 0)                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         roff += SLAB; if (roff == RING * SLAB) roff = 0;                                         \
@@ -284,7 +284,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
         if constexpr ((LP) != 23 && (LP) != 47) FF_LOAD_HALF(0, roff, (((LP) + 1) % 24) / 6, (((LP) + 1) % 6) / 2, ((LP) + 1) & 1) \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         FF_MMA(ACC, 1)                                                                           \
-        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);                                 \
+        if constexpr (VAR & 4) __builtin_amdgcn_s_setprio(0);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
 #define FF_PHASE(ACC, AR, J, KP, LP)                                                             \

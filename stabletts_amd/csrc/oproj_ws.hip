@@ -26,6 +26,10 @@
 #include "launch.h"
 #include <type_traits>
 
+#ifndef ST_PRIO_OWS
+#define ST_PRIO_OWS 0      // 1: s_setprio 1 around the MFMA clusters (the round-4 form; without it the solve is 0.2-0.5 % faster per kernel family, paired: profiles/r05_ab_setprio.txt)
+#endif
+
 namespace st {
 
 constexpr int kOwsAo = 32 * 512, kOwsXPitch = 1040, kOwsX = 32 * kOwsXPitch, kOwsConst = 3 * 1024 + 256;
@@ -188,10 +192,10 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
             for (int c = 0; c < 4; ++c) {
                 if (c < 3) load_chunk(c + 1, (c + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
+                if constexpr (ST_PRIO_OWS) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ksl = 0; ksl < 4; ++ksl) { if constexpr (kOwsVar & 32) asm volatile("" :: "v"(bf[c & 1][ksl])); else acc = P::mfma(wf[c * 4 + ksl], bf[c & 1][ksl], acc); }
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (ST_PRIO_OWS) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -35,6 +35,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef ST_PRIO_QWS
+#define ST_PRIO_QWS 0      // 1: s_setprio 1 around the MFMA clusters (the round-4 form; without it the solve is 0.2-0.5 % faster per kernel family, paired: profiles/r05_ab_setprio.txt)
+#endif
+
 namespace st {
 
 constexpr int kQwsTile = 64 * 512, kQwsRing = 2, kQwsPitch = 144, kQwsImage = 256 * kQwsPitch;      // 32,768 / 36,864 B
@@ -238,7 +242,7 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
                 for (int c = 0; c < 4; ++c) {
                     if (c < 3) load_chunk(c + 1, (c + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
+                    if constexpr (ST_PRIO_QWS) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int ksl = 0; ksl < 4; ++ksl)
 #pragma unroll
@@ -252,7 +256,7 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
                                 else acc[b] = P::mfma(wf[c * 4 + ksl], bf[c & 1][ksl][b], acc[b]);
                             }
                         }
-                    __builtin_amdgcn_s_setprio(0);
+                    if constexpr (ST_PRIO_QWS) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
