@@ -99,7 +99,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
 
     const int total = g.n_items * g.tiles_f;
     const int per_xcd = gridDim.x >> 3;
-    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // (tiles dealt round-robin to the XCDs instead: +0.3 % all-ones, -0.5 % ragged, paired -- profiles/r05_ab_prio_ffnrr.txt)
     if (lin >= total) return;
     const int tf = lin % g.tiles_f, n = lin / g.tiles_f;
     const int t0 = tf * FV;
