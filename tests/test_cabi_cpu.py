@@ -171,3 +171,34 @@ def test_vocoder_config_limits(lib):
         cfg = StVocosConfig(**{**ok, **bad})
         assert lib.st_create_vocoder(ctypes.byref(cfg), 0, ctypes.byref(h)) == code, bad
         assert lib.st_last_error(None)
+
+
+def test_winograd_opt_in_turns_the_finite_check_on(monkeypatch):
+    """The FFN default is the direct fused kernel; the Winograd form (ST_FUSED_FFN=3, f16 only) halves the f16 range of the FFN
+    intermediate, so a decoder created under it checks its output by itself (an explicit check_finite wins either way)."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    args = (128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256)
+    monkeypatch.delenv("ST_FUSED_FFN", raising=False)
+    assert CFMDecoder(*args).check_finite is False
+    monkeypatch.setenv("ST_FUSED_FFN", "3")
+    assert CFMDecoder(*args).check_finite is True
+    assert CFMDecoder(*args, operand_dtype="bf16").check_finite is False      # bf16 engines never run the Winograd kernel
+    assert CFMDecoder(*args, check_finite=False).check_finite is False
+    monkeypatch.setenv("ST_FUSED_FFN", "1")
+    assert CFMDecoder(*args).check_finite is False and CFMDecoder(*args, check_finite=True).check_finite is True
+
+
+def test_bench_refuses_engine_changing_environment():
+    """bench.py describes the library as shipped: with an ST_* variable that changes which kernels run (or STABLETTS_HIP_LIB) it
+    refuses before touching the device; ST_SPLIT / ST_HIP_GRAPH only change how the same kernels are enqueued and pass."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ST_") and k != "STABLETTS_HIP_LIB"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env={**env, "ST_FUSED_FFN": "3"},
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to measure" in (r.stderr + r.stdout) and "ST_FUSED_FFN" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env={**env, "ST_SPLIT": "1"},
+                       capture_output=True, text=True, timeout=300)
+    assert "refusing to measure" not in (r.stderr + r.stdout)       # (on a CPU-only box it then stops at "needs a HIP device")
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a HIP device" in (r.stderr + r.stdout)
