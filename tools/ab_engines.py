@@ -3,7 +3,9 @@
 read at st_create (and visible at solve time: ST_SPLIT); the headline solve (B=32 x T=1000, 10 Euler steps, CFG) alternates between the two engines so that clock /
 thermal drift hits both alike.  ONLY for configurations with the same number of solve parts: two engines' part streams share the
 process's hardware queues, and a 4-part engine next to a 2-part one measured 30.7 ms instead of its 24.4 -- compare part counts in
-separate processes, alternating (tools/r04b_session10.sh).     usage: python tools/ab_engines.py "ST_FUSED_FFN=1" "ST_FUSED_FFN=2" [rounds] [per_round]"""
+separate processes, alternating (tools/r04b_session10.sh).  A configuration may also name its own BUILD of the library
+(STABLETTS_HIP_LIB=/path/variant.so, e.g. ST_BUILD_DEFS=-DST_NT_DMA=1 ST_BUILD_OUT=... python -m stabletts_amd.build): both libraries are
+loaded into the one process.     usage: python tools/ab_engines.py "" "ST_FUSED_FFN=3" [rounds] [per_round]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
