@@ -67,14 +67,18 @@ int vocos_finalize(st_engine* e) {
     {
         Conv& h = v->head;
         const int bins = c.n_fft / 2 + 1, planes = 2 * kVocHeadPlane;
-        h.cout = planes; h.cin = C; h.taps = 1; h.split = false;
-        if ((rc = dev_alloc(e, &h.w, (size_t)planes * C * 2))) return rc;
+        // split-precision operands (round 5), as for the decoder's in_proj / final_proj: the head's output x feeds exp(x) -- an absolute
+        // error of x is a RELATIVE error of the magnitude -- so the 16-bit rounding of its operands reached the waveform un-attenuated
+        // (f16: hidden 4.8e-4 -> audio 1.1e-3).  K = [h_hi | h_lo | h_hi] against [W_hi | W_hi | W_lo]: 3x the MFMA work of one small GEMM.
+        h.cout = planes; h.cin = 3 * C; h.taps = 1; h.split = true;
+        if ((rc = dev_alloc(e, &h.w, (size_t)planes * 3 * C * 2))) return rc;
         if ((rc = dev_alloc(e, (void**)&h.bias, (size_t)planes * 4))) return rc;
-        HIPCHK(e, hipMemsetAsync(h.w, 0, (size_t)planes * C * 2, s));
+        HIPCHK(e, hipMemsetAsync(h.w, 0, (size_t)planes * 3 * C * 2, s));
         HIPCHK(e, hipMemsetAsync(h.bias, 0, (size_t)planes * 4, s));
         const float* W = P(e, "head.out.weight"); const float* Bv = P(e, "head.out.bias");
         for (int part = 0; part < 2; ++part) {       // head.py:104: mag, p = x.chunk(2, dim=1)
-            HIPCHK(e, launch_pack_weight(e->dt, W + (size_t)part * bins * C, bins, C, 1, 0, C, h.w, part * kVocHeadPlane, C, 0, C, 0, s));
+            for (int k3 = 0; k3 < 3; ++k3)
+                HIPCHK(e, launch_pack_weight(e->dt, W + (size_t)part * bins * C, bins, C, 1, 0, C, h.w, part * kVocHeadPlane, 3 * C, k3 * C, C, k3 == 2, s));
             HIPCHK(e, hipMemcpyAsync(h.bias + part * kVocHeadPlane, Bv + (size_t)part * bins, (size_t)bins * 4, hipMemcpyDeviceToDevice, s));
         }
     }
@@ -135,10 +139,10 @@ int st_vocos_forward(st_engine* e, const float* mel, float* audio, int B, int T,
     // workspace: im2col rows, fp32 residual stream, 16-bit operands, head output, windowed frames
     size_t off = 0;
     auto want = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_a16 = want((size_t)R * 7 * M * 2), o_x = want((size_t)R * C * 4), o_h16 = want((size_t)R * C * 2);
+    const size_t o_a16 = want((size_t)R * 7 * M * 2), o_x = want((size_t)R * C * 4), o_h16 = want((size_t)R * C * 2), o_h16lo = want((size_t)R * C * 2);
     const size_t o_u16 = want((size_t)R * F * 2), o_head = want((size_t)R * 2 * kVocHeadPlane * 4), o_fr = want((size_t)R * kVocNfft * 4);
     int rc = ensure_ws(e, off); if (rc) return rc;
-    void* a16 = e->ws + o_a16; float* x = (float*)(e->ws + o_x); void* h16 = e->ws + o_h16; void* u16 = e->ws + o_u16;
+    void* a16 = e->ws + o_a16; float* x = (float*)(e->ws + o_x); void* h16 = e->ws + o_h16; void* h16lo = e->ws + o_h16lo; void* u16 = e->ws + o_u16;
     float* head = (float*)(e->ws + o_head); float* frames = (float*)(e->ws + o_fr);
 
     auto args = [&](const Conv& cv) {
@@ -153,7 +157,7 @@ int st_vocos_forward(st_engine* e, const float* mel, float* audio, int B, int T,
         HIPCHK(e, launch_voc_im2col7(e->dt, mel, B, M, T, a16, s));
         ConvGemmArgs a = args(v->embed); a.a0 = a16; a.c0 = 7 * M; a.out32 = x;
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
-        HIPCHK(e, launch_voc_ln(e->dt, x, P(e, "backbone.norm.weight"), P(e, "backbone.norm.bias"), R, x, nullptr, s));
+        HIPCHK(e, launch_voc_ln(e->dt, x, P(e, "backbone.norm.weight"), P(e, "backbone.norm.bias"), R, x, nullptr, nullptr, s));
     }
     if (cap) capture(e, "voc.embed", x, R * C, false, s);
     for (int i = 0; i < L; ++i) {       // ConvNeXtBlock.forward (module.py:33-46)
@@ -178,8 +182,8 @@ int st_vocos_forward(st_engine* e, const float* mel, float* audio, int B, int T,
     {   // final LayerNorm (backbone.py:55) + head projection (head.py:103)
         ProfScope ps(e, s, PC_FINAL, 2.0 * R * C * (double)(c.n_fft + 2));
         HIPCHK(e, launch_voc_ln(e->dt, x, P(e, "backbone.final_layer_norm.weight"), P(e, "backbone.final_layer_norm.bias"), R,
-                                cap ? x : nullptr, h16, s));
-        ConvGemmArgs a = args(v->head); a.a0 = h16; a.c0 = C; a.out32 = head;
+                                cap ? x : nullptr, h16, h16lo, s));
+        ConvGemmArgs a = args(v->head); a.a0 = h16; a.c0 = C; a.a1 = h16lo; a.c1 = C; a.c2 = C; a.out32 = head;
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
     if (cap) { capture(e, "voc.hidden", x, R * C, false, s); capture(e, "voc.head_out", head, R * 2 * kVocHeadPlane, false, s); }

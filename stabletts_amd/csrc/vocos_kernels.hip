@@ -57,7 +57,7 @@ __device__ __forceinline__ void st16x8(void* p, const Row8& v) {
 
 template <class P>
 __global__ __launch_bounds__(256) void voc_ln_kernel(const float* x, const float* __restrict__ w, const float* __restrict__ b,
-                                                     long long rows, float* out32, void* out16) {
+                                                     long long rows, float* out32, void* out16, void* out16_lo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -66,13 +66,19 @@ __global__ __launch_bounds__(256) void voc_ln_kernel(const float* x, const float
     voc_ln8(v, ld8(w + ch), ld8(b + ch));
     if (out32) { *(float4*)(out32 + (size_t)row * 512 + ch) = v.a; *(float4*)(out32 + (size_t)row * 512 + ch + 4) = v.b; }
     if (out16) st16x8<P>((unsigned char*)out16 + ((size_t)row * 512 + ch) * 2, v);
+    if (out16_lo) {      // the low half of a split-precision operand pair: x - float(round16(x)), rounded once more
+        Row8 r;
+        r.a.x = v.a.x - (float)to16<P>(v.a.x); r.a.y = v.a.y - (float)to16<P>(v.a.y); r.a.z = v.a.z - (float)to16<P>(v.a.z); r.a.w = v.a.w - (float)to16<P>(v.a.w);
+        r.b.x = v.b.x - (float)to16<P>(v.b.x); r.b.y = v.b.y - (float)to16<P>(v.b.y); r.b.z = v.b.z - (float)to16<P>(v.b.z); r.b.w = v.b.w - (float)to16<P>(v.b.w);
+        st16x8<P>((unsigned char*)out16_lo + ((size_t)row * 512 + ch) * 2, r);
+    }
 }
 
 hipError_t launch_voc_ln(int dtype, const float* x, const float* w, const float* b, int64_t rows, float* out32, void* out16,
-                         hipStream_t s) {
+                         void* out16_lo, hipStream_t s) {
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((voc_ln_kernel<OpBF16>), grid, blk, 0, s, x, w, b, (long long)rows, out32, out16);
-    else                  hipLaunchKernelGGL((voc_ln_kernel<OpF16>), grid, blk, 0, s, x, w, b, (long long)rows, out32, out16);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((voc_ln_kernel<OpBF16>), grid, blk, 0, s, x, w, b, (long long)rows, out32, out16, out16_lo);
+    else                  hipLaunchKernelGGL((voc_ln_kernel<OpF16>), grid, blk, 0, s, x, w, b, (long long)rows, out32, out16, out16_lo);
     return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ constexpr int kVocHeadPlane = 1152; // channel pitch of the magnitude / phase pl
 hipError_t launch_voc_im2col7(int dtype, const float* mel, int B, int M, int T, void* a16, hipStream_t s);
 // y = LayerNorm_512(x) * w + b  (eps 1e-6): out32 and/or out16 (may alias x for out32)
 hipError_t launch_voc_ln(int dtype, const float* x, const float* w, const float* b, int64_t rows, float* out32, void* out16,
-                         hipStream_t s);
+                         void* out16_lo, hipStream_t s);      // out16_lo (optional): x - float(round16(x)), the low half of a split-precision operand
 // h16 = LayerNorm_512(dwconv7(x) + bias) * w + b   per utterance (rows of different items never mix); dw: [512][7]
 hipError_t launch_voc_dwconv_ln(int dtype, const float* x, const float* dw, const float* dbias, const float* w, const float* b,
                                 int B, int T, void* h16, hipStream_t s);
