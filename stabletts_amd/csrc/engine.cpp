@@ -598,6 +598,7 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
             ConvGemmArgs a = base_args(e, p, e->ffn2[i], N);
             a.a0 = p.u16; a.c0 = F; a.mask = mask; a.gate = ada_i + 5 * C; a.gate_stride = 6 * C; a.out32 = p.X;
             a.out16 = p.cur16;
+            if (i + 1 == L) a.out16_lo = p.cur16lo;      // operand pair of proj (split precision, like the decoder's final_proj)
             if (i + 1 < L) {      // LN1 + modulate of block i+1 (no FiLM, not masked)
                 a.ln_h16 = p.h16; a.ln_film = nullptr; a.ln_film_mod = 1;
                 a.ln_ada = ada_of(i + 1); a.ln_ada_stride = 6 * C; a.ln_shift_off = 0; a.ln_scale_off = C; a.ln_mask_out = 0;
@@ -609,7 +610,7 @@ int run_text_blocks(st_engine* e, const Plan& p, const float* mask, hipStream_t 
     }
     {   // mu_x = proj(x) * x_mask (text_encoder.py:42)
         ConvGemmArgs a = base_args(e, p, e->fin, N);
-        a.a0 = p.cur16; a.c0 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
+        a.a0 = p.cur16; a.c0 = C; a.a1 = p.cur16lo; a.c1 = C; a.c2 = C; a.mask = mask; a.flags = GF_MASK; a.out32 = p.v32;
         ProfScope ps(e, s, PC_FINAL, conv_flops(p, e->fin, N));
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
@@ -1202,7 +1203,7 @@ int pack_all(st_engine* e, hipStream_t s) {
     };
     int rc;
     if (e->kind == 1) {
-        if ((rc = pack(e->fin, "proj.weight", P(e, "proj.bias"), M, Mp, C, 1, 0, C, C, false))) return rc;
+        if ((rc = pack(e->fin, "proj.weight", P(e, "proj.bias"), M, Mp, C, 1, 0, C, C, true))) return rc;      // split precision: its error reaches mu_x un-gated
     } else {
     if (e->pre.size() != 3) e->pre.assign(3, Conv());
     if ((rc = pack(e->pre[0], "cond_proj.0.weight", P(e, "cond_proj.0.bias"), F, F, M, K, 0, M, Mp, false))) return rc;

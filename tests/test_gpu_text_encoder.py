@@ -14,8 +14,9 @@ from oracle.make_golden_text_encoder import CASES, text_inputs
 
 pytestmark = pytest.mark.gpu
 
-TOL_X = {"bf16": 8e-3, "f16": 1e-3}
-TOL_MU = {"bf16": 1.2e-2, "f16": 1.5e-3}
+# measured on MI355X (round 5, proj on split-precision operands): f16 x 1.1e-4 / mu_x 5.9e-5, bf16 1.1e-3 / 5.8e-4
+TOL_X = {"bf16": 3e-3, "f16": 3e-4}
+TOL_MU = {"bf16": 2e-3, "f16": 3e-4}
 
 
 def _rel(a, b):
@@ -54,7 +55,9 @@ def test_vs_reference_fixture(encoders, dt, case):
     x, mu_x, mask = encoders[dt](tok.cuda(), c.cuda(), lens.cuda())
     assert np.array_equal(mask.cpu().numpy(), g[case + "_mask"])
     assert _rel(x.cpu().numpy(), g[case + "_x"]) <= TOL_X[dt]
-    assert _rel(mu_x.cpu().numpy(), g[case + "_mu_x"]) <= TOL_MU[dt]
+    ex, em = _rel(x.cpu().numpy(), g[case + "_x"]), _rel(mu_x.cpu().numpy(), g[case + "_mu_x"])
+    print(f"text encoder {dt} {case}: x {ex:.2e} mu_x {em:.2e}")
+    assert em <= TOL_MU[dt]
     pad = ~mask.bool().expand_as(mu_x)
     assert float(mu_x[pad].abs().max()) == 0.0          # proj(x) * x_mask (text_encoder.py:42)
     assert float(x[~mask.bool().expand_as(x)].abs().max()) == 0.0
