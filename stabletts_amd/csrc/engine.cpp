@@ -148,7 +148,6 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
     else if (a.ln_h16 || epi == EPI_QKV) cfg = G2_RC;
     else if (taps == 3 && a.c0 + a.c1 >= 512 && a.c2 == 0) cfg = G2_K3PIPE;
     else cfg = G2_T128;
-    if (cfg == G2_BIG && taps == 1 && epi == EPI_RESGATE && a.ln_h16 && e->oproj_rc) cfg = G2_RC;
     // latency-bound small grids: 64-frame tiles double the block count and halve every block's serial work
     const bool tiny = e->small_tiles && e->conc == 1 && (int64_t)a.n_items * ((T + 127) / 128) * (a.cout / 128) <= e->small_tiles;
     if (tiny && cfg == G2_T128 && (epi == EPI_ACT16 ? taps == 3 : epi == EPI_F32)) cfg = G2_T64;
@@ -973,7 +972,6 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
 #endif
     if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
     if (const char* v = getenv("ST_QKV_WS_MIN_TILES")) e->qkv_ws_min_tiles = atoi(v);
-    if (const char* v = getenv("ST_OPROJ_RC")) e->oproj_rc = atoi(v);
     if (const char* v = getenv("ST_OPROJ_WS")) e->oproj_ws = atoi(v);
     if (const char* v = getenv("ST_OPROJ_WS_MIN_TILES")) e->oproj_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)

@@ -115,7 +115,6 @@ struct st_engine {
                                         // ST_QKV_WS=0: the generic conv tile
     int oproj_ws = 1;                   // out projection of big grids as the weight-stationary persistent kernel (oproj_ws.hip; default); ST_OPROJ_WS=0: the generic 256 x 256 tile
     int oproj_ws_min_tiles = 1000;      // ... from this many 32-frame tiles per launch
-    int oproj_rc = 0;                   // out projection of big grids on row-complete 256 x 128 tiles (G2_RC) instead of 256 x 256 (ST_OPROJ_RC=1: A/B runs)
     int qkv_rc1 = 1;                    // fused q/k/v projection of big grids on 256 x 128 tiles with one weight buffer, two blocks per CU (ST_QKV_RC1=0: A/B)
     int ragged_skip = 1;                // conv / attention launches skip frame tiles past an utterance's last needed frame (ST_RAGGED_SKIP=0: A/B)
     int fused_ffn = -1;                 // FFN of big grids as ONE kernel, the intermediate kept in LDS.  -1 = default = 1: the direct kernel on 32x32x16 MFMA

@@ -465,11 +465,9 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
     const int64_t R = (int64_t)N * T;
     const int cin = c0 + c1;
     const int frames = taps * cin;
-    static const bool use_tn = [] { const char* v = getenv("ST_WGRAD_TN"); return !(v && atoi(v) == 0); }();
-    static const int blocks_env = [] { const char* v = getenv("ST_WGRAD_BLOCKS"); return v ? std::max(1, atoi(v)) : 0; }();
-    const int target_blocks = blocks_env ? blocks_env : 512;        // transposed-copy path: two rounds of its smaller blocks
-    const int target_tn = blocks_env ? blocks_env : 256;            // TN path: one block per CU
-    if (use_tn && cout16 % 256 == 0 && !(c0 & 63) && !(c1 & 63) && (!c1 || c0 % 256 == 0)) {
+    const int target_blocks = 512;        // transposed-copy path (cout = 128: final_proj): two rounds of its smaller blocks
+    const int target_tn = 256;            // TN path: one block per CU
+    if (cout16 % 256 == 0 && !(c0 & 63) && !(c1 & 63) && (!c1 || c0 % 256 == 0)) {
         // no transposed copies: the TN GEMM reads dY and X as they are (wgrad_tn.hip).  K (= items x 32-frame chunks) is split
         // into S ranges such that tiles x S fills ONE round of blocks (the kernel holds 128 KB of LDS: one block per CU) --
         // every block then carries the same share of the contraction and the reduce kernel reads the fewest planes
