@@ -19,6 +19,7 @@ using namespace st;
 using namespace sthost;
 
 namespace sthost {
+constexpr int kPartPhaseUs = 100;      // start offset between the launch sequences of a multi-part solve (engine.cpp: body)
 
 std::string g_create_error;
 
@@ -1470,6 +1471,10 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
         } else if (adaptive) {
             if ((rc = solve_adaptive(e, parts[0].p, parts[0].mask, use_cfg, cfg_strength, tableau, cs))) return rc;
         } else {
+            // The parts run the same kernel sequence; started together they tend to sit in the same kernel at the same time (FFN beside
+            // FFN: two power-limited kernels sharing the CUs).  Part k starts 100 k us late -- about half a layer of a half batch: any
+            // offset from 30 to 250 us measured +0.4 ... +0.6 % per solve, paired (profiles/r05_ab_part_phase.txt).
+            for (int k = 1; k < nparts; ++k) HIPCHK(e, launch_delay(kPartPhaseUs * k, parts[k].s));
             for (int i = 0; i < n_steps; ++i)
                 for (auto& pt : parts)
                     if ((rc = step_fixed(pt, i, pt.s))) return rc;

@@ -163,6 +163,7 @@ hipError_t launch_from_time_major(const float* in, int B, int C, int T, int Cp, 
 hipError_t launch_embed_tokens(const long long* tokens, const long long* lengths, const float* emb, int n_vocab,
                                int C, float scale, int B, int T, float* X, float* mask_out, hipStream_t s);
 hipError_t launch_set_values(float* dst, const float* host_vals, int n, hipStream_t s);
+hipError_t launch_delay(int us, hipStream_t s);      // one sleeping wave holds stream s for ~us microseconds (phase offset between solve parts)
 hipError_t launch_cvec_prep(const float* c, const float* fake_or_null, int B, int G, float* dst, hipStream_t s);
 hipError_t launch_fill_rows16(int dtype, const float* vec, int C, int Cp, int T, void* out16, hipStream_t s);
 

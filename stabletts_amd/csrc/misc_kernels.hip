@@ -243,6 +243,17 @@ __global__ void set_values_kernel(float* dst, int n, SetValuesArgs a) {
     if (i < n) dst[i] = a.v[i];
 }
 // host values -> device array through kernel arguments (64 per launch): the evaluation times of a solve
+// holds its stream for about `us` microseconds (one wave sleeping; 100-MHz constant-rate counter): the phase offset between the
+// launch sequences of a multi-part solve (engine.cpp)
+__global__ void delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+hipError_t launch_delay(int us, hipStream_t s) {
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)us * 100ull);
+    return hipGetLastError();
+}
+
 hipError_t launch_set_values(float* dst, const float* host_vals, int n, hipStream_t s) {
     for (int o = 0; o < n; o += 64) {
         SetValuesArgs a;
