@@ -176,20 +176,6 @@ __device__ __forceinline__ void store_row8(void* p, uint2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off " ST_ROW_STORE_POLICY "\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x2_t, v)) : "memory");
 }
 
-// a residual row that this block reads exactly once (the epilogue's x rows): ST_NT_RES=1 loads it non-temporally (A/B switch)
-#ifndef ST_NT_RES
-#define ST_NT_RES 0
-#endif
-__device__ __forceinline__ float4 ld_row16_once(const float* p) {
-#if ST_NT_RES
-    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-    const f32x4_nt v = __builtin_nontemporal_load((const f32x4_nt*)p);
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *(const float4*)p;
-#endif
-}
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
@@ -226,24 +212,9 @@ __device__ __forceinline__ void glds16bo(const void* gsrc, unsigned lds_off) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
-// The same piece with the NON-TEMPORAL hint, for activation rows that one block streams once (residual rows, attention output,
-// the FFN / long-skip operand tiles): they do not displace what the L2 is kept for -- weights every CU re-reads, K / V tiles shared
-// by a group's query tiles.  BUILD-TIME A/B SWITCH, OFF (-DST_NT_DMA=1 turns it on): round 5 measured it -1.1 % on the single-sequence
-// solve (q/k/v, out projection and attention gain), 0.0 % on the default two-part solve and +1.5 % (slower) on a ragged batch, paired
-// (profiles/r05_ab_nt_dma.txt).  Never for the q/k/v projection's tile, which the three plane blocks of an XCD read one after another
-// (there nt costs 8 %, profiles/r05_ab_store_policy.txt).
-#ifndef ST_NT_DMA
-#define ST_NT_DMA 0
-#endif
-__device__ __forceinline__ void glds16bo_nt(const void* gsrc, unsigned lds_off) {
-#if ST_NT_DMA
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
-#else
-    glds16bo(gsrc, lds_off);
-#endif
-}
+// (Round 5 measured the same piece with the non-temporal hint, `global_load_lds_dwordx4 ... nt`, for the activation tiles a block streams
+// once: -1.1 % on the single-sequence solve, 0.0 % on the default two-part solve, +1.5 % (slower) on a ragged batch, +8 % on the q/k/v
+// projection's own tile -- profiles/r05_ab_nt_dma.txt, r05_ab_store_policy.txt.  Not kept.)
 // the 4-byte-per-lane form (64 lanes x 4 B = 256 B at lds_off + 4 lane): for fp32 rows whose start is only dword-aligned
 __device__ __forceinline__ void glds4bo(const void* gsrc, unsigned lds_off) {
     unsigned keep;

@@ -211,7 +211,7 @@ __device__ __forceinline__ void g2_epilogue_core(Park park, float* stage, const 
             const int tl = t < tlim ? t : tlim - 1;      // loads of an invalid row are clamped, its stores dropped
             mk[u] = mrow ? mrow[tl] : 1.0f;
             xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_RESGATE) xin[u] = ld_row16_once((g.res32 ? g.res32 : g.out32) + ((size_t)n * T + tl) * g.cout + cbase + chl);
+            if constexpr (EPI == EPI_RESGATE) xin[u] = *(const float4*)((g.res32 ? g.res32 : g.out32) + ((size_t)n * T + tl) * g.cout + cbase + chl);
             if constexpr (EPI == EPI_F32) { if (g.add32) xin[u] = *(const float4*)(g.add32 + ((size_t)an * T + tl) * g.cout + cbase + chl); }
         }
         __syncthreads();

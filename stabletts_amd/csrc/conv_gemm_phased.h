@@ -140,12 +140,12 @@ void conv_gemm_phased3_kernel(const ConvGemmArgs g) {
             const unsigned char* sb = a0_s + (size_t)ch0 * 2;
 #pragma unroll
             for (int k = 0; k < APW; ++k)
-                if (k >= k0 && k < k1) glds16bo_nt(validA[k] ? sb + voffA0[k] : zeros, ldsA + buf * A_BYTES + (wave * APW + k) * 1024);
+                if (k >= k0 && k < k1) glds16bo(validA[k] ? sb + voffA0[k] : zeros, ldsA + buf * A_BYTES + (wave * APW + k) * 1024);
         } else if constexpr (TWO_SRC) {
             const unsigned char* sb = a1_s + (size_t)(ch0 - g.c0) * 2;
 #pragma unroll
             for (int k = 0; k < APW; ++k)
-                if (k >= k0 && k < k1) glds16bo_nt(validA[k] ? sb + voffA1[k] : zeros, ldsA + buf * A_BYTES + (wave * APW + k) * 1024);
+                if (k >= k0 && k < k1) glds16bo(validA[k] ? sb + voffA1[k] : zeros, ldsA + buf * A_BYTES + (wave * APW + k) * 1024);
         }
     };
 

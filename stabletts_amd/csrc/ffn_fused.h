@@ -157,7 +157,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
         const unsigned char* sb = h_s + ci * 128;
         const unsigned dst = (k < 2) ? lds0 + (unsigned)(ci * AREA + (wave + 8 * k) * 1024)
                                      : (wave == 0 ? lds0 + (unsigned)(ci * AREA + 16 * 1024) : lds0 + (unsigned)OFF_SINK);
-        glds16bo_nt(validH[k] ? sb + voffH[k] : zeros, dst);
+        glds16bo(validH[k] ? sb + voffH[k] : zeros, dst);
     };
     unsigned roff = 0, woff = DEPTH * SLAB, sig = DEPTH;      // ring offsets of the slab being read / issued, index of the slab being issued
     auto issueW = [&]() {
@@ -175,7 +175,7 @@ void ffn_fused_kernel(const ConvGemmArgs g) {
         for (int k = 0; k < 3; ++k) {
             const unsigned dst = (k < 2) ? lds0 + (unsigned)(ci * AREA + (wave + 8 * k) * 1024)
                                          : (wave == 0 ? lds0 + (unsigned)(ci * AREA + 16 * 1024) : lds0 + (unsigned)OFF_SINK);
-            glds16bo_nt(validH[k] ? h_s + ci * 128 + voffH[k] : zeros, dst);
+            glds16bo(validH[k] ? h_s + ci * 128 + voffH[k] : zeros, dst);
         }
 #pragma unroll
     for (int sl = 0; sl < DEPTH; ++sl) {

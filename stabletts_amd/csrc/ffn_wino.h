@@ -127,9 +127,9 @@ void ffn_wino_kernel(const ConvGemmArgs g) {
         const unsigned dst = lds0 + (unsigned)(area * AREA + ((k < 2) ? wave + 8 * k : 16) * 1024);
         int tidh = threadIdx.x; asm volatile("" : "+v"(tidh));
         const unsigned vo = htab[k * 512 + tidh];
-        glds16bo_nt(vo != 0xFFFFFFFFu ? h_s + area * 128 + vo : zeros, dst);
+        glds16bo(vo != 0xFFFFFFFFu ? h_s + area * 128 + vo : zeros, dst);
     };
-    auto issueDummy = [&]() { glds16bo_nt(zeros, lds0 + (unsigned)kWnOffSink); };
+    auto issueDummy = [&]() { glds16bo(zeros, lds0 + (unsigned)kWnOffSink); };
     unsigned soff = 0;      // ring offset of the k-step being read = the one the k-step + 3 is issued into
     int gs = 0;             // global k-step index
     auto issueW = [&]() {

@@ -117,9 +117,9 @@ void oproj_ws_kernel(const ConvGemmArgs g, int L) {
         const unsigned base = lds0 + (unsigned)(slot * kOwsSlot);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            glds16bo_nt((unit && vrowA[k] && !(kOwsVar & 16)) ? ab + voffA[k] : zeros, base + (unsigned)((wave >> 1) * 4096 + (wave & 1) * 2048 + k * 1024));
+            glds16bo((unit && vrowA[k] && !(kOwsVar & 16)) ? ab + voffA[k] : zeros, base + (unsigned)((wave >> 1) * 4096 + (wave & 1) * 2048 + k * 1024));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) glds16bo_nt((unit && vrowX[k] && !(kOwsVar & 8)) ? xb + voffX[k] : zeros, base + (unsigned)(kOwsAo + (wave * 4 + k) * kOwsXPitch));
+        for (int k = 0; k < 4; ++k) glds16bo((unit && vrowX[k] && !(kOwsVar & 8)) ? xb + voffX[k] : zeros, base + (unsigned)(kOwsAo + (wave * 4 + k) * kOwsXPitch));
         {   // waves 0, 1, 2: the item's gate / adaLN shift / adaLN scale rows; wave 3: the frame mask of the tile's 32 frames (a row
             // that is only dword-aligned: 4-byte pieces, frames past T clamped like the generic epilogue); waves 4..7: zero page -> sink
             const float* ad = g.ln_ada + (size_t)nn * g.ln_ada_stride;
