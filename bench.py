@@ -14,9 +14,13 @@ resident in HBM, explicit noise z.  With N GPUs every rank
 solves its own 32-utterance batch (utterances are independent units: no data-path collective,
 weak scaling); value = frames solved by all ranks / max-over-ranks wall time.
 
-  --ragged   BASELINE config 4: 32*N utterances with len ~ U{600..1000}, length-sorted and dealt to the ranks by
-             stabletts_amd.sharding.assign_batches (32 per GPU); value counts VALID frames only, the line carries
-             the sharder's imbalance / padding figures.
+  --ragged   BASELINE config 4 as the headline: the SAME 256 utterances with len ~ U{600..1000} at every N (strong
+             scaling), cut by stabletts_amd.sharding.assign_batches into equal-cost length buckets (mean 32 utterances,
+             variable count) and dealt to the ranks; a rank solves its buckets back to back inside the timed region
+             (N=1: eight buckets); value counts VALID frames only, the line carries the sharder's imbalance / padding.
+  Every default line (any N) also carries the legs "ragged" (config 4 as above, one timed pass per step) and, for N > 1,
+  "train_ddp" (config 5: DistributedDataParallel around compute_loss, B=64 per rank, gradient all-reduce over RCCL);
+  for N = 1 "train_step" is the same step without the process group.
   --dtype    MFMA operand type of the headline line (f16 = the shipping default, parity-gated at 1e-3; bf16 = BASELINE's
              word for "16-bit operands", ~4e-3).  The other type is timed after the headline region ("other_dtype").
 
@@ -51,33 +55,39 @@ def algorithmic_flops_per_frame(T, n_evals, B):
     return n_evals * body + prenet * (1.0 + 1.0 / B)
 
 
-CPU_THREADS = 32               # fixed (min with the host's cores): the figure must not move with a calibration sweep
+CPU_THREADS = 32               # one of the two fixed thread counts timed (the other: os.cpu_count()); the faster is reported
 
 
 def cpu_baseline(sd, cfg_params):
     """SURVEY.md section 8(d)'s protocol for config-2-sized inputs: time ONE evaluation of the workload's own batch -- B=32 x T=1000,
     the cond and the uncond estimator call of one cfg_wrapper step (flow_matching.py:58-67), prenet recomputed in each as the
     reference does -- and scale by the step count (every Euler step costs the same two evaluations).  The oracle (fp32 torch-CPU
-    restatement of the reference) on a FIXED thread count; ~10-30 s of CPU work on the MI355X host."""
+    restatement of the reference), timed ONCE with os.cpu_count() threads (SURVEY's rule) and ONCE with 32 (oneDNN stops scaling
+    well before 256 threads on the MI355X hosts): the faster of the two is the baseline, both are in the line.  ~15-30 s of CPU."""
     import oracle
     from oracle.inputs import make_inputs
     fs, fc = cfg_params
-    threads = max(1, min(CPU_THREADS, os.cpu_count() or 1))
-    torch.set_num_threads(threads)
     inp = make_inputs(B_PER_GPU, T_FRAMES, seed=0)
     small = make_inputs(2, 256, seed=0)
     t_span = oracle.linspace_f32(N_STEPS)
-    with torch.inference_mode():
-        oracle.cfg_wrapper(sd, t_span[0], small["z"], small["mask"], small["mu"], small["c"], fs, fc, CFG)      # warm-up (thread pool, oneDNN primitives)
-        t0 = time.perf_counter()
-        oracle.cfg_wrapper(sd, t_span[0], inp["z"], inp["mask"], inp["mu"], inp["c"], fs, fc, CFG)
-        t_eval = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    timed = {}
+    for threads in sorted({max(1, min(CPU_THREADS, ncpu)), ncpu}):
+        torch.set_num_threads(threads)
+        with torch.inference_mode():
+            oracle.cfg_wrapper(sd, t_span[0], small["z"], small["mask"], small["mu"], small["c"], fs, fc, CFG)      # warm-up (thread pool, oneDNN primitives)
+            t0 = time.perf_counter()
+            oracle.cfg_wrapper(sd, t_span[0], inp["z"], inp["mask"], inp["mu"], inp["c"], fs, fc, CFG)
+            timed[threads] = time.perf_counter() - t0
+    threads = min(timed, key=timed.get)
+    t_eval = timed[threads]
     per_solve = t_eval * N_STEPS
     return dict(value=B_PER_GPU * T_FRAMES / per_solve, unit="mel-frames/sec", cores=threads, kind="port",
+                seconds_per_cfg_step_by_threads={str(k): v for k, v in timed.items()},
                 sample=f"oracle (fp32 torch-CPU restatement of the reference; prenet recomputed every evaluation as the reference does), "
                        f"the workload's own batch B={B_PER_GPU} x T={T_FRAMES}, cfg={CFG}: ONE cfg_wrapper step (cond + uncond evaluation) timed "
-                       f"({t_eval:.2f} s) and scaled by the {N_STEPS} euler steps (SURVEY 8d); {threads} torch threads (fixed), "
-                       f"os.cpu_count()={os.cpu_count()}")
+                       f"with {' and '.join(str(k) for k in timed)} torch threads, the faster kept ({threads} threads: {t_eval:.2f} s) and scaled by the "
+                       f"{N_STEPS} euler steps (SURVEY 8d); os.cpu_count()={ncpu}")
 
 
 def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
@@ -140,6 +150,135 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
     return res
 
 
+# Variables the engine reads (getenv in csrc/engine*.cpp, stabletts_amd/_lib.py) that change which kernels run or which library is loaded;
+# tests/test_cabi_cpu.py checks this list against the sources.  Unknown ST_* names are refused too (a new switch must be classified).
+ENGINE_ENV = ("STABLETTS_HIP_LIB", "ST_BIG_MIN_BLOCKS", "ST_PHASED", "ST_FUSED_FFN", "ST_RAGGED_SKIP", "ST_SKIP_CLASSES", "ST_QKV_WS",
+              "ST_QKV_WS_MIN_TILES", "ST_OPROJ_WS", "ST_OPROJ_WS_MIN_TILES", "ST_QKV_RC1", "ST_SMALL_GRID", "ST_FUSE_SILU", "ST_FUSE_TRAIN_LN")
+# ... and those that do not: ST_SPLIT / ST_HIP_GRAPH change how the same kernels are enqueued (bitwise identical, tests/test_gpu_engine.py),
+# ST_BUILD_* are read by stabletts_amd.build only (a left-over from a build step must not cost the harness its line)
+ENGINE_NEUTRAL_ENV = ("ST_SPLIT", "ST_HIP_GRAPH", "ST_BUILD_OUT", "ST_BUILD_DEFS")
+RAGGED_UTTERANCES = 256        # BASELINE config 4: "batch=256 utterances sharded"; the same set at every N (strong scaling)
+
+
+def ragged_batches(world, rank, dev, n_utt=RAGGED_UTTERANCES):
+    """BASELINE config 4: n_utt utterances, len ~ U{600..1000} (fixed seed: identical on every rank and at every world size),
+    cut into equal-cost length buckets (mean 32, variable count) and dealt to the ranks by the sharder.  Returns this rank's
+    buckets as device-resident input dicts (longest first) and the sharding figures of the whole assignment."""
+    import numpy as np
+    from oracle.inputs import make_inputs
+    from stabletts_amd import sharding
+    lengths = np.random.default_rng(4).integers(600, T_FRAMES + 1, size=n_utt).tolist()
+    per_rank = sharding.assign_batches(lengths, B_PER_GPU, world)
+    mine = []
+    for b in sorted(per_rank[rank], key=lambda b: -max(lengths[i] for i in b)):
+        bl = [lengths[i] for i in b]
+        inp = make_inputs(len(b), max(bl), seed=1000 + b[0], lengths=bl)
+        mine.append({"g": {k: v.to(dev) for k, v in inp.items() if k != "lengths"}, "B": len(b), "T": max(bl), "valid": sum(bl)})
+    imb, pad = sharding.imbalance(lengths, per_rank)
+    fixed = sharding.assign_batches(lengths, B_PER_GPU, world, equal_cost=False)
+    info = {"utterances": n_utt, "valid_frames": sum(lengths), "imbalance_max_over_mean": imb, "padded_over_valid_frames": pad,
+            "batches_per_rank": [[len(b) for b in bs] for bs in per_rank],
+            "batch_max_len_per_rank": [[max(lengths[i] for i in b) for b in bs] for bs in per_rank],
+            "cost_model_speedup_over_one_rank": sharding.scaling_ceiling(lengths, per_rank),
+            "fixed_count_buckets_imbalance": sharding.imbalance(lengths, fixed)[0],
+            "policy": "equal-cost, variable-count length buckets (cost = count x len_max x (12,320,768 + 3,072 len_max)), LPT deal"}
+    return mine, info, lengths
+
+
+def ragged_leg(dec, kw, world, rank, dev, sync, allreduce_max, reps, n_utt=RAGGED_UTTERANCES):
+    """Config 4 as a leg of the default line: every rank solves its buckets back to back, `reps` timed passes between two
+    barriers, max over ranks.  At N = 1 the eight buckets are also timed one by one: their measured times give the 8-GPU
+    ceiling this assignment has on real hardware (sum / max), beside the cost model's."""
+    mine, info, _ = ragged_batches(world, rank, dev, n_utt)
+
+    def solve(b):
+        g = b["g"]
+        return dec(g["mu"], g["mask"], N_STEPS, 1.0, g["c"], "euler", kw, z=g["z"])
+    for b in mine:
+        solve(b)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for b in mine:
+            solve(b)
+    sync()
+    sec = allreduce_max(time.perf_counter() - t0) / reps
+    res = {"workload": f"BASELINE config 4: the same {n_utt} ragged utterances len~U{{600..1000}} at every N (strong scaling), equal-cost length "
+                       f"buckets dealt to the ranks, n_timesteps={N_STEPS} euler, cfg={CFG}; valid frames only",
+           "value": info["valid_frames"] / sec, "unit": "mel-frames/sec", "ms_per_pass": sec * 1e3, "scaling": "strong", "sharding": info}
+    if world == 1:
+        per = []
+        for b in mine:
+            solve(b)
+            torch.cuda.synchronize(dev); t1 = time.perf_counter()
+            for _ in range(3):
+                solve(b)
+            torch.cuda.synchronize(dev)
+            per.append((time.perf_counter() - t1) / 3 * 1e3)
+        res["ms_per_bucket"] = per
+        res["bucket_B_x_T"] = [[b["B"], b["T"]] for b in mine]
+        if len(per) >= 2:
+            res["measured_ceiling_one_bucket_per_gpu"] = {"gpus": len(per), "speedup": sum(per) / max(per), "max_over_mean": max(per) / (sum(per) / len(per))}
+    return res
+
+
+class _LossModule(torch.nn.Module):
+    """What StableTTS.forward does with the decoder (models/model.py:173): calls compute_loss.  DDP prepares its gradient hooks
+    inside ITS forward, so compute_loss has to run under a module's forward for the reducer to see the backward."""
+    def __init__(self, dec):
+        super().__init__()
+        self.dec = dec
+
+    def forward(self, x1, mask, mu, c):
+        return self.dec.compute_loss(x1, mask, mu, c)
+
+
+def train_ddp_leg(dev, sd, world, rank, dist, share_gpu, B=64, T=T_FRAMES, dtype="f16", steps=5):
+    """BASELINE config 5: train.py:49-51,78-81 around the native decoder -- DistributedDataParallel(compute_loss), B utterances
+    per rank (ragged, T <= 1000, dropout on), AdamW; the gradient all-reduce is DDP's, over RCCL ("nccl" backend) with one
+    GPU per rank.  Ranks sharing a device (BENCH_SHARE_GPU=1, tests) use gloo: RCCL refuses two ranks on one device."""
+    from oracle.inputs import make_inputs
+    from stabletts_amd.flow_matching import CFMDecoder
+    backend = "gloo" if share_gpu else "nccl"
+    pg = dist.new_group(backend=backend)
+    dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dtype)
+    dec.estimator.load_state_dict(sd)
+    dec = dec.to(dev).train(True)
+    ddp = torch.nn.parallel.DistributedDataParallel(_LossModule(dec), device_ids=[dev.index], process_group=pg)
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-4)
+    raw = make_inputs(B, T, seed=100 + rank, ragged=True)
+    inp = {k: v.to(dev) for k, v in raw.items() if k != "lengths"}
+    x1 = make_inputs(B, T, seed=200 + rank)["z"].to(dev)
+    grad_bytes = sum(p.numel() for p in dec.parameters() if p.requires_grad) * 4
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = ddp(x1, inp["mask"], inp["mu"], inp["c"])
+        loss.backward()
+        opt.step()
+        return loss
+    with torch.enable_grad():
+        for _ in range(3):              # DDP rebuilds its buckets in arrival order after the first step
+            step()
+        torch.cuda.synchronize(dev); dist.barrier(group=pg); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize(dev); dist.barrier(group=pg); torch.cuda.synchronize(dev)
+        sec = (time.perf_counter() - t0) / steps
+    tt = torch.tensor([sec, float(raw["lengths"].sum()), float(loss.detach())], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=pg)
+    sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM, group=pg)
+    sec, valid = float(mx[0]), float(sm[1])
+    res = {"workload": f"BASELINE config 5: DistributedDataParallel around CFMDecoder.compute_loss, B={B} x T={T} ragged per rank, dropout 0.1, "
+                       f"AdamW, {dtype} operands, native forward / backward; {steps} steps between barriers, max over ranks",
+           "ms_per_step": sec * 1e3, "mel_frames_per_sec": valid / sec, "ranks": world, "backend": backend,
+           "rccl_ranks": world if backend == "nccl" else 0, "allreduce_bytes_per_step": grad_bytes,
+           "mean_loss_last_step": float(sm[2]) / world, "scaling": "weak"}
+    del ddp, dec, opt
+    return res
+
+
 # kernel that implements each profiled class on the default path (for the PMC traffic lookup)
 CLASS_KERNEL = {
     "ffn_conv1": "conv_gemm_phased3_kernel<st::Op{DT}, 0, false>",
@@ -162,12 +301,25 @@ def class_kernel(cls, dtype):
 
 def _pmc_table():
     """Committed rocprofv3 PMC passes of this same command (newest round first)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic_before_wino.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic_before_wino.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v2.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", name))), name
         except Exception:
             continue
     return None, None
+
+
+def pmc_source():
+    """Which committed table the `traffic` figures come from, and whether it was taken from the kernels this run executes: the
+    table's `csrc_digest` (written by tools/rocprof_summary.py) against the digest of the sources the loaded library was built from."""
+    table, name = _pmc_table()
+    if table is None:
+        return None
+    from stabletts_amd import build
+    now = build._digest()[:16]
+    was = table.get("_summary", {}).get("csrc_digest")
+    return {"file": "profiles/" + name, "csrc_digest_of_table": was, "csrc_digest_now": now,
+            "stale": (None if was is None else was != now)}
 
 
 def pmc_solve_bytes():
@@ -204,6 +356,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other-dtype and config-1 latency legs")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the config-5 training-step leg of the extras")
     ap.add_argument("--ragged", action="store_true", help="BASELINE config 4: ragged utterances through the sharder")
+    ap.add_argument("--ragged-utterances", type=int, default=RAGGED_UTTERANCES, help="size of the config-4 utterance set (256 = BASELINE; tests use fewer)")
+    ap.add_argument("--train-batch", type=int, default=64, help="utterances per rank of the config-5 legs (64 = BASELINE; tests use fewer)")
     ap.add_argument("--n-timesteps", type=int, default=N_STEPS,
                     help="Euler steps per solve: 10 = BASELINE config 2 (default, the headline metric); 50 = config 3, "
                          "the long-ODE stress case")
@@ -215,7 +369,7 @@ def main():
     # The headline line describes the library AS SHIPPED: refuse to run with any variable that changes which kernels run or what
     # they return.  (ST_SPLIT / ST_HIP_GRAPH only change how the same kernels are enqueued -- results are bitwise identical,
     # tests/test_gpu_engine.py -- and the profiling scripts set ST_SPLIT=1 for per-kernel passes.)
-    dev_env = {k: v for k, v in os.environ.items() if (k.startswith("ST_") and k not in ("ST_SPLIT", "ST_HIP_GRAPH")) or k == "STABLETTS_HIP_LIB"}
+    dev_env = {k: v for k, v in os.environ.items() if k in ENGINE_ENV or (k.startswith("ST_") and k not in ENGINE_NEUTRAL_ENV)}
     if dev_env and not args.dev_env:
         raise SystemExit("bench.py: refusing to measure with engine-changing variables set: " + ", ".join(sorted(dev_env)) +
                          " (unset them, or pass --dev-env for a developer run that is marked as such)")
@@ -273,29 +427,36 @@ def main():
     dec.estimator.load_state_dict(sd)
     dec = dec.to(dev)
 
-    # utterance sharding: world*32 utterances, dealt as length-sorted batches (no collective)
-    if args.ragged:
-        import numpy as np
-        lengths = np.random.default_rng(4).integers(600, T_FRAMES + 1, size=B_PER_GPU * world).tolist()
-    else:
-        lengths = [T_FRAMES] * (B_PER_GPU * world)
-    per_rank = sharding.assign_batches(lengths, B_PER_GPU, world)
-    my_batches = per_rank[rank]
-    assert len(my_batches) == 1 and len(my_batches[0]) == B_PER_GPU
-    my_lengths = [lengths[i] for i in my_batches[0]]
-    T_batch = max(my_lengths)
-    inp = make_inputs(B_PER_GPU, T_batch, seed=rank, lengths=my_lengths)
-    g = {k: v.to(dev) for k, v in inp.items() if k != "lengths"}
+    # workload: a list of device-resident batches this rank solves back to back in one step
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
     kw = dict(fake_speaker=fs.to(dev), fake_content=fc.to(dev), cfg_strength=CFG)
-    valid_frames_total = sum(lengths)
-    shard_imbalance, shard_padding = sharding.imbalance(lengths, per_rank)
+    if args.ragged:             # config 4 as the headline: the same utterances at every N, equal-cost buckets
+        batches, shard_info, _ = ragged_batches(world, rank, dev, args.ragged_utterances)
+        valid_frames_total = shard_info["valid_frames"]
+        if not batches:
+            raise SystemExit(f"rank {rank}: no bucket (fewer buckets than ranks)")
+    else:                       # config 2: one all-ones batch of 32 x 1000 per rank (independent units, weak scaling)
+        inp = make_inputs(B_PER_GPU, T_FRAMES, seed=rank)
+        batches = [{"g": {k: v.to(dev) for k, v in inp.items() if k != "lengths"}, "B": B_PER_GPU, "T": T_FRAMES, "valid": B_PER_GPU * T_FRAMES}]
+        valid_frames_total = B_PER_GPU * T_FRAMES * world
+        shard_info = {"utterances": B_PER_GPU * world, "valid_frames": valid_frames_total, "imbalance_max_over_mean": 1.0,
+                      "padded_over_valid_frames": 1.0, "batches_per_rank": [[B_PER_GPU]] * world}
+    g, T_batch, B_batch = batches[0]["g"], batches[0]["T"], batches[0]["B"]      # the rank's first (longest) batch: survey / roofline sampling
+
+    def solve(gg):
+        return dec(gg["mu"], gg["mask"], N_STEPS, 1.0, gg["c"], "euler", kw, z=gg["z"])
+
+    def step_all():
+        for b in batches:
+            out = solve(b["g"])
+        return out
 
     def step():
-        return dec(g["mu"], g["mask"], N_STEPS, 1.0, g["c"], "euler", kw, z=g["z"])
+        return solve(g)
 
     eng = dec.estimator.engine()
     for _ in range(args.warmup):
-        step()
+        step_all()
     heavy = ["ffn_conv1", "ffn_conv2", "attention", "qkv_rope", "lsc_conv", "out_proj"]
     # Survey pass (untimed): every heavy class timed with HIP events around every launch -> class breakdown and
     # the dominant class.  An event pair costs ~10 us of idle stream time (rocprofv3 kernel trace: 3.5 ms per
@@ -333,16 +494,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def allreduce_max(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    if len(batches) > 1:
+        step_all()              # back in the multi-shape rhythm (the survey ran one shape)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step_all()
     sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = allreduce_max(time.perf_counter() - t0)
     assert torch.isfinite(out).all()
     os.environ["ST_SPLIT"] = "1"
     step()
@@ -374,6 +540,11 @@ def main():
         return (time.perf_counter() - t1) / reps
 
     extras = {}
+    if not args.no_extras and not args.ragged:
+        # legs every rank takes part in: config 4 (strong scaling of one 256-utterance workload) and, for N > 1, config 5 (DDP)
+        extras["ragged"] = ragged_leg(dec, kw, world, rank, dev, sync, allreduce_max, max(2, args.steps // 3), args.ragged_utterances)
+        if world > 1 and not args.no_train_leg:
+            extras["train_ddp"] = train_ddp_leg(dev, sd, world, rank, dist, share_gpu, args.train_batch, T_FRAMES, args.dtype, 5)
     if rank == 0 and world == 1 and not args.no_extras:
         # (a) the other MFMA operand type on the same workload (f16 is the parity-gated configuration: it meets
         #     north_star's 1e-3 on the displacement metric; bf16 is BASELINE's named dtype and measures ~4e-3)
@@ -382,7 +553,7 @@ def main():
         dec2.estimator.load_state_dict(sd)
         dec2 = dec2.to(dev)
         sec = time_variant(dec2, g, N_STEPS, kw, max(3, args.steps // 2))
-        extras["other_dtype"] = {"dtype": other, "ms_per_step": sec * 1e3, "value": valid_frames_total / sec,
+        extras["other_dtype"] = {"dtype": other, "workload": f"rank 0's first batch, {B_batch} x {T_batch}", "ms_per_step": sec * 1e3, "value": batches[0]["valid"] / sec,
                                  "unit": "mel-frames/sec"}
         del dec2
         # (b) BASELINE config 1 shape on the GPU: one utterance, T=500, n=10 euler, CFG off (interactive latency)
@@ -409,29 +580,35 @@ def main():
         torch.cuda.synchronize(dev)
         voc_s = (time.perf_counter() - t2) / 10
         assert torch.isfinite(audio).all()
-        audio_seconds = valid_frames_total * 512 / 44100.0
-        extras["vocoder"] = {"workload": f"Vocos (8 ConvNeXt blocks dim 512 + ISTFT head), the batch's {B_PER_GPU} x {T_batch} mel frames, f16 operands",
-                             "ms_per_batch": voc_s * 1e3, "mel_frames_per_sec": B_PER_GPU * T_batch / voc_s,
-                             "decoder_plus_vocoder_audio_seconds_per_second": audio_seconds / (elapsed / args.steps + voc_s),
-                             "real_time_factor": (elapsed / args.steps + voc_s) / audio_seconds}
+        audio_seconds = batches[-1]["valid"] * 512 / 44100.0
+        dec_s = time_variant(dec, batches[-1]["g"], N_STEPS, kw, 3)
+        extras["vocoder"] = {"workload": f"Vocos (8 ConvNeXt blocks dim 512 + ISTFT head), the last batch's {out.shape[0]} x {out.shape[2]} mel frames, f16 operands",
+                             "ms_per_batch": voc_s * 1e3, "mel_frames_per_sec": out.shape[0] * out.shape[2] / voc_s,
+                             "decoder_plus_vocoder_audio_seconds_per_second": audio_seconds / (dec_s + voc_s),
+                             "real_time_factor": (dec_s + voc_s) / audio_seconds}
         del voc
         # (d) BASELINE config 5 on this GPU: one training step (forward with activations + backward + AdamW), native kernels
         if not args.no_train_leg:
-            extras["train_step"] = train_step_leg(dev, sd, 64, T_FRAMES, args.dtype, 5)
+            extras["train_step"] = train_step_leg(dev, sd, args.train_batch, T_FRAMES, args.dtype, 5)
 
     if rank == 0:
         p = prof[dom]
         avg_s = p["total_ms"] / max(p["launches"], 1) * 1e-3
         achieved = p["flops_per_launch"] / avg_s / 1e12
         n_evals = 2 * N_STEPS
-        falg = algorithmic_flops_per_frame(T_batch, n_evals, B_PER_GPU)
+        if args.ragged:         # padded-frame algorithmic FLOPs of every bucket of every rank (SURVEY 8d at each bucket's own B, T)
+            job_flops = sum(algorithmic_flops_per_frame(t, n_evals, n) * n * t for ns, ts in zip(shard_info["batches_per_rank"], shard_info["batch_max_len_per_rank"])
+                            for n, t in zip(ns, ts))
+        else:
+            job_flops = algorithmic_flops_per_frame(T_FRAMES, n_evals, B_PER_GPU) * B_PER_GPU * T_FRAMES * world
         line = {
             "metric": f"mel-frames/sec (whole node), 31M DiT, n_timesteps={N_STEPS}+CFG",
             "value": value, "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.ragged else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"BASELINE config 4: 31M CFM decoder, {world * B_PER_GPU} ragged utterances len~U{{600..1000}} "
-                                    f"sharded 32 per GPU (length-sorted batches), n_timesteps={N_STEPS} euler, cfg=3.0; value counts valid frames"
+            "config": {"workload": (f"BASELINE config 4: 31M CFM decoder, the same {shard_info['utterances']} ragged utterances len~U{{600..1000}} at every N "
+                                    f"(strong scaling), equal-cost length buckets (mean 32 utterances, variable count) dealt to the ranks, a rank's buckets "
+                                    f"solved back to back in one step, n_timesteps={N_STEPS} euler, cfg=3.0; value counts valid frames"
                                     if args.ragged else
                                     f"BASELINE config {2 if N_STEPS == 10 else 3}: 31M CFM decoder (hidden 256, filter 1024, 4 heads, 6 DiT blocks, "
                                     f"n_mels 128), batch 32 x T=1000 synthetic mu/mask per GPU, n_timesteps={N_STEPS} euler, "
@@ -439,17 +616,16 @@ def main():
                                    (f"; {args.dtype} MFMA operands" + (" -- same width as BASELINE's bf16, the type that meets north_star's 1e-3 "
                                                                         "(every gate of tests/test_gpu_parity.py)" if args.dtype == "f16" else
                                                                         " (BASELINE's named dtype; ~4e-3 on the displacement metric)")),
-                       "global_batch": world * B_PER_GPU, "seq_len": T_FRAMES,
+                       "global_batch": shard_info["utterances"], "seq_len": T_FRAMES,
                        "parallelism": f"utterance-sharded x{world}, no data-path collective"},
-            "sharding": {"imbalance_max_over_mean": shard_imbalance, "padded_over_valid_frames": shard_padding,
-                         "valid_frames": valid_frames_total, "padded_T_this_rank": T_batch},
+            "sharding": {**shard_info, "rank0_first_batch_B_x_T": [B_batch, T_batch]},
             "parity": "f16 operands (default, this line unless --dtype bf16) meet north_star's 1e-3 on the displacement metric and per "
                       "evaluation (tests/test_gpu_parity.py, gates 7e-4; this workload 3.0e-4 against the fp32 oracle, tools/parity_c2.py; with "
                       "trained-like O(1) adaLN gates at this size 7.3e-4 per evaluation / 4.1e-4 displacement, tools/parity_trained.py); "
                       "bf16 operands measure ~4e-3 (other_dtype)",
             "roofline": {"bound": "mfma", "kernel": ((class_kernel(dom, args.dtype) or "conv_gemm2_kernel") + f" [{dom}]"), "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(dom, args.dtype), "traffic_unit": "HBM bytes per launch (PMC)",
+                         "traffic": pmc_traffic(dom, args.dtype), "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": pmc_source(),
                          "launches_sampled": p["launches"], "sample_stride": PROFILE_STRIDE, "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": p["flops_per_launch"],
                          **({"flops_note": "algorithmic = the direct convolutions' multiply-adds (SURVEY 8d); ffn_wino_kernel executes 2/3 of them as MFMAs "
@@ -458,12 +634,12 @@ def main():
                          "sampled_over": f"{args.steps} single-sequence solves (ST_SPLIT=1, {single_seq_ms:.2f} ms each) run right after "
                                          "the timed region, whose concurrent part sequences (two streams by default) would fold the other parts' kernels "
                                          "into a launch's event-bracketed duration"},
-            "whole_solve_tflops": falg * B_PER_GPU * T_batch / (elapsed / args.steps) / 1e12 * world,
+            "whole_solve_tflops": job_flops / (elapsed / args.steps) / 1e12,
             "solve_parts": int(os.environ.get("ST_SPLIT", "-1")),
             "solve_parts_note": "-1 = library default: batches >= 24000 (CFG-doubled) frames run as two part-batch launch sequences on two streams (four only with the generic q/k/v tile, ST_QKV_WS=0)",
             "whole_solve_hbm": (lambda b: None if b is None else {
                 "bytes_per_solve_pmc": b, "achieved": b / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS})(pmc_solve_bytes() if N_STEPS == 10 else None),
+                "unit": "GB/s", "frac": b / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS})(pmc_solve_bytes() if N_STEPS == 10 and not args.ragged else None),
             "kernel_classes_ms_per_step": {k: v["total_ms"] for k, v in survey.items() if v["launches"]},
             "kernel_classes_note": f"untimed single-sequence survey solve (ST_SPLIT=1, {survey_ms:.2f} ms with its ~360 event pairs at "
                                    "~10 us each) with every launch of these six classes bracketed by HIP events on the launch stream; "

@@ -188,6 +188,26 @@ def test_winograd_opt_in_turns_the_finite_check_on(monkeypatch):
     assert CFMDecoder(*args).check_finite is False and CFMDecoder(*args, check_finite=True).check_finite is True
 
 
+def test_bench_env_lists_cover_every_variable_the_engine_reads():
+    """bench.py classifies the environment by explicit lists: every getenv("ST_*") of the engine sources (and the variables _lib.py /
+    build.py read) must be in exactly one of them, so a new switch cannot slip through as 'neutral' by default."""
+    import re
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    read = set()
+    csrc = os.path.join(ROOT, "stabletts_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".cpp", ".h", ".hip")):
+            read |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(os.path.join(csrc, f)).read()))
+    for f in ("_lib.py", "build.py", "flow_matching.py", "estimator.py"):
+        read |= set(re.findall(r'environ(?:\.get)?[\(\[]"((?:ST_|STABLETTS_)[A-Z_0-9]+)"', open(os.path.join(ROOT, "stabletts_amd", f)).read()))
+    listed = set(bench.ENGINE_ENV) | set(bench.ENGINE_NEUTRAL_ENV)
+    assert read <= listed, sorted(read - listed)
+    assert not set(bench.ENGINE_ENV) & set(bench.ENGINE_NEUTRAL_ENV)
+
+
 def test_bench_refuses_engine_changing_environment():
     """bench.py describes the library as shipped: with an ST_* variable that changes which kernels run (or STABLETTS_HIP_LIB) it
     refuses before touching the device; ST_SPLIT / ST_HIP_GRAPH only change how the same kernels are enqueued and pass."""
@@ -200,5 +220,8 @@ def test_bench_refuses_engine_changing_environment():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env={**env, "ST_SPLIT": "1"},
                        capture_output=True, text=True, timeout=300)
     assert "refusing to measure" not in (r.stderr + r.stdout)       # (on a CPU-only box it then stops at "needs a HIP device")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       env={**env, "ST_BUILD_OUT": "/tmp/x.so", "ST_BUILD_DEFS": "-DX"}, capture_output=True, text=True, timeout=300)
+    assert "refusing to measure" not in (r.stderr + r.stdout)       # build-only left-overs do not cost the harness its line
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs a HIP device" in (r.stderr + r.stdout)

@@ -370,18 +370,43 @@ def test_two_ranks_sharing_one_gpu_equal_single_process(tmp_path):
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's plain command form): bench.py
     re-executes itself under torch.distributed.run, one rank per GPU (BENCH_SHARE_GPU=1: both ranks on the one visible
-    GPU), and rank 0 prints exactly one JSON line for the whole job."""
+    GPU), and rank 0 prints exactly one JSON line for the whole job -- the config-2 headline (weak scaling) plus the two
+    multi-rank legs: "ragged" (config 4: ONE utterance set cut into equal-cost buckets, strong scaling) and "train_ddp"
+    (config 5: DistributedDataParallel around compute_loss; gloo here because the ranks share a device, RCCL otherwise).
+    Reduced leg sizes so that the test stays short."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BENCH_SHARE_GPU"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu-baseline", "--ragged-utterances", "48", "--train-batch", "4"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["dtype"] == "f16"
     assert j["config"]["global_batch"] == 64 and j["value"] > 0 and j["roofline"]["frac"] > 0
+    rg = j["ragged"]
+    assert rg["scaling"] == "strong" and rg["value"] > 0 and rg["sharding"]["utterances"] == 48
+    assert rg["sharding"]["imbalance_max_over_mean"] <= 1.05 and len(rg["sharding"]["batches_per_rank"]) == 2
+    assert sum(n for bs in rg["sharding"]["batches_per_rank"] for n in bs) == 48
+    td = j["train_ddp"]
+    assert td["ranks"] == 2 and td["backend"] == "gloo" and td["ms_per_step"] > 0 and td["allreduce_bytes_per_step"] > 80e6
+    assert td["mean_loss_last_step"] == td["mean_loss_last_step"]          # finite
+
+
+def test_bench_ragged_headline_is_one_workload_in_equal_cost_buckets():
+    """`bench.py --ragged` (config 4 as the headline): N = 1 solves the SAME utterance set an 8-GPU run shards -- all of its buckets
+    back to back inside the timed region -- so the driver's 1 -> 8 curve is strong scaling of one workload."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ragged", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extras", "--ragged-utterances", "96"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 1 and j["config"]["global_batch"] == 96
+    assert len(j["sharding"]["batches_per_rank"][0]) == 3 and sum(j["sharding"]["batches_per_rank"][0]) == 96
+    assert j["value"] > 0 and j["sharding"]["valid_frames"] < 96 * 1000
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])

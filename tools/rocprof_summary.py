@@ -24,6 +24,19 @@ def stats(path):
         print(f"{calls:7d} {tot:12.1f} {avg:10.2f} {pct:6.2f}  {name[:150]}")
 
 
+def _csrc_digest():
+    """Digest of the kernel sources + build flags the profiled library was built from (stabletts_amd.build): bench.py prints it next
+    to the digest of the sources it runs, so a table taken from older kernels is visible in the bench line."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from stabletts_amd import build
+        return build._digest()[:16]
+    except Exception:
+        return None
+
+
 def pmc(fetch_csv, write_csv):
     agg = collections.defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0, "wl": 0})
     for r in csv.DictReader(open(fetch_csv)):
@@ -45,7 +58,7 @@ def pmc(fetch_csv, write_csv):
     # whole-solve HBM traffic: every kernel of the run, divided by the number of solves (one from_time_major per solve)
     solves = max([v["launches"] for k, v in out.items() if "from_time_major" in k] or [1])
     total = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in out.values())
-    out["_summary"] = {"solves": solves, "hbm_bytes_per_solve": total / solves}
+    out["_summary"] = {"solves": solves, "hbm_bytes_per_solve": total / solves, "csrc_digest": _csrc_digest()}
     print(f"# {solves} solves in the run, {total / solves / 1e9:.2f} GB of HBM traffic per solve (all kernels)")
     return out
 
