@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
 
 hipError_t launch_attn_bwd_dq(int dtype, const AttnBwdArgs& a, hipStream_t s) {
     if (!a.zeros || !a.kbias || !a.lse || !a.Dq || !a.Fq || !a.aq || !a.vmean || !a.kmean || !a.vlo || !a.dsmax) return hipErrorInvalidValue;
-    if (hipMemsetAsync(a.dsmax, 0, (size_t)a.n_items * a.H * 4, s) != hipSuccess) return hipErrorInvalidValue;
+    // a.dsmax ([n_items * H] maxima the first pass publishes) must arrive ZEROED: the engine zeroes the cells of all blocks in one memset
     const int qtiles = (a.T + 255) / 256;
     const int total = a.n_items * a.H * qtiles;
     const int grid = ((total + 7) / 8) * 8;

@@ -64,13 +64,35 @@ struct TrainState {
     float *dX, *dskip[8], *tmpC, *tmpF, *Dbuf, *Fbuf, *abuf, *alphabuf, *vmean, *qmean, *kmean, *dq, *dk, *dv, *partial, *part_b, *red, *dada, *dfilm, *dtau, *dth, *demb, *dcvec,
           *gin, *gsc;
     unsigned *gbits, *dsmax, *qbits;
+    // one zeroed region per backward (a single memset in bwd_head): the maximum cells of every re-centring point (a group of
+    // kMaxCellWords each), max |dq|, |dk|, |dv| per block (qbits_all + 4 i) and the dS bounds per block (dsmax_all + i N H)
+    unsigned *zero_region = nullptr, *cells_ring = nullptr, *qbits_all = nullptr, *dsmax_all = nullptr; size_t zero_bytes = 0;
+    int cell_idx = 0;
+    float* gsc_ring = nullptr; int gsc_slots = 0;     // the pass-wide scale pair lives in a ring of slots: a re-centring point writes the NEXT slot (ts->gsc moves on)
+    const float* skip_gsc[8] = {};                    // the slot each long-skip gradient was written under
+    float* red_site[5] = {};                          // per-(item, chunk) partial sums of a block's five row kernels (one reduce launch per block)
+    unsigned *drop_rowh_all = nullptr, *drop_colh_all = nullptr; size_t drop_row_stride = 0, drop_col_stride = 0;   // dropout tables of every attention site
     bool fuse_ln = true;                        // ST_FUSE_TRAIN_LN=0: stand-alone residual / LayerNorm kernels after out-proj and FFN conv_2 (A/B)
     bool fuse_silu = true;                      // ST_FUSE_SILU=0: stand-alone silu_drop / silu_bwd kernels (A/B and the bit-identity test)
     unsigned *drop_rowh, *drop_colh;            // dropout hash tables of the attention site being processed (launch_drop_tables)
     float* skip_sc;                             // {scale, 1 / scale} each long-skip gradient was written at
     float* qs;                                  // local scales of the attention-input gradients (launch_qkv_grad_scales)
-    void* g16w;                                 // d [q | k | v] with per-tensor scales: the dY operand of their weight gradients
-    void *g16a, *g16b, *vnat, *vnat_lo, *qT, *kT, *dOT, *xt, *dyt;
+    // 16-bit gradient operands.  Every tensor a weight-gradient GEMM reads has its OWN buffer: the weight gradients run on a side
+    // stream (below) and may still be reading when the main chain produces the next operand.
+    enum { DY_FFN2, DY_FFN1, DY_OPROJ, DY_DATTN, DY_QKVD, DY_QKVW, DY_LSC, DY_HEAD, DY_T0, DY_T1, DY_T2, DY_T3, DY_COUNT };
+    void* dy[DY_COUNT] = {};
+    void *vnat, *vnat_lo, *qT, *kT, *dOT, *xt, *dyt;
+    // Side streams of the backward (ST_TRAIN_SIDE=0: everything on the caller's stream; results are bitwise identical either way):
+    //   side  -- every weight-gradient GEMM + its reduction.  Nothing on the main chain reads their outputs; they only have to be
+    //            finished when a backward part returns.  The main chain (data gradients, row kernels, attention) no longer waits
+    //            for them, and their small reduce launches run beside the main chain's big kernels.
+    //   side2 -- the gradient-INDEPENDENT operand copies of a block's attention backward (centred q / k / v copies, T layouts),
+    //            forked at the start of the block and joined in front of its attention kernels.
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t ev_fork[16] = {}, ev_site[DY_COUNT] = {}, ev_join = nullptr, ev_blk = nullptr, ev_prep = nullptr;
+    bool site_pending[DY_COUNT] = {};
+    int fork_idx = 0;
+    bool use_side = true;
     size_t partial_cap = 0, xt_cap = 0, dyt_cap = 0;
 };
 
@@ -124,6 +146,17 @@ int train_prepare(st_engine* e, hipStream_t s) {
         e->train = new TrainState();
         if (const char* v = getenv("ST_FUSE_SILU")) e->train->fuse_silu = atoi(v) != 0;
         if (const char* v = getenv("ST_FUSE_TRAIN_LN")) e->train->fuse_ln = atoi(v) != 0;
+        if (const char* v = getenv("ST_TRAIN_SIDE")) e->train->use_side = atoi(v) != 0;
+        TrainState* t0 = e->train;
+        if (t0->use_side) {
+            HIPCHK(e, hipStreamCreateWithFlags(&t0->side, hipStreamNonBlocking));
+            HIPCHK(e, hipStreamCreateWithFlags(&t0->side2, hipStreamNonBlocking));
+            for (auto& ev : t0->ev_fork) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            for (auto& ev : t0->ev_site) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&t0->ev_join, hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&t0->ev_blk, hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&t0->ev_prep, hipEventDisableTiming));
+        }
     }
     TrainState* ts = e->train;
     if (ts->packed) return ST_OK;
@@ -192,6 +225,11 @@ int64_t train_bytes(const st_engine* e) {      // transposed weights + gradient 
 void train_destroy(st_engine* e) {
     if (!e->train) return;
     for (void* p : e->train->owned) hipFree(p);
+    if (e->train->side) { hipStreamSynchronize(e->train->side); hipStreamDestroy(e->train->side); }
+    if (e->train->side2) { hipStreamSynchronize(e->train->side2); hipStreamDestroy(e->train->side2); }
+    for (auto ev : e->train->ev_fork) if (ev) hipEventDestroy(ev);
+    for (auto ev : e->train->ev_site) if (ev) hipEventDestroy(ev);
+    for (auto ev : {e->train->ev_join, e->train->ev_blk, e->train->ev_prep}) if (ev) hipEventDestroy(ev);
     if (e->train->ws) hipFree(e->train->ws);
     delete e->train;
     e->train = nullptr;
@@ -232,8 +270,12 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->dX, R * C * 4);
     for (int j = 0; j < L / 2; ++j) want((void**)&ts->dskip[j], R * C * 4);
     want((void**)&ts->tmpC, R * C * 4); want((void**)&ts->tmpF, R * F * 4); want((void**)&ts->gin, R * Mp * 4);
-    want(&ts->g16a, R * F * 2); want(&ts->g16b, R * 3 * C * 2); want(&ts->g16w, R * 3 * C * 2);
-    want((void**)&ts->qs, 64); want((void**)&ts->qbits, 16);
+    {
+        const size_t w[TrainState::DY_COUNT] = {(size_t)C, (size_t)F, (size_t)C, (size_t)C, (size_t)3 * C, (size_t)3 * C, (size_t)C, (size_t)std::max(C, Mp),
+                                                (size_t)C, (size_t)C, (size_t)F, (size_t)F};
+        for (int k = 0; k < TrainState::DY_COUNT; ++k) want(&ts->dy[k], R * w[k] * 2);
+    }
+    want((void**)&ts->qs, (size_t)L * 64); want((void**)&ts->qbits, 16);      // qs: one 16-float record per block (the side stream's reduce reads it after the main chain has moved on)
     want((void**)&ts->drop_rowh, (N * H * TT + 64) * 4); want((void**)&ts->drop_colh, (size_t)(Tp / 2 + 64) * 4);
     want(&ts->vnat, R * C * 2); want(&ts->vnat_lo, R * C * 2); want((void**)&ts->dsmax, N * H * 4); want(&ts->qT, N * C * Tp * 2); want(&ts->kT, N * C * Tp * 2); want(&ts->dOT, N * C * Tp * 2);
     want((void**)&ts->Dbuf, N * H * TT * 4); want((void**)&ts->Fbuf, N * H * TT * 4); want((void**)&ts->abuf, N * H * TT * 4);
@@ -248,6 +290,16 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
     want((void**)&ts->partial, ts->partial_cap);
     want((void**)&ts->part_b, (Rpad / 64) * (size_t)std::max(F, 3 * C) * 4);
     want((void**)&ts->red, N * (size_t)red_chunks(T) * 2 * 256 * 4);
+    for (int k = 0; k < 5; ++k) want((void**)&ts->red_site[k], N * (size_t)red_chunks(T) * 2 * 256 * 4);
+    ts->gsc_slots = 4 * L + 8;
+    want((void**)&ts->gsc_ring, (size_t)ts->gsc_slots * 16);
+    {
+        const size_t cells = (size_t)(4 * L + 8) * kMaxCellWords, qb = (size_t)4 * L, dm = (size_t)L * N * H;
+        ts->zero_bytes = (cells + qb + dm) * 4;
+        want((void**)&ts->zero_region, ts->zero_bytes);
+    }
+    ts->drop_row_stride = (size_t)N * H * TT + 64; ts->drop_col_stride = (size_t)(Tp / 2 + 64);
+    want((void**)&ts->drop_rowh_all, (size_t)L * ts->drop_row_stride * 4); want((void**)&ts->drop_colh_all, (size_t)L * ts->drop_col_stride * 4);
     want((void**)&ts->dada, (size_t)L * N * 6 * C * 4); want((void**)&ts->dfilm, (size_t)L * N * 2 * C * 4);
     want((void**)&ts->dtau, N * C * 4); want((void**)&ts->dth, N * F * 4); want((void**)&ts->demb, N * C * 4);
     want((void**)&ts->dcvec, N * G * 4);
@@ -258,6 +310,9 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
         ts->ws_cap = off;
     }
     for (auto& sl : slots) *sl.dst = ts->ws + sl.off;
+    ts->cells_ring = ts->zero_region;
+    ts->qbits_all = ts->zero_region + (size_t)(4 * L + 8) * kMaxCellWords;
+    ts->dsmax_all = ts->qbits_all + (size_t)4 * L;
     ts->B = B; ts->T = T; ts->Tp = Tp;
     return ST_OK;
 }
@@ -316,6 +371,12 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         HIPCHK(e, launch_linear(ain, N, C, P(e, pa + "weight"), P(e, pa + "bias"), 6 * C, ts->ada + (size_t)i * N * 6 * C, 1, 0, s));
     }
     const DropCfg nodrop = make_drop(0.f, 0, 0);
+    if (make_drop(p_dropout, seed, 1).thresh16) {      // the hash tables of all L attention sites, once: forward and backward read them
+        DropSeeds sd; memset(&sd, 0, sizeof(sd));
+        if (L > 16) return e->fail(ST_ERR_INVALID, "training supports up to 16 blocks");
+        for (int i = 0; i < L; ++i) sd.seed[i] = make_drop(p_dropout, seed, 2 * i + 1).seed;
+        HIPCHK(e, launch_drop_tables_multi(sd, L, N * H * T + 64, Tp / 2, ts->drop_rowh_all, ts->drop_colh_all, ts->drop_row_stride, ts->drop_col_stride, s));
+    }
     // cond prenet (estimator.py:83-89,118): pre-activations kept for SiLU'
     {
         ConvGemmArgs a = cargs(e, e->pre[0], N, T, B); a.a0 = ts->mu16; a.c0 = Mp; a.out16 = ts->a1;
@@ -365,10 +426,7 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
             a.q = A.q; a.k = A.k; a.vt = A.vt; a.out = A.attn16; a.kbias = ts->kbias; a.mask_mod = B; a.zeros = e->zeros;
             a.kv_end = ts->kv_end; a.n_full = ts->n_full; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
             a.lse = A.lse; a.drop = make_drop(p_dropout, seed, 2 * i + 1);
-            if (a.drop.thresh16) {
-                HIPCHK(e, launch_drop_tables(a.drop, N * H * T + 64, Tp / 2, ts->drop_rowh, ts->drop_colh, s));
-                a.drop.rowh = ts->drop_rowh; a.drop.colh = ts->drop_colh;
-            }
+            if (a.drop.thresh16) { a.drop.rowh = ts->drop_rowh_all + (size_t)i * ts->drop_row_stride; a.drop.colh = ts->drop_colh_all + (size_t)i * ts->drop_col_stride; }
             HIPCHK(e, launch_attention(e->dt, a, s));
         }
         if (ts->fuse_ln) {   // o = (Wo attn + b) * mask ; x2 = x1 + g_msa * o ; LN2 + modulate, masked -> h2: one GEMM with the
@@ -478,16 +536,16 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
         while ((size_t)((kchunks + cps - 1) / cps) * frames * cout16 * 4 > ts->partial_cap && cps < kchunks) ++cps;
         const int S_tn = (kchunks + cps - 1) / cps;
         if ((size_t)S_tn * frames * cout16 * 4 <= ts->partial_cap) {
-            HIPCHK(e, launch_wgrad_tn(e->dt, dy, cout16, x0, c0, x1, c1, taps, N, T, cps, e->zeros, ts->partial, s));
             bool need_b = false;
             for (int k = 0; k < n_outs; ++k) need_b = need_b || outs[k].db;
-            if (need_b) HIPCHK(e, launch_colsum_rows(e->dt, dy, cout16, R, ts->part_b, s));
+            // bias-gradient partials [S_tn][cout16] come out of the GEMM itself (the first N tile's blocks sum the dY fragments they hold)
+            HIPCHK(e, launch_wgrad_tn(e->dt, dy, cout16, x0, c0, x1, c1, taps, N, T, cps, e->zeros, ts->partial, need_b ? ts->part_b : nullptr, s));
+            WgradRed red[3];
             for (int k = 0; k < n_outs; ++k) {
                 const WgradOut& o = outs[k];
-                const float* us = o.unscale ? o.unscale : ts->gsc;
-                if (o.dW) HIPCHK(e, launch_wgrad_reduce(ts->partial, S_tn, cin, cout16, taps, o.dW, o.cin_total, o.ci_off, o.ci_cnt, o.co_start, o.co_cnt, us, s));
-                if (o.db) HIPCHK(e, launch_bias_reduce(ts->part_b, (int)((R + 63) / 64), cout16, o.db, o.co_start, o.co_cnt, us, s));
+                red[k] = {o.dW, o.db, o.unscale ? o.unscale : ts->gsc, o.cin_total, o.ci_off, o.ci_cnt, o.co_start, o.co_cnt};
             }
+            HIPCHK(e, launch_wgrad_reduce_multi(ts->partial, need_b ? ts->part_b : nullptr, S_tn, cin, cout16, taps, red, n_outs, s));
             return ST_OK;
         }
     }
@@ -519,6 +577,35 @@ int wgrad(st_engine* e, TrainState* ts, const void* x0, int c0, const void* x1, 
 
 float* G(TrainState* ts, const std::string& name) { return ts->gbase + ts->goff.at(name); }
 
+// The weight gradient of one site on the side stream: it starts when everything enqueued on `s` so far (the producer of its dY
+// operand) has run, and records the site's event when it is done with that operand.
+int wgrad_side(st_engine* e, TrainState* ts, int site, const void* x0, int c0, const void* x1, int c1, int cout16, int taps,
+               const WgradOut* outs, int n_outs, hipStream_t s) {
+    const void* dy = ts->dy[site];
+    if (!ts->use_side) return wgrad(e, ts, x0, c0, x1, c1, dy, cout16, taps, outs, n_outs, s);
+    hipEvent_t f = ts->ev_fork[ts->fork_idx]; ts->fork_idx = (ts->fork_idx + 1) % 16;
+    HIPCHK(e, hipEventRecord(f, s));
+    HIPCHK(e, hipStreamWaitEvent(ts->side, f, 0));
+    int rc = wgrad(e, ts, x0, c0, x1, c1, dy, cout16, taps, outs, n_outs, ts->side);
+    if (rc) return rc;
+    HIPCHK(e, hipEventRecord(ts->ev_site[site], ts->side));
+    ts->site_pending[site] = true;
+    return ST_OK;
+}
+// ... and in front of the kernel that OVERWRITES a site's dY operand: wait until the previous block's weight gradient has read it
+int site_free(st_engine* e, TrainState* ts, int site, hipStream_t s) {
+    if (ts->use_side && ts->site_pending[site]) { HIPCHK(e, hipStreamWaitEvent(s, ts->ev_site[site], 0)); ts->site_pending[site] = false; }
+    return ST_OK;
+}
+// end of a backward part: the parameter gradients must be complete when the call returns its stream to the caller
+int side_join(st_engine* e, TrainState* ts, hipStream_t s) {
+    if (!ts->use_side) return ST_OK;
+    HIPCHK(e, hipEventRecord(ts->ev_join, ts->side));
+    HIPCHK(e, hipStreamWaitEvent(s, ts->ev_join, 0));
+    for (auto& p : ts->site_pending) p = false;
+    return ST_OK;
+}
+
 }  // namespace
 }  // namespace sthost
 
@@ -543,11 +630,16 @@ BwdDims bwd_dims(const st_engine* e, const TrainState* ts) {
 // gradients to 16 bits: block boundaries and, inside a block, after each LayerNorm backward -- with trained-like weights (adaLN
 // gates of O(1), peaky attention) the gradient grows by more than two orders of magnitude INSIDE a block and overflowed f16
 // (65504) when the scale was only re-centred per block (profiles/r04_nan_trace.txt).
-int recentre(st_engine* e, TrainState* ts, const BwdDims& d, hipStream_t s) {
-    HIPCHK(e, launch_grad_rescale(ts->dX, d.R * d.C, ts->gbits, ts->gsc, s));
-    HIPCHK(e, launch_scale_by(ts->dX, d.R * d.C, ts->gsc, s));
+int recentre(st_engine* e, TrainState* ts, const BwdDims& d, bool have_max, hipStream_t s) {
+    // have_max: the kernel that wrote dX last published max |dX| into next_cells(ts) (ln_bwd / add_rescaled); else an absmax pass runs here
+    unsigned* cells = ts->cells_ring + (size_t)ts->cell_idx * kMaxCellWords;
+    float* next = ts->gsc + 4;
+    if (ts->cell_idx + 1 >= 4 * d.L + 8 || next >= ts->gsc_ring + (size_t)ts->gsc_slots * 4) return e->fail(ST_ERR_STATE, "re-centring ring exhausted");
+    HIPCHK(e, launch_recentre(ts->dX, d.R * d.C, cells, have_max, ts->gsc, next, s));
+    ts->gsc = next; ts->cell_idx += 1;
     return ST_OK;
 }
+inline unsigned* next_cells(TrainState* ts) { return ts->cells_ring + (size_t)ts->cell_idx * kMaxCellWords; }
 
 int bwd_head(st_engine* e, TrainState* ts, const float* grad_out, hipStream_t s) {
     const BwdDims d = bwd_dims(e, ts);
@@ -556,23 +648,34 @@ int bwd_head(st_engine* e, TrainState* ts, const float* grad_out, hipStream_t s)
     const float* m = ts->maskbuf;
     int rc;
     const bool cap = e->capture;
-    HIPCHK(e, hipMemsetAsync(ts->dada, 0, (size_t)L * N * 6 * C * 4, s));
-    HIPCHK(e, hipMemsetAsync(ts->dfilm, 0, (size_t)L * N * 2 * C * 4, s));
-    for (const char* nm : {"time_mlp.layer.0.weight", "time_mlp.layer.0.bias", "time_mlp.layer.2.weight", "time_mlp.layer.2.bias"})
-        HIPCHK(e, hipMemsetAsync(G(ts, nm), 0, (size_t)e->params.at(nm).numel() * 4, s));
-    HIPCHK(e, hipMemsetAsync(ts->dcvec, 0, (size_t)N * e->G * 4, s));
-    HIPCHK(e, hipMemsetAsync(ts->dtau, 0, (size_t)N * C * 4, s));
+    // ONE memset per backward: the maximum cells of the re-centring points, the attention kernels' max / bound cells of every block.
+    // (d ada / d film rows, the per-item linears' gradients and d c / d tau are WRITTEN by their first producer: no zero fills.)
+    HIPCHK(e, hipMemsetAsync(ts->zero_region, 0, ts->zero_bytes, s));
+    ts->cell_idx = 0; ts->gsc = ts->gsc_ring;
     // d v (time-major, masked: out = (W x + b) * mask), as the 16-bit operand of the first GEMMs
     HIPCHK(e, launch_grad_scale(grad_out, (int64_t)B * M * T, ts->gbits, ts->gsc, s));
     HIPCHK(e, launch_to_time_major(e->dt, grad_out, B, M, T, Mp, ts->gin, nullptr, nullptr, s));
-    HIPCHK(e, launch_cast16(e->dt, ts->gin, m, B, T, Mp, R, ts->gsc, ts->g16a, s));
+    HIPCHK(e, launch_cast16(e->dt, ts->gin, m, B, T, Mp, R, ts->gsc, ts->dy[TrainState::DY_HEAD], s));
     {   // final_proj
         WgradOut o = {G(ts, "final_proj.weight"), C, 0, C, 0, M, G(ts, "final_proj.bias")};
-        if ((rc = wgrad(e, ts, ts->L[L - 1].x3_16, C, nullptr, 0, ts->g16a, Mp, 1, &o, 1, s))) return rc;
-        ConvGemmArgs a = cargs(e, ts->finT, N, T, B); a.a0 = ts->g16a; a.c0 = Mp; a.mask = m; a.flags = GF_MASK; a.out32 = ts->dX;
+        if ((rc = wgrad_side(e, ts, TrainState::DY_HEAD, ts->L[L - 1].x3_16, C, nullptr, 0, Mp, 1, &o, 1, s))) return rc;
+        ConvGemmArgs a = cargs(e, ts->finT, N, T, B); a.a0 = ts->dy[TrainState::DY_HEAD]; a.c0 = Mp; a.mask = m; a.flags = GF_MASK; a.out32 = ts->dX;
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
     if (cap) { capture(e, "g.scale", ts->gsc, 2, false, s); capture(e, "g.x3_" + std::to_string(L - 1), ts->dX, R * C, false, s); }
+    return ST_OK;
+}
+
+// The gradient-independent operand copies of block i's attention backward: V back to natural rows, centred, as a hi + lo pair;
+// the means of q and k; centred T-layout copies of q and k (attention_bwd.hip's header says why).
+int attn_prep(st_engine* e, TrainState* ts, int i, hipStream_t s) {
+    const int H = e->H, N = ts->B, T = ts->T, Tp = ts->Tp;
+    LayerAct& A = ts->L[i];
+    HIPCHK(e, launch_attn_from_T(e->dt, A.vt, N, H, T, Tp, ts->vmean, ts->vnat, ts->vnat_lo, s));
+    HIPCHK(e, launch_attn_mean_nat(e->dt, A.q, N * H, T, ts->qmean, s));
+    HIPCHK(e, launch_attn_mean_nat(e->dt, A.k, N * H, T, ts->kmean, s));
+    HIPCHK(e, launch_attn_to_T(e->dt, A.q, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->qmean, ts->qT, s));
+    HIPCHK(e, launch_attn_to_T(e->dt, A.k, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->kmean, ts->kT, s));
     return ST_OK;
 }
 
@@ -583,6 +686,12 @@ int bwd_block(st_engine* e, TrainState* ts, int i, hipStream_t s) {
     const float* m = ts->maskbuf;
     int rc;
     const bool cap = e->capture;
+    if (ts->use_side) {      // (everything enqueued on s so far includes the previous block's attention kernels, the last readers of the copies)
+        HIPCHK(e, hipEventRecord(ts->ev_blk, s));
+        HIPCHK(e, hipStreamWaitEvent(ts->side2, ts->ev_blk, 0));
+        if ((rc = attn_prep(e, ts, i, ts->side2))) return rc;
+        HIPCHK(e, hipEventRecord(ts->ev_prep, ts->side2));
+    }
     {
         LayerAct& A = ts->L[i];
         const std::string b = e->blk(i);
@@ -593,133 +702,137 @@ int bwd_block(st_engine* e, TrainState* ts, int i, hipStream_t s) {
         // re-centred on the running gradient here and after each LayerNorm backward (recentre), so that every 16-bit operand
         // derived from it sits in f16's range.  Every fp32 result is un-scaled by the pair current at the time it is written; a
         // long-skip gradient remembers the scale it was written at (skip_sc) and is converted when it is added.
-        if (i < L - 1 && (rc = recentre(e, ts, d, s))) return rc;
+        // (block i + 1 wrote dX last through add_rescaled -- which published the maximum -- when it lies in the first half, else through a GEMM)
+        if (i < L - 1 && (rc = recentre(e, ts, d, i + 1 < L / 2, s))) return rc;
         if (cap) capture(e, "g.scale_" + std::to_string(i), ts->gsc, 2, false, s);      // the scale block i's captured tensors carry
+        RedSites sites; memset(&sites, 0, sizeof(sites));      // the block's per-(item, channel) sums: ONE reduce launch at its end
+        auto site = [&](int k, int K, float* out, int out_stride, int off0, int off1) {
+            sites.s[sites.n] = RedSite{ts->red_site[k], K, out, out_stride, {off0, off1}, ts->gsc};      // the pair current NOW un-scales these sums
+            sites.n += 1;
+            return ts->red_site[k];
+        };
         // ---- x3 = x2 + g_mlp * f
-        HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.f32b, ada_i + 5 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
-        { const int off[1] = {5 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 1, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        if ((rc = site_free(e, ts, TrainState::DY_FFN2, s))) return rc;
+        HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.f32b, ada_i + 5 * C, 6 * C, m, B, T, N, ts->dy[TrainState::DY_FFN2], site(0, 1, dada_i, 6 * C, 5 * C, 0), s));
         {   // conv_2
             WgradOut o = {G(ts, b + "mlp.conv_2.weight"), F, 0, F, 0, C, G(ts, b + "mlp.conv_2.bias")};
-            if ((rc = wgrad(e, ts, A.u16, F, nullptr, 0, ts->g16b, C, K, &o, 1, s))) return rc;
-            ConvGemmArgs a = cargs(e, ts->ffn2T[i], N, T, B); a.a0 = ts->g16b; a.c0 = C;
+            if ((rc = wgrad_side(e, ts, TrainState::DY_FFN2, A.u16, F, nullptr, 0, C, K, &o, 1, s))) return rc;
+            if ((rc = site_free(e, ts, TrainState::DY_FFN1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->ffn2T[i], N, T, B); a.a0 = ts->dy[TrainState::DY_FFN2]; a.c0 = C;
             const DropCfg dc = make_drop(ts->p_drop, ts->seed, 2 * i);
             if (ts->fuse_silu && K == 3 && gemm_is_phased(e, 3, a) && !a.bias) {      // d pre-activation straight from the dgrad's epilogue
-                a.out16 = ts->g16a; a.dact16 = A.a16; a.mask = m; a.drop_seed = dc.seed; a.drop_thresh16 = dc.thresh16; a.drop_scale = dc.scale;
+                a.out16 = ts->dy[TrainState::DY_FFN1]; a.dact16 = A.a16; a.mask = m; a.drop_seed = dc.seed; a.drop_thresh16 = dc.thresh16; a.drop_scale = dc.scale;
                 HIPCHK(e, gemm(e, K, EPI_SILU, a, s));
             } else {
                 a.out32 = ts->tmpF;
                 HIPCHK(e, gemm(e, K, EPI_F32, a, s));
-                HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, A.a16, m, B, T, F, R, dc, ts->g16a, s));
+                HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, A.a16, m, B, T, F, R, dc, ts->dy[TrainState::DY_FFN1], s));
             }
         }
         {   // conv_1
             WgradOut o = {G(ts, b + "mlp.conv_1.weight"), C, 0, C, 0, F, G(ts, b + "mlp.conv_1.bias")};
-            if ((rc = wgrad(e, ts, A.h2, C, nullptr, 0, ts->g16a, F, K, &o, 1, s))) return rc;
-            ConvGemmArgs a = cargs(e, ts->ffn1T[i], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->tmpC;
+            if ((rc = wgrad_side(e, ts, TrainState::DY_FFN1, A.h2, C, nullptr, 0, F, K, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->ffn1T[i], N, T, B); a.a0 = ts->dy[TrainState::DY_FFN1]; a.c0 = F; a.out32 = ts->tmpC;
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
         }
-        HIPCHK(e, launch_ln_bwd(A.x2, ts->tmpC, ada_i, 6 * C, 4 * C, m, B, 1, T, N, ts->dX, ts->red, nullptr, s));
-        { const int off[2] = {4 * C, 3 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        HIPCHK(e, launch_ln_bwd(A.x2, ts->tmpC, ada_i, 6 * C, 4 * C, m, B, 1, T, N, ts->dX, site(1, 2, dada_i, 6 * C, 4 * C, 3 * C), nullptr, next_cells(ts), s));
         if (cap) capture(e, "g.x2_" + std::to_string(i), ts->dX, R * C, false, s);
-        if ((rc = recentre(e, ts, d, s))) return rc;
+        if ((rc = recentre(e, ts, d, true, s))) return rc;
         if (cap) capture(e, "g.scale_a" + std::to_string(i), ts->gsc, 2, false, s);      // the scale of this block's attention-part tensors
         // ---- x2 = x1 + g_msa * o
-        HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.o32, ada_i + 2 * C, 6 * C, m, B, T, N, ts->g16b, ts->red, s));
-        { const int off[1] = {2 * C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 1, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        if ((rc = site_free(e, ts, TrainState::DY_OPROJ, s))) return rc;
+        HIPCHK(e, launch_gate_bwd(e->dt, ts->dX, A.o32, ada_i + 2 * C, 6 * C, m, B, T, N, ts->dy[TrainState::DY_OPROJ], site(2, 1, dada_i, 6 * C, 2 * C, 0), s));
         {   // out projection
             WgradOut o = {G(ts, b + "attn.conv_o.weight"), C, 0, C, 0, C, G(ts, b + "attn.conv_o.bias")};
-            if ((rc = wgrad(e, ts, A.attn16, C, nullptr, 0, ts->g16b, C, 1, &o, 1, s))) return rc;
-            ConvGemmArgs a = cargs(e, ts->oprojT[i], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out16 = ts->g16a;      // d attn (16 bit)
+            if ((rc = wgrad_side(e, ts, TrainState::DY_OPROJ, A.attn16, C, nullptr, 0, C, 1, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->oprojT[i], N, T, B); a.a0 = ts->dy[TrainState::DY_OPROJ]; a.c0 = C; a.out16 = ts->dy[TrainState::DY_DATTN];      // d attn (16 bit)
             HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
         }
         {   // attention
-            HIPCHK(e, launch_attn_from_T(e->dt, A.vt, N, H, T, Tp, ts->vmean, ts->vnat, ts->vnat_lo, s));
-            HIPCHK(e, launch_attn_mean_nat(e->dt, A.q, N * H, T, ts->qmean, s));
-            HIPCHK(e, launch_attn_mean_nat(e->dt, A.k, N * H, T, ts->kmean, s));
-            HIPCHK(e, launch_attn_to_T(e->dt, A.q, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->qmean, ts->qT, s));
-            HIPCHK(e, launch_attn_to_T(e->dt, A.k, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->kmean, ts->kT, s));
-            HIPCHK(e, launch_attn_to_T(e->dt, ts->g16a, (int64_t)T * C, 64, C, N, H, T, Tp, nullptr, ts->dOT, s));
+            if (ts->use_side) HIPCHK(e, hipStreamWaitEvent(s, ts->ev_prep, 0));      // the operand copies forked at the start of the block
+            else if ((rc = attn_prep(e, ts, i, s))) return rc;
+            HIPCHK(e, launch_attn_to_T(e->dt, ts->dy[TrainState::DY_DATTN], (int64_t)T * C, 64, C, N, H, T, Tp, nullptr, ts->dOT, s));
             AttnBwdArgs a; memset(&a, 0, sizeof(a));
             a.q = A.q; a.k = A.k; a.v = ts->vnat; a.vlo = ts->vnat_lo; a.dsmax = ts->dsmax; a.qT = ts->qT; a.kT = ts->kT; a.dOT = ts->dOT;
-            a.dO = ts->g16a; a.dO_row_stride = C; a.lse = A.lse; a.vmean = ts->vmean; a.qmean = ts->qmean; a.kmean = ts->kmean;
+            a.dO = ts->dy[TrainState::DY_DATTN]; a.dO_row_stride = C; a.lse = A.lse; a.vmean = ts->vmean; a.qmean = ts->qmean; a.kmean = ts->kmean;
             a.Dq = ts->Dbuf; a.Fq = ts->Fbuf; a.aq = ts->abuf; a.alphaq = ts->alphabuf; a.kbias = ts->kbias; a.mask_mod = B;
             a.kv_end = ts->kv_end; a.dq = ts->dq; a.dk = ts->dk; a.dv = ts->dv; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
             a.drop = make_drop(ts->p_drop, ts->seed, 2 * i + 1); a.zeros = e->zeros;
-            if (a.drop.thresh16) {
-                HIPCHK(e, launch_drop_tables(a.drop, N * H * T + 64, Tp / 2, ts->drop_rowh, ts->drop_colh, s));
-                a.drop.rowh = ts->drop_rowh; a.drop.colh = ts->drop_colh;
-            }
-            HIPCHK(e, hipMemsetAsync(ts->qbits, 0, 12, s));
-            a.gmax = ts->qbits;          // the kernels publish max |dq|, |dk|, |dv| themselves
+            if (a.drop.thresh16) { a.drop.rowh = ts->drop_rowh_all + (size_t)i * ts->drop_row_stride; a.drop.colh = ts->drop_colh_all + (size_t)i * ts->drop_col_stride; }
+            unsigned* qbits = ts->qbits_all + 4 * i;      // (zeroed with the rest of zero_region in bwd_head)
+            a.dsmax = ts->dsmax_all + (size_t)i * N * H;
+            a.gmax = qbits;              // the kernels publish max |dq|, |dk|, |dv| themselves
             HIPCHK(e, launch_attn_bwd_dq(e->dt, a, s));
             HIPCHK(e, launch_attn_bwd_dkv(e->dt, a, s));
             // d q, d k are ~1/T of d v: each gets its own power-of-two factor before the rounding to 16 bits (f16's normal
             // range ends at 6e-5); the fused dgrad GEMM takes the copy with one common factor
-            HIPCHK(e, launch_qkv_grad_scales(ts->dq, ts->dk, ts->dv, R * C, ts->gsc, ts->qbits, ts->qs, s, true));
-            HIPCHK(e, launch_qkv_grad_pack(e->dt, ts->dq, ts->dk, ts->dv, e->rope_cos, e->rope_sin, N, H, T, ts->qs, ts->g16b, ts->g16w, s));
+            float* qs = ts->qs + 16 * i;
+            HIPCHK(e, launch_qkv_grad_scales(ts->dq, ts->dk, ts->dv, R * C, ts->gsc, qbits, qs, s, true));
+            if ((rc = site_free(e, ts, TrainState::DY_QKVW, s))) return rc;
+            HIPCHK(e, launch_qkv_grad_pack(e->dt, ts->dq, ts->dk, ts->dv, e->rope_cos, e->rope_sin, N, H, T, qs, ts->dy[TrainState::DY_QKVD], ts->dy[TrainState::DY_QKVW], s));
         }
         if (cap) { capture(e, "g.dq_" + std::to_string(i), ts->dq, R * C, false, s); capture(e, "g.dk_" + std::to_string(i), ts->dk, R * C, false, s);
-                   capture(e, "g.dv_" + std::to_string(i), ts->dv, R * C, false, s); capture(e, "g.dattn_" + std::to_string(i), ts->g16a, R * C, true, s); }
+                   capture(e, "g.dv_" + std::to_string(i), ts->dv, R * C, false, s); capture(e, "g.dattn_" + std::to_string(i), ts->dy[TrainState::DY_DATTN], R * C, true, s); }
         {   // fused q/k/v projection
             WgradOut o[3];
             int r = 0;
             for (const char* nm : {"q", "k", "v"}) {
-                o[r] = {G(ts, b + "attn.conv_" + nm + ".weight"), C, 0, C, r * C, C, G(ts, b + "attn.conv_" + nm + ".bias"), ts->qs + 2 + 2 * r};
+                o[r] = {G(ts, b + "attn.conv_" + nm + ".weight"), C, 0, C, r * C, C, G(ts, b + "attn.conv_" + nm + ".bias"), ts->qs + 16 * i + 2 + 2 * r};
                 ++r;
             }
-            if ((rc = wgrad(e, ts, A.h1, C, nullptr, 0, ts->g16w, 3 * C, 1, o, 3, s))) return rc;
-            ConvGemmArgs a = cargs(e, ts->qkvT[i], N, T, B); a.a0 = ts->g16b; a.c0 = 3 * C; a.out32 = ts->tmpC;
+            if ((rc = wgrad_side(e, ts, TrainState::DY_QKVW, A.h1, C, nullptr, 0, 3 * C, 1, o, 3, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->qkvT[i], N, T, B); a.a0 = ts->dy[TrainState::DY_QKVD]; a.c0 = 3 * C; a.out32 = ts->tmpC;
             HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
         }
-        HIPCHK(e, launch_ln_bwd(A.x1, ts->tmpC, ada_i, 6 * C, C, m, B, 0, T, N, ts->dX, ts->red, ts->qs, s));
-        { const int off[2] = {C, 0}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, dada_i, 6 * C, off, 0, ts->gsc, s)); }
+        HIPCHK(e, launch_ln_bwd(A.x1, ts->tmpC, ada_i, 6 * C, C, m, B, 0, T, N, ts->dX, site(3, 2, dada_i, 6 * C, C, 0), ts->qs + 16 * i, next_cells(ts), s));
         if (cap) capture(e, "g.x1_" + std::to_string(i), ts->dX, R * C, false, s);
-        if ((rc = recentre(e, ts, d, s))) return rc;
+        if ((rc = recentre(e, ts, d, true, s))) return rc;
         if (cap) capture(e, "g.scale_b" + std::to_string(i), ts->gsc, 2, false, s);      // ... and of what follows (g.xin_i)
         // ---- x1 = (gamma * xpre + beta) * mask
+        if (i >= L / 2 && (rc = site_free(e, ts, TrainState::DY_LSC, s))) return rc;
         HIPCHK(e, launch_film_bwd(e->dt, xpre_of(ts, i, L), ts->film + (size_t)i * N * 2 * C, 2 * C, N, m, B, T, N, ts->dX,
-                                  i >= L / 2 ? ts->g16b : nullptr, ts->red, s));
-        { const int off[2] = {0, C}; HIPCHK(e, launch_reduce_parts(ts->red, N, chunks, 2, ts->dfilm + (size_t)i * N * 2 * C, 2 * C, off, 0, ts->gsc, s)); }
+                                  i >= L / 2 ? ts->dy[TrainState::DY_LSC] : nullptr, site(4, 2, ts->dfilm + (size_t)i * N * 2 * C, 2 * C, 0, C), s));
+        HIPCHK(e, launch_reduce_sites(sites, N, chunks, s));
         if (i >= L / 2) {   // long-skip conv: xpre_i = W [x3_{i-1} ; skip] + b
             const int j = i - L / 2, src = L - 1 - i;
             const std::string n = "lsc_layers." + std::to_string(j);
             const void* skip16 = src == 0 ? ts->h0_16 : ts->L[src - 1].x3_16;
             WgradOut o = {G(ts, n + ".weight"), 2 * C, 0, 2 * C, 0, C, G(ts, n + ".bias")};
-            if ((rc = wgrad(e, ts, ts->L[i - 1].x3_16, C, skip16, C, ts->g16b, C, K, &o, 1, s))) return rc;
-            ConvGemmArgs a = cargs(e, ts->lscTb[j], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->dskip[src];
-            HIPCHK(e, launch_copy_scalars(ts->skip_sc + 2 * src, ts->gsc, 2, s));
+            if ((rc = wgrad_side(e, ts, TrainState::DY_LSC, ts->L[i - 1].x3_16, C, skip16, C, C, K, &o, 1, s))) return rc;
+            ConvGemmArgs a = cargs(e, ts->lscTb[j], N, T, B); a.a0 = ts->dy[TrainState::DY_LSC]; a.c0 = C; a.out32 = ts->dskip[src];
+            ts->skip_gsc[src] = ts->gsc;      // the slot this long-skip gradient is written under (slots are never rewritten within a backward)
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
-            a = cargs(e, ts->lscTa[j], N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->dX;
+            a = cargs(e, ts->lscTa[j], N, T, B); a.a0 = ts->dy[TrainState::DY_LSC]; a.c0 = C; a.out32 = ts->dX;
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
         }
         // x3_{i-1} (or the in_proj output) is also a long-skip source of a later block: add that gradient
-        if (i < L / 2) HIPCHK(e, launch_add_rescaled(ts->dX, ts->dskip[i], R * C, ts->gsc, ts->skip_sc + 2 * i, s));
+        if (i < L / 2) HIPCHK(e, launch_add_rescaled(ts->dX, ts->dskip[i], R * C, ts->gsc, ts->skip_gsc[i], i > 0 ? next_cells(ts) : nullptr, s));
         if (cap) capture(e, "g.xin_" + std::to_string(i), ts->dX, R * C, false, s);
     }
-    {   // this block's per-item linears: adaLN modulation (-> d c), FiLM (-> d tau); its d ada / d film rows are complete now
+    {   // this block's per-item linears: adaLN modulation (-> d c), FiLM (-> d tau); its d ada / d film rows are complete now.
+        // Every weight / bias gradient here has ONE producer (written, not accumulated: no zero fills); d c and d tau add up over
+        // the blocks: the first block of a backward (L - 1) writes them, the others accumulate.
+        const int acc = i == L - 1 ? 0 : 1;
         const std::string pa = e->blk(i) + "adaLN_modulation.2.";
         float* gw = G(ts, pa + "weight"); float* gb = G(ts, pa + "bias");
-        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)6 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)6 * C * 4, s));
         const float* dout = ts->dada + (size_t)i * N * 6 * C;
         if (e->G == C) {
-            HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, s));
-            HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, 1, s));
+            HIPCHK(e, launch_linear_bwd_w(ts->cvec, dout, N, C, 6 * C, 1, gw, gb, 0, s));
+            HIPCHK(e, launch_linear_bwd_in(ts->cvec, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dcvec, acc, s));
         } else {        // through SiLU into adaLN_modulation.0, then into c
             const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
             const float* pre = ts->ada_pre + (size_t)i * N * C;
             float* g0w = G(ts, p0 + "weight"); float* g0b = G(ts, p0 + "bias");
-            HIPCHK(e, hipMemsetAsync(g0w, 0, (size_t)C * e->G * 4, s)); HIPCHK(e, hipMemsetAsync(g0b, 0, (size_t)C * 4, s));
-            HIPCHK(e, launch_linear_bwd_w(pre, dout, N, C, 6 * C, 1, gw, gb, s));
+            HIPCHK(e, launch_linear_bwd_w(pre, dout, N, C, 6 * C, 1, gw, gb, 0, s));
             HIPCHK(e, launch_linear_bwd_in(pre, dout, P(e, pa + "weight"), N, C, 6 * C, 1, ts->dada_pre, 0, s));
-            HIPCHK(e, launch_linear_bwd_w(ts->cvec, ts->dada_pre, N, e->G, C, 0, g0w, g0b, s));
-            HIPCHK(e, launch_linear_bwd_in(ts->cvec, ts->dada_pre, P(e, p0 + "weight"), N, e->G, C, 0, ts->dcvec, 1, s));
+            HIPCHK(e, launch_linear_bwd_w(ts->cvec, ts->dada_pre, N, e->G, C, 0, g0w, g0b, 0, s));
+            HIPCHK(e, launch_linear_bwd_in(ts->cvec, ts->dada_pre, P(e, p0 + "weight"), N, e->G, C, 0, ts->dcvec, acc, s));
         }
         const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
         gw = G(ts, pf + "weight"); gb = G(ts, pf + "bias");
-        HIPCHK(e, hipMemsetAsync(gw, 0, (size_t)2 * C * C * 4, s)); HIPCHK(e, hipMemsetAsync(gb, 0, (size_t)2 * C * 4, s));
         const float* dfo = ts->dfilm + (size_t)i * N * 2 * C;
-        HIPCHK(e, launch_linear_bwd_w(ts->tau, dfo, N, C, 2 * C, 0, gw, gb, s));
-        HIPCHK(e, launch_linear_bwd_in(ts->tau, dfo, P(e, pf + "weight"), N, C, 2 * C, 0, ts->dtau, 1, s));
+        HIPCHK(e, launch_linear_bwd_w(ts->tau, dfo, N, C, 2 * C, 0, gw, gb, 0, s));
+        HIPCHK(e, launch_linear_bwd_in(ts->tau, dfo, P(e, pf + "weight"), N, C, 2 * C, 0, ts->dtau, acc, s));
     }
     return ST_OK;
 }
@@ -730,46 +843,47 @@ int bwd_tail(st_engine* e, TrainState* ts, float* grad_x, float* grad_mu, float*
     const int64_t R = d.R;
     int rc;
     // ---- in_proj: h0 = Wx x + Wc cond + b
-    HIPCHK(e, launch_cast16(e->dt, ts->dX, nullptr, 1, T, C, R, nullptr, ts->g16b, s));
+    void* const t0 = ts->dy[TrainState::DY_T0]; void* const t1 = ts->dy[TrainState::DY_T1]; void* const t2 = ts->dy[TrainState::DY_T2]; void* const t3 = ts->dy[TrainState::DY_T3];
+    HIPCHK(e, launch_cast16(e->dt, ts->dX, nullptr, 1, T, C, R, nullptr, t0, s));
     {
         WgradOut ox = {G(ts, "in_proj.weight"), C + M, 0, M, 0, C, G(ts, "in_proj.bias")};
-        if ((rc = wgrad(e, ts, ts->x16, Mp, nullptr, 0, ts->g16b, C, 1, &ox, 1, s))) return rc;
+        if ((rc = wgrad_side(e, ts, TrainState::DY_T0, ts->x16, Mp, nullptr, 0, C, 1, &ox, 1, s))) return rc;
         WgradOut oc = {G(ts, "in_proj.weight"), C + M, M, C, 0, C, nullptr};
-        if ((rc = wgrad(e, ts, ts->cond16, C, nullptr, 0, ts->g16b, C, 1, &oc, 1, s))) return rc;
+        if ((rc = wgrad_side(e, ts, TrainState::DY_T0, ts->cond16, C, nullptr, 0, C, 1, &oc, 1, s))) return rc;
         if (grad_x) {
-            ConvGemmArgs a = cargs(e, ts->inxT, N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out32 = ts->gin;
+            ConvGemmArgs a = cargs(e, ts->inxT, N, T, B); a.a0 = t0; a.c0 = C; a.out32 = ts->gin;
             HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
             HIPCHK(e, launch_unscale_inplace(ts->gin, R * Mp, ts->gsc, s));
             HIPCHK(e, launch_from_time_major(ts->gin, B, M, T, Mp, grad_x, s));
         }
-        ConvGemmArgs a = cargs(e, ts->incT, N, T, B); a.a0 = ts->g16b; a.c0 = C; a.out16 = ts->g16a;     // d cond (16 bit)
+        ConvGemmArgs a = cargs(e, ts->incT, N, T, B); a.a0 = t0; a.c0 = C; a.out16 = t1;     // d cond (16 bit)
         HIPCHK(e, gemm(e, 1, EPI_F32, a, s));
     }
     {   // cond prenet
         const DropCfg nodrop = make_drop(0.f, 0, 0);
         WgradOut o2 = {G(ts, "cond_proj.4.weight"), F, 0, F, 0, C, G(ts, "cond_proj.4.bias")};
-        if ((rc = wgrad(e, ts, ts->p2, F, nullptr, 0, ts->g16a, C, K, &o2, 1, s))) return rc;
-        ConvGemmArgs a = cargs(e, ts->preT[2], N, T, B); a.a0 = ts->g16a; a.c0 = C; a.out32 = ts->tmpF;
+        if ((rc = wgrad_side(e, ts, TrainState::DY_T1, ts->p2, F, nullptr, 0, C, K, &o2, 1, s))) return rc;
+        ConvGemmArgs a = cargs(e, ts->preT[2], N, T, B); a.a0 = t1; a.c0 = C; a.out32 = ts->tmpF;
         HIPCHK(e, gemm(e, K, EPI_F32, a, s));
-        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a2, nullptr, 1, T, F, R, nodrop, ts->g16a, s));
+        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a2, nullptr, 1, T, F, R, nodrop, t2, s));
         WgradOut o1 = {G(ts, "cond_proj.2.weight"), F, 0, F, 0, F, G(ts, "cond_proj.2.bias")};
-        if ((rc = wgrad(e, ts, ts->p1, F, nullptr, 0, ts->g16a, F, K, &o1, 1, s))) return rc;
-        a = cargs(e, ts->preT[1], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->tmpF;
+        if ((rc = wgrad_side(e, ts, TrainState::DY_T2, ts->p1, F, nullptr, 0, F, K, &o1, 1, s))) return rc;
+        a = cargs(e, ts->preT[1], N, T, B); a.a0 = t2; a.c0 = F; a.out32 = ts->tmpF;
         HIPCHK(e, gemm(e, K, EPI_F32, a, s));
-        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a1, nullptr, 1, T, F, R, nodrop, ts->g16a, s));
+        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a1, nullptr, 1, T, F, R, nodrop, t3, s));
         WgradOut o0 = {G(ts, "cond_proj.0.weight"), M, 0, M, 0, F, G(ts, "cond_proj.0.bias")};
-        if ((rc = wgrad(e, ts, ts->mu16, Mp, nullptr, 0, ts->g16a, F, K, &o0, 1, s))) return rc;
+        if ((rc = wgrad_side(e, ts, TrainState::DY_T3, ts->mu16, Mp, nullptr, 0, F, K, &o0, 1, s))) return rc;
         if (grad_mu) {
-            a = cargs(e, ts->preT[0], N, T, B); a.a0 = ts->g16a; a.c0 = F; a.out32 = ts->gin;
+            a = cargs(e, ts->preT[0], N, T, B); a.a0 = t3; a.c0 = F; a.out32 = ts->gin;
             HIPCHK(e, gemm(e, K, EPI_F32, a, s));
             HIPCHK(e, launch_unscale_inplace(ts->gin, R * Mp, ts->gsc, s));
             HIPCHK(e, launch_from_time_major(ts->gin, B, M, T, Mp, grad_mu, s));
         }
     }
     // ---- per-item vectors: adaLN (-> d c), FiLM (-> d tau), time MLP
-    HIPCHK(e, launch_linear_bwd_w(ts->th_pre, ts->dtau, N, F, C, 1, G(ts, "time_mlp.layer.2.weight"), G(ts, "time_mlp.layer.2.bias"), s));
+    HIPCHK(e, launch_linear_bwd_w(ts->th_pre, ts->dtau, N, F, C, 1, G(ts, "time_mlp.layer.2.weight"), G(ts, "time_mlp.layer.2.bias"), 0, s));
     HIPCHK(e, launch_linear_bwd_in(ts->th_pre, ts->dtau, P(e, "time_mlp.layer.2.weight"), N, F, C, 1, ts->dth, 0, s));
-    HIPCHK(e, launch_linear_bwd_w(ts->emb, ts->dth, N, C, F, 0, G(ts, "time_mlp.layer.0.weight"), G(ts, "time_mlp.layer.0.bias"), s));
+    HIPCHK(e, launch_linear_bwd_w(ts->emb, ts->dth, N, C, F, 0, G(ts, "time_mlp.layer.0.weight"), G(ts, "time_mlp.layer.0.bias"), 0, s));
     if (grad_c) HIPCHK(e, hipMemcpyAsync(grad_c, ts->dcvec, (size_t)N * e->G * 4, hipMemcpyDeviceToDevice, s));
     return ST_OK;
 }
@@ -796,7 +910,7 @@ int bwd_part(st_engine* e, TrainState* ts, int part, const float* grad_out, floa
     } else {
         if ((rc = bwd_tail(e, ts, grad_x, grad_mu, grad_c, s))) return rc;
     }
-    return ST_OK;
+    return side_join(e, ts, s);
 }
 
 }  // namespace

@@ -4,6 +4,7 @@
 // fp32 linears.  All fp32 arithmetic; 16-bit tensors are MFMA operands only.
 #include "common.h"
 #include "train_launch.h"
+#include <cstring>
 
 namespace st {
 
@@ -24,6 +25,21 @@ __global__ __launch_bounds__(256) void drop_tables_kernel(unsigned long long see
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rows) rowh[i] = drop_rowh(seed, (unsigned)i);
     if (i < n_colpairs) colh[i] = drop_colh(seed, (unsigned)i);
+}
+// ... for every attention site of one forward in ONE launch (grid.y = site); the backward re-reads the tables
+__global__ __launch_bounds__(256) void drop_tables_multi_kernel(DropSeeds sd, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh,
+                                                                size_t row_stride, size_t col_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long seed = sd.seed[blockIdx.y];
+    if (i < n_rows) rowh[blockIdx.y * row_stride + i] = drop_rowh(seed, (unsigned)i);
+    if (i < n_colpairs) colh[blockIdx.y * col_stride + i] = drop_colh(seed, (unsigned)i);
+}
+hipError_t launch_drop_tables_multi(const DropSeeds& sd, int n_sites, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh,
+                                    size_t row_stride, size_t col_stride, hipStream_t s) {
+    if (n_sites < 1 || n_sites > 16) return hipErrorInvalidValue;
+    const int n = n_rows > n_colpairs ? n_rows : n_colpairs;
+    hipLaunchKernelGGL(drop_tables_multi_kernel, dim3((n + 255) / 256, n_sites), dim3(256), 0, s, sd, n_rows, n_colpairs, rowh, colh, row_stride, col_stride);
+    return hipGetLastError();
 }
 hipError_t launch_drop_tables(const DropCfg& d, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh, hipStream_t s) {
     const int n = n_rows > n_colpairs ? n_rows : n_colpairs;
@@ -179,6 +195,43 @@ __device__ __forceinline__ void store_parts(float4 (&acc)[K], float* part, int n
     }
 }
 
+// max |value| a block saw -> ONE atomic into a group of kMaxCells cells 64 bytes apart (blocks are dealt over the cells: a few
+// thousand same-address atomics serialise in the L2 and would set the kernel's time; the consumer takes the maximum of the group).
+// Non-negative floats order like their bit patterns; NaN / inf do not set a scale (as absmax_kernel).
+__device__ __forceinline__ float absmax_take(float m, float v) { v = fabsf(v); return (v == v && v < 3.0e38f) ? fmaxf(m, v) : m; }
+__device__ __forceinline__ void publish_block_max(float m, unsigned* cells) {
+    __shared__ float wm_[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wm_[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float b = fmaxf(fmaxf(wm_[0], wm_[1]), fmaxf(wm_[2], wm_[3]));
+        if (b > 0.f) atomicMax(cells + (((blockIdx.x + blockIdx.y * 7u) % kMaxCells) << 4), __float_as_uint(b));
+    }
+}
+
+// Every per-(item, channel) sum of one backward block in ONE launch: site q = {partials of a row kernel, its K sums, where they go,
+// the un-scaling pair that was current when the row kernel ran}; block (j, n) reduces flat sum j of item n over the chunks in order.
+__global__ __launch_bounds__(256) void reduce_sites_kernel(RedSites S, int chunks) {
+    int j = blockIdx.x, q = 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) if (t < S.n - 1 && q == t && j >= S.s[t].K) { j -= S.s[t].K; q = t + 1; }
+    const RedSite st = S.s[q];
+    const int n = blockIdx.y, ch = threadIdx.x;
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += st.part[(((size_t)n * chunks + c) * st.K + j) * 256 + ch];
+    if (st.unscale) v *= st.unscale[1];
+    st.out[(size_t)n * st.out_stride + st.off[j] + ch] = v;
+}
+hipError_t launch_reduce_sites(const RedSites& S, int n_items, int chunks, hipStream_t s) {
+    if (S.n < 1 || S.n > 6) return hipErrorInvalidValue;
+    int total = 0;
+    for (int q = 0; q < S.n; ++q) { if (S.s[q].K < 1 || S.s[q].K > 2) return hipErrorInvalidValue; total += S.s[q].K; }
+    hipLaunchKernelGGL(reduce_sites_kernel, dim3(total, n_items), dim3(256), 0, s, S, chunks);
+    return hipGetLastError();
+}
+
 struct RedOff { int off[4]; };
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int chunks, int K, float* out, int out_stride,
                                                             RedOff off, int accumulate, const float* unscale) {
@@ -232,10 +285,11 @@ hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, cons
 // h = (LN(x) * (1 + sc) + sh) [* mask]
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float* dH, const float* ada, int ada_stride,
                                                      int scale_off, const float* mask, int mask_mod, int mask_out, int T,
-                                                     float* dX, float* part, const float* dh_scale) {
+                                                     float* dX, float* part, const float* dh_scale, unsigned* amax) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x, n = blockIdx.y, chunks = gridDim.x;
     const float dhs = dh_scale ? dh_scale[1] : 1.0f;
+    float mx = 0.f;
     const float4 sc = *(const float4*)(ada + (size_t)n * ada_stride + scale_off + lane * 4);
     float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     for (int t = chunk * kRedRows + wave; t < T && t < (chunk + 1) * kRedRows; t += 4) {
@@ -258,15 +312,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float
         d.x += rstd * (e0 - m1 - n0 * m2); d.y += rstd * (e1 - m1 - n1 * m2);
         d.z += rstd * (e2 - m1 - n2 * m2); d.w += rstd * (e3 - m1 - n3 * m2);
         *(float4*)(dX + o) = d;
+        mx = absmax_take(absmax_take(absmax_take(absmax_take(mx, d.x), d.y), d.z), d.w);
     }
     store_parts<2>(acc, part, n, chunk, chunks);
+    if (amax) publish_block_max(mx, amax);      // the re-centring point that follows needs max |dX|: no separate 65-MB pass
 }
 
 hipError_t launch_ln_bwd(const float* x, const float* dH, const float* ada, int ada_stride, int scale_off,
                          const float* mask, int mask_mod, int mask_out, int T, int n_items, float* dX, float* part,
-                         const float* dh_scale, hipStream_t s) {
+                         const float* dh_scale, unsigned* amax, hipStream_t s) {
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(red_chunks(T), n_items), dim3(256), 0, s, x, dH, ada, ada_stride, scale_off,
-                       mask, mask_mod, mask_out, T, dX, part, dh_scale);
+                       mask, mask_mod, mask_out, T, dX, part, dh_scale, amax);
     return hipGetLastError();
 }
 
@@ -421,6 +477,55 @@ hipError_t launch_grad_rescale(const float* g, int64_t n, unsigned* bits, float*
     hipLaunchKernelGGL(grad_rescale_kernel, dim3(1), dim3(1), 0, s, bits, sc);
     return hipGetLastError();
 }
+// max |x| into a cell GROUP (publish_block_max): the fall-back of a re-centring point whose producer is a GEMM epilogue
+__global__ __launch_bounds__(256) void absmax_cells_kernel(const float* x, int64_t n, unsigned* cells) {
+    float m = 0.f;
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(x + 4 * (i + u * stride));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = absmax_take(absmax_take(absmax_take(absmax_take(m, v[u].x), v[u].y), v[u].z), v[u].w);
+    }
+    for (; i < n4; i += stride) { const float4 v = *(const float4*)(x + 4 * i); m = absmax_take(absmax_take(absmax_take(absmax_take(m, v.x), v.y), v.z), v.w); }
+    publish_block_max(m, cells);
+}
+// One launch per re-centring point: f from the published maximum and the CURRENT pair (both read-only here), the tensor multiplied
+// by f (nothing to do when f == 1: the usual case), the NEXT pair {s f, 1 / (s f), f} written to its own slot by one thread --
+// later kernels are handed the new slot, so nothing races with the blocks still reading the old one.
+__global__ __launch_bounds__(256) void rescale_apply_kernel(float* a, int64_t n4, const unsigned* cells, const float* sc, float* sc_next) {
+    unsigned mb = 0u;
+#pragma unroll
+    for (int c = 0; c < kMaxCells; ++c) { const unsigned v = cells[c << 4]; mb = v > mb ? v : mb; }
+    const float m = __uint_as_float(mb), s0 = sc[0];
+    float f = 1.0f;
+    if (m > 0.f && (m < 2.0f || m >= 512.0f)) {
+        int ex = 5 - (int)floorf(log2f(m));
+        const int cur = (int)floorf(log2f(s0));
+        if (cur + ex > 100) ex = 100 - cur;              // keep the total scale a finite fp32 power of two
+        if (cur + ex < -100) ex = -100 - cur;
+        f = exp2f((float)ex);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc_next[0] = s0 * f; sc_next[1] = 1.0f / (s0 * f); sc_next[2] = f; }
+    if (f == 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = *(float4*)(a + 4 * i);
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        *(float4*)(a + 4 * i) = v;
+    }
+}
+hipError_t launch_recentre(float* a, int64_t n, unsigned* cells, bool have_max, const float* sc, float* sc_next, hipStream_t s) {
+    if (n & 3) return hipErrorInvalidValue;
+    if (!have_max) {
+        int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(absmax_cells_kernel, dim3(grid), dim3(256), 0, s, a, n, cells);
+    }
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(rescale_apply_kernel, dim3(grid), dim3(256), 0, s, a, n / 4, cells, sc, sc_next);
+    return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void scale_by_kernel(float* a, int64_t n4, const float* sc) {
     const float f = sc[2];
     if (f == 1.0f) return;
@@ -453,17 +558,22 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* a, const float*
     x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
     *(float4*)(a + i) = x;
 }
-__global__ __launch_bounds__(256) void add_rescaled_kernel(float* a, const float* b, int64_t n, const float* sc, const float* sc_b) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    const float f = sc[0] / sc_b[0];
-    float4 x = *(float4*)(a + i);
-    const float4 y = *(const float4*)(b + i);
-    x.x += y.x * f; x.y += y.y * f; x.z += y.z * f; x.w += y.w * f;
-    *(float4*)(a + i) = x;
+__global__ __launch_bounds__(256) void add_rescaled_kernel(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, unsigned* amax) {
+    float mx = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const float f = sc[0] / sc_b[0];
+        float4 x = *(float4*)(a + i);
+        const float4 y = *(const float4*)(b + i);
+        x.x += y.x * f; x.y += y.y * f; x.z += y.z * f; x.w += y.w * f;
+        *(float4*)(a + i) = x;
+        mx = absmax_take(absmax_take(absmax_take(absmax_take(mx, x.x), x.y), x.z), x.w);
+    }
+    if (amax) publish_block_max(mx, amax);      // (every thread of the block reaches this: the loop has no early return)
 }
-hipError_t launch_add_rescaled(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, hipStream_t s) {
-    hipLaunchKernelGGL(add_rescaled_kernel, dim3((int)((n / 4 + 255) / 256)), dim3(256), 0, s, a, b, n, sc, sc_b);
+hipError_t launch_add_rescaled(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, unsigned* amax, hipStream_t s) {
+    if (n & 3) return hipErrorInvalidValue;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(add_rescaled_kernel, dim3(grid), dim3(256), 0, s, a, b, n, sc, sc_b, amax);
     return hipGetLastError();
 }
 __global__ void copy_scalars_kernel(float* dst, const float* src, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
@@ -585,6 +695,55 @@ hipError_t launch_wgrad_reduce(const float* partial, int S, int cin, int cout, i
     return hipGetLastError();
 }
 
+// The same reduction for EVERY output of one weight-gradient GEMM in one launch (the fused q/k/v projection has three row blocks with
+// their own un-scaling pairs), plus the bias gradients from the [S][cout] column-sum planes wgrad_tn_kernel writes beside its tiles:
+// blocks [0, nb_w) reduce dW elements (co fastest), the last ceil(cout / 256) blocks one bias channel per thread.  Plane order fixed.
+struct WgradRed3 { WgradRed o[3]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const float* partial, const float* part_b, int S, int cin, int cout, int taps,
+                                                                 WgradRed3 R, unsigned nb_w) {
+    const int64_t total = (int64_t)taps * cin * cout;
+    if (blockIdx.x >= nb_w) {
+        const int co = (int)(blockIdx.x - nb_w) * 256 + threadIdx.x;
+        if (co >= cout || !part_b) return;
+        int k = -1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (q < R.n && R.o[q].db && co >= R.o[q].co_start && co < R.o[q].co_start + R.o[q].co_cnt) k = q;
+        if (k < 0) return;
+        float v = 0.f;
+        for (int sI = 0; sI < S; ++sI) v += part_b[(size_t)sI * cout + co];
+        if (R.o[k].unscale) v *= R.o[k].unscale[1];
+        R.o[k].db[co - R.o[k].co_start] = v;
+        return;
+    }
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (j*cin + ci) x co, co fastest
+    if (idx >= total) return;
+    const int co = (int)(idx % cout);
+    const int jc = (int)(idx / cout);
+    const int j = jc / cin, ci = jc % cin;
+    int k = -1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (q < R.n && R.o[q].dW && co >= R.o[q].co_start && co < R.o[q].co_start + R.o[q].co_cnt && ci < R.o[q].ci_cnt) k = q;
+    if (k < 0) return;
+    float v = 0.f;
+    for (int sI = 0; sI < S; ++sI) v += partial[(size_t)sI * total + idx];
+    if (R.o[k].unscale) v *= R.o[k].unscale[1];
+    R.o[k].dW[((size_t)(co - R.o[k].co_start) * R.o[k].cin_total + R.o[k].ci_off + ci) * taps + j] = v;
+}
+
+hipError_t launch_wgrad_reduce_multi(const float* partial, const float* part_b, int S, int cin, int cout, int taps, const WgradRed* outs,
+                                     int n_outs, hipStream_t s) {
+    if (n_outs < 1 || n_outs > 3) return hipErrorInvalidValue;
+    WgradRed3 R; memset(&R, 0, sizeof(R));
+    R.n = n_outs;
+    bool need_b = false;
+    for (int k = 0; k < n_outs; ++k) { R.o[k] = outs[k]; need_b = need_b || outs[k].db; }
+    if (need_b && !part_b) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)taps * cin * cout;
+    const unsigned nb_w = (unsigned)((total + 255) / 256), nb_b = need_b ? (unsigned)((cout + 255) / 256) : 0u;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nb_w + nb_b), dim3(256), 0, s, partial, part_b, S, cin, cout, taps, R, nb_w);
+    return hipGetLastError();
+}
+
 // block = 16 channels x 64 row-block groups (cout / 16 blocks: the earlier 64 x 16 shape ran a 256-channel bias on 4 blocks);
 // fixed summation order (group partials combined 0..63): deterministic
 __global__ __launch_bounds__(1024) void bias_reduce_kernel(const float* part_b, int rowblocks, int cout, float* db, int co_start,
@@ -696,7 +855,7 @@ hipError_t launch_pack_jobs(int dtype, const PackJob* jobs_dev, int njobs, unsig
 // dW[o][k] += sum_n dout[n][o] * act(in[n][k]) ; db[o] += sum_n dout[n][o].  block = 64 inputs x 8 consecutive outputs, its 4
 // waves take every fourth item (the loop is a chain of L2-latency loads: four short chains + a fixed-order LDS combine)
 __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* in, const float* dout, int n, int k, int o, int silu_in,
-                                                           float* dW, float* db) {
+                                                           float* dW, float* db, int accumulate) {
     __shared__ float red[4][16][64];
     const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int ki = blockIdx.x * 64 + tx, o0 = blockIdx.y * 8;
@@ -728,14 +887,18 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* in, cons
     for (int j = g; j < 8; j += 4) {          // wave g finishes outputs o0 + g, o0 + g + 4
         if (o0 + j >= o) continue;
         const float t = ((red[0][j][tx] + red[1][j][tx]) + red[2][j][tx]) + red[3][j][tx];
-        dW[(size_t)(o0 + j) * k + ki] += t;
-        if (ki == 0 && db) db[o0 + j] += ((red[0][8 + j][0] + red[1][8 + j][0]) + red[2][8 + j][0]) + red[3][8 + j][0];
+        float* w = dW + (size_t)(o0 + j) * k + ki;
+        *w = accumulate ? *w + t : t;
+        if (ki == 0 && db) {
+            const float tb = ((red[0][8 + j][0] + red[1][8 + j][0]) + red[2][8 + j][0]) + red[3][8 + j][0];
+            db[o0 + j] = accumulate ? db[o0 + j] + tb : tb;
+        }
     }
 }
 
 hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k, int o, int silu_in, float* dW, float* db,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((o + 7) / 8)), dim3(256), 0, s, in, dout, n, k, o, silu_in, dW, db);
+                               int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((o + 7) / 8)), dim3(256), 0, s, in, dout, n, k, o, silu_in, dW, db, accumulate);
     return hipGetLastError();
 }
 

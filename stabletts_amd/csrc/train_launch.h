@@ -50,6 +50,20 @@ hipError_t launch_unscale_inplace(float* a, int64_t n, const float* sc, hipStrea
 // launch_scale_by then multiplies a tensor that lives in scaled units by sc[2] (returns at once when it is 1).
 hipError_t launch_grad_rescale(const float* g, int64_t n, unsigned* bits, float* sc, hipStream_t s);
 hipError_t launch_scale_by(float* a, int64_t n, const float* sc, hipStream_t s);
+// The same re-centring as ONE launch (+ one when no producer published the maximum): `cells` is a group of kMaxCells maxima 64
+// bytes apart (zeroed by the caller; producers: ln_bwd / add_rescaled `amax`, or the absmax pass run here when !have_max);
+// a *= f and sc_next = {sc[0] f, 1 / (sc[0] f), f}.  sc is only read: kernels enqueued later are handed sc_next.
+constexpr int kMaxCells = 16;
+constexpr int kMaxCellWords = kMaxCells * 16;
+hipError_t launch_recentre(float* a, int64_t n, unsigned* cells, bool have_max, const float* sc, float* sc_next, hipStream_t s);
+// every per-(item, channel) sum of one backward block in one launch (replaces one launch_reduce_parts per row kernel)
+struct RedSite { const float* part; int K; float* out; int out_stride; int off[2]; const float* unscale; };
+struct RedSites { RedSite s[6]; int n; };
+hipError_t launch_reduce_sites(const RedSites& S, int n_items, int chunks, hipStream_t s);
+// dropout hash tables of every attention site of a forward in one launch
+struct DropSeeds { unsigned long long seed[16]; };
+hipError_t launch_drop_tables_multi(const DropSeeds& sd, int n_sites, int n_rows, int n_colpairs, unsigned* rowh, unsigned* colh,
+                                    size_t row_stride, size_t col_stride, hipStream_t s);
 
 // x_out = x_in + gate * branch:   d branch16 = dX * gate * mask ; part[.][0] = sum_t dX * branch
 hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, const float* gate, int gate_stride,
@@ -58,7 +72,7 @@ hipError_t launch_gate_bwd(int dtype, const float* dX, const float* branch, cons
 // dh_scale (optional): dH is multiplied by dh_scale[1] on load (a GEMM result computed from locally re-scaled operands)
 hipError_t launch_ln_bwd(const float* x, const float* dH, const float* ada, int ada_stride, int scale_off,
                          const float* mask, int mask_mod, int mask_out, int T, int n_items, float* dX, float* part,
-                         const float* dh_scale, hipStream_t s);
+                         const float* dh_scale, unsigned* amax, hipStream_t s);
 // x = (gamma * xpre + beta) * mask:  part[.][0] = d gamma, part[.][1] = d beta ; dX = dX * mask * gamma (in place) (+ 16-bit copy)
 hipError_t launch_film_bwd(int dtype, const float* xpre, const float* film, int film_stride, int film_mod,
                            const float* mask, int mask_mod, int T, int n_items, float* dX, void* dX16, float* part,
@@ -71,7 +85,8 @@ hipError_t launch_cast16(int dtype, const float* x, const float* mask, int mask_
                          const float* scale, void* y16, hipStream_t s);
 hipError_t launch_add_inplace(float* a, const float* b, int64_t n, hipStream_t s);
 // a += b * sc[0] / sc_b[0]: b was written when the pass-wide scale was sc_b[0], a lives at the current scale sc[0] (both powers of two)
-hipError_t launch_add_rescaled(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, hipStream_t s);
+// amax != null: also publishes max |a| after the add into the cell group (launch_recentre's input)
+hipError_t launch_add_rescaled(float* a, const float* b, int64_t n, const float* sc, const float* sc_b, unsigned* amax, hipStream_t s);
 hipError_t launch_copy_scalars(float* dst, const float* src, int n, hipStream_t s);
 
 // ---------------------------------------------------------------- weight gradient as a forward GEMM
@@ -88,8 +103,15 @@ hipError_t launch_wgrad_dyt(int dtype, const void* dy, int cout, int64_t R, int 
 // The same weight gradient WITHOUT the transposed copies (wgrad_tn.hip): a "TN" GEMM that stages dY and X in LDS as they lie
 // in memory ([frame][channel]) and reads the k-strided MFMA fragments with ds_read_b64_tr_b16.  Splits K over ranges of 32-frame chunks (cps chunks
 // per block; a chunk lies inside one item): partial[S = ceil(n_items * ceil(T / 32) / cps)][taps*Cin][cout].  Needs cout % 256 == 0, c0 % 64 == c1 % 64 == 0.
+// part_b != null: the blocks of the first N tile also write part_b[S][cout] = column sums of dY over their K range (bias-gradient
+// partials as a by-product of the A fragments they already hold; replaces the colsum_rows pass over dY).
 hipError_t launch_wgrad_tn(int dtype, const void* dy, int cout, const void* x0, int c0, const void* x1, int c1, int taps,
-                           int n_items, int T, int cps, const void* zeros, float* partial, hipStream_t s);
+                           int n_items, int T, int cps, const void* zeros, float* partial, float* part_b, hipStream_t s);
+// ONE launch for every output of a weight-gradient GEMM: up to three (co_start, co_cnt) row blocks of the fused q/k/v projection, each
+// with its own un-scaling pair; dW as launch_wgrad_reduce, db[co - co_start] = sum_s part_b[s][co] (part_b from launch_wgrad_tn).
+struct WgradRed { float* dW; float* db; const float* unscale; int cin_total, ci_off, ci_cnt, co_start, co_cnt; };
+hipError_t launch_wgrad_reduce_multi(const float* partial, const float* part_b, int S, int cin, int cout, int taps, const WgradRed* outs,
+                                     int n_outs, hipStream_t s);
 // part_b[rowblock][cout] = column sums of every 64-row block of dY [R][cout] (bias-gradient partials for launch_bias_reduce)
 hipError_t launch_colsum_rows(int dtype, const void* dy, int cout, int64_t R, float* part_b, hipStream_t s);
 // dW (reference layout (co_cnt, Cin_total, taps), fp32) [co - co_start][ci_off + ci][j] = sum_s partial[s][j*Cin + ci][co]
@@ -107,7 +129,7 @@ hipError_t launch_pack_weight_t(int dtype, const float* src, int cout, int cin_t
 // ---------------------------------------------------------------- small fp32 linears (adaLN, FiLM, time MLP): backward
 // out = W act(in) + b:  dW[o][k] (+)= sum_n dout[n][o] act(in[n][k]);  db[o] (+)= sum_n dout[n][o]
 hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k, int o, int silu_in, float* dW, float* db,
-                               hipStream_t s);
+                               int accumulate, hipStream_t s);
 // din[n][k] (+)= (sum_o dout[n][o] W[o][k]) * act'(in[n][k])
 hipError_t launch_linear_bwd_in(const float* in, const float* dout, const float* W, int n, int k, int o, int silu_in,
                                 float* din, int accumulate, hipStream_t s);

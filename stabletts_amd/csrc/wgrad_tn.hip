@@ -30,6 +30,7 @@ struct WgradTnArgs {
     const void* x0; int c0; const void* x1; int c1;   // [items * T][c0], [items * T][c1] (channel concat; c1 may be 0)
     int taps, n_items, T, cps;                   // cps: 32-frame chunks per split (K range of a block; chunks never straddle items)
     const void* zeros;
+    float* part_b;                               // [S][cout] column sums of the block's dY rows (bias-gradient partials), or null
 };
 
 namespace {
@@ -44,6 +45,26 @@ __device__ __forceinline__ uint2 tr_read(unsigned addr) {
 template <class P>
 __device__ __forceinline__ typename P::vec8 join8(uint2 lo, uint2 hi) {
     return as_vec8<P>(make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+// acc + the sum of a fragment's 8 values (fp32 accumulation, products with 1 are exact): 4 dot instructions beside the MFMAs
+template <class P>
+__device__ __forceinline__ float sum8(uint2 lo, uint2 hi, float acc);
+template <>
+__device__ __forceinline__ float sum8<OpF16>(uint2 lo, uint2 hi, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, lo.x), one, acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, lo.y), one, acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, hi.x), one, acc, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, hi.y), one, acc, false);
+}
+template <>
+__device__ __forceinline__ float sum8<OpBF16>(uint2 lo, uint2 hi, float acc) {      // bf16 -> fp32 is a 16-bit shift
+    const unsigned w[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc += __uint_as_float(w[i] << 16) + __uint_as_float(w[i] & 0xffff0000u);
+    return acc;
 }
 
 }  // namespace
@@ -129,6 +150,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // bias-gradient partials as a by-product: the blocks of the first N tile (tap 0, first cin slice) see every dY row of their K
+    // range exactly once; their two wf == 0 waves (one per 128-channel half) add up the A fragments they feed to the MFMAs.
+    // Lane l of fragment a holds 8 frames of channel (l & 31); lanes l and l ^ 32 hold the two frame halves of a k-step.
+    const bool do_bias = w.part_b != nullptr && tn == 0 && wf == 0;       // wave-uniform
+    float csum[FC] = {0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
         const unsigned bo = (unsigned)buf * BUF;
 #define ST_TN_KSTEP(KS)                                                                                             \
@@ -144,6 +170,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
                          : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]), \
                            "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]) :: "memory");                          \
             vec8 bf0 = join8<P>(bl[0], bh[0]), bf1 = join8<P>(bl[1], bh[1]);                                        \
+            if (do_bias) { _Pragma("unroll") for (int a = 0; a < FC; ++a) csum[a] = sum8<P>(al[a], ah[a], csum[a]); }   \
             _Pragma("unroll") for (int a = 0; a < FC; ++a) {                                                        \
                 const vec8 af = join8<P>(al[a], ah[a]);                                                             \
                 acc[a][0] = P::mfma(af, bf0, acc[a][0]);                                                            \
@@ -177,6 +204,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_kernel(const WgradTnArgs w, c
 #endif
     }
     __syncthreads();
+    if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < FC; ++a) {
+            const float v = csum[a] + __shfl_xor(csum[a], 32);
+            if (lane < 32) w.part_b[(size_t)s * w.cout + mb + (wc * 2 + (a >> 1)) * 64 + (a & 1) * 32 + lane] = v;
+        }
+    }
 
     // partial tile -> plane s of partial[S][taps*cin][cout] (rows = this tap's input channels cb .. cb + 256 of cin)
     const int fvalid = min(BF, cin - cb);
@@ -208,8 +242,9 @@ static hipError_t launch_wgrad_tn_t(const WgradTnArgs& w, float* partial, int S,
 }
 
 hipError_t launch_wgrad_tn(int dtype, const void* dy, int cout, const void* x0, int c0, const void* x1, int c1, int taps,
-                           int n_items, int T, int cps, const void* zeros, float* partial, hipStream_t s) {
+                           int n_items, int T, int cps, const void* zeros, float* partial, float* part_b, hipStream_t s) {
     WgradTnArgs w;
+    w.part_b = part_b;
     w.dy = dy; w.cout = cout; w.x0 = x0; w.c0 = c0; w.x1 = x1; w.c1 = c1; w.taps = taps; w.n_items = n_items; w.T = T; w.cps = cps;
     w.zeros = zeros;
     const int kchunks = n_items * ((T + 31) / 32);

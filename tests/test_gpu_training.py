@@ -683,6 +683,44 @@ def test_dropout_forward_and_backward_match_oracle_with_same_masks(sd, monkeypat
     assert not bad, bad
 
 
+@pytest.mark.parametrize("B,T,lengths", [(3, 300, [300, 211, 64]), (8, 1000, None)])
+def test_side_streams_are_bitwise_neutral(sd, monkeypatch, B, T, lengths):
+    """Round 6: the backward's weight-gradient GEMMs (+ their reductions) run on a side stream and each block's gradient-independent
+    attention operand copies on a second one (csrc/engine_train.cpp: wgrad_side / attn_prep); every operand a weight gradient reads has
+    its own buffer and the parts join the streams before they return.  The SAME kernels run either way, so loss and every gradient must
+    be bit-identical to the single-stream order (ST_TRAIN_SIDE=0) -- a missed dependency would show up here as a difference.  Train
+    mode (dropout tables shared by forward and backward), two steps each so that buffers are re-used across backwards."""
+    inp = make_inputs(B, T, seed=71, lengths=lengths, ragged=lengths is None)
+    x1 = make_inputs(B, T, seed=72)["z"]
+    g0 = torch.Generator().manual_seed(11)
+    t_rand = torch.rand(B, 1, 1, generator=g0); z = torch.randn(B, 128, T, generator=g0)
+
+    def run(side):
+        if side:
+            monkeypatch.delenv("ST_TRAIN_SIDE", raising=False)
+        else:
+            monkeypatch.setenv("ST_TRAIN_SIDE", "0")
+        dec = _decoder(sd, "f16", train=True)
+        outs = []
+        for step in range(2):
+            torch.manual_seed(500 + step)
+            dec.zero_grad()
+            mu = inp["mu"].cuda().requires_grad_(True)
+            c = inp["c"].cuda().requires_grad_(True)
+            loss, _ = dec.compute_loss(x1.cuda(), inp["mask"].cuda(), mu, c, t_rand=t_rand.cuda(), z=z.cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((float(loss.detach()), mu.grad.cpu(), c.grad.cpu(), {n: q.grad.detach().cpu().clone() for n, q in dec.estimator.named_parameters()}))
+        return outs
+
+    a, b = run(True), run(False)
+    for (la, gma, gca, gpa), (lb, gmb, gcb, gpb) in zip(a, b):
+        assert la == lb and torch.equal(gma, gmb) and torch.equal(gca, gcb)
+        diff = [n for n in gpa if not torch.equal(gpa[n], gpb[n])]
+        assert not diff, diff
+        assert all(torch.isfinite(v).all() for v in gpa.values())
+
+
 def test_inference_mode_and_frozen_parameters_take_the_inference_path(sd):
     """No autograd graph when nothing requires grad; the training path when a leaf does (mu only, frozen decoder)."""
     dec = _decoder(sd, "f16")
