@@ -557,6 +557,16 @@ def main():
         extras["other_dtype"] = {"dtype": other, "workload": f"rank 0's first batch, {B_batch} x {T_batch}", "ms_per_step": sec * 1e3, "value": batches[0]["valid"] / sec,
                                  "unit": "mel-frames/sec"}
         del dec2
+        # (a2) the opt-in split-precision attention operands (attention_precision="split": q, k as hi + lo pairs, 3x the QK^T MFMAs) on the
+        #      same workload: what the mode costs -- it is for checkpoints in the arg-max regime, not the default
+        dec3 = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=args.dtype, attention_precision="split")
+        dec3.estimator.load_state_dict(sd)
+        dec3 = dec3.to(dev)
+        sec3 = time_variant(dec3, g, N_STEPS, kw, max(3, args.steps // 2))
+        extras["attention_precision_split"] = {"workload": f"rank 0's first batch, {B_batch} x {T_batch}", "ms_per_step": sec3 * 1e3,
+                                               "value": batches[0]["valid"] / sec3, "unit": "mel-frames/sec",
+                                               "max_attention_log_sum_exp": dec.estimator.engine().attention_stats(torch.cuda.current_stream(dev).cuda_stream)}
+        del dec3
         # (b) BASELINE config 1 shape on the GPU: one utterance, T=500, n=10 euler, CFG off (interactive latency)
         one = {k: v.to(dev) for k, v in make_inputs(1, 500, seed=0).items() if k != "lengths"}
         sec1 = time_variant(dec, one, 10, None, 10)

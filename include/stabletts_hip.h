@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ST_ABI_VERSION 3
+#define ST_ABI_VERSION 4
 
 enum {
     ST_OK = 0,
@@ -249,6 +249,24 @@ int st_output_status(st_engine* e, void* stream, int* nonfinite);
 
 /* Function evaluations, attempted steps and rejected steps of the last st_cfm_solve (adaptive solvers vary). */
 int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_t* rejects);
+
+/* Engine options by name (no reference analogue: models/diffusion_transformer.py:70-77 computes the attention in fp32).
+ *   "attention_precision"  0 (default): q, k, v enter the attention MFMAs as 16-bit operands.
+ *                          1: q and k as hi + lo PAIRS of 16-bit operands, scores = q_hi k_hi + q_lo k_hi + q_hi k_lo (3x the QK^T
+ *                             MFMAs) in st_estimator_forward / st_cfm_solve -- for checkpoints whose softmax has become an arg-max
+ *                             (score maxima of 80-200), where the 2^-11 rounding of q and k moves the winning probability and
+ *                             f16 operands miss the 1e-3 parity bar.  Takes effect at the next call.
+ *   "fused_ffn"            read-only: 0 two-kernel FFN, 1 fused direct kernel (default), 3 fused Winograd kernel (ST_FUSED_FFN=3).
+ * st_get_option returns ST_ERR_INVALID for an unknown name. */
+int st_set_option(st_engine* e, const char* name, int value);
+int st_get_option(const st_engine* e, const char* name, int* value);
+
+/* Largest log-sum-exp (natural-log units; of the scaled, masked scores of softmax(q k^T / sqrt(d) + mask), diffusion_transformer.py:77)
+ * over every valid attention row of the estimator evaluations completed on `stream` since the last query; -inf if there were none.  A
+ * row's score maximum lies within log(T) below it, so this is the run-time sign of the arg-max regime above: seeded / freshly
+ * initialised weights give ~10, values beyond ~50 mean "attention_precision" = 1 is needed for 1e-3 parity.  Synchronises `stream`,
+ * reads 16 words, resets the statistic.  Costs one atomic per attention block while running. */
+int st_attention_stats(st_engine* e, void* stream, float* max_lse);
 
 /* ---- measurement / test hooks (no reference analogue) ------------------------------------- */
 

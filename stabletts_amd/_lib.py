@@ -31,6 +31,7 @@ EXPORTS = [
     "st_train_grad_numel", "st_param_grad", "st_param_grads_flat",
     "st_durations", "st_generate_path", "st_align", "st_create_vocoder", "st_vocos_forward",
     "st_cfm_loss_prep", "st_cfm_loss", "st_cfm_loss_backward", "st_cfm_loss_scratch_floats",
+    "st_set_option", "st_get_option", "st_attention_stats",
 ]
 
 
@@ -160,7 +161,13 @@ def load():
     lib.st_create_vocoder.restype = c_int
     lib.st_vocos_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.st_vocos_forward.restype = c_int
-    if lib.st_abi_version() != 3:
+    lib.st_set_option.argtypes = [c_void_p, ctypes.c_char_p, c_int]
+    lib.st_set_option.restype = c_int
+    lib.st_get_option.argtypes = [c_void_p, ctypes.c_char_p, ctypes.POINTER(c_int)]
+    lib.st_get_option.restype = c_int
+    lib.st_attention_stats.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_float)]
+    lib.st_attention_stats.restype = c_int
+    if lib.st_abi_version() != 4:
         raise ImportError("libstabletts_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -381,3 +388,18 @@ class Engine:
 
     def device_bytes(self):
         return self.lib.st_device_bytes(self.handle)
+
+    def set_option(self, name, value):
+        """st_set_option: 'attention_precision' 0 (16-bit q / k operands) / 1 (split hi + lo operands)."""
+        self._check(self.lib.st_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int()
+        self._check(self.lib.st_get_option(self.handle, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def attention_stats(self, stream):
+        """Largest log-sum-exp (natural units) of any valid attention row since the last query (synchronises the stream; -inf: none)."""
+        v = ctypes.c_float()
+        self._check(self.lib.st_attention_stats(self.handle, ctypes.c_void_p(stream), ctypes.byref(v)))
+        return float(v.value)

@@ -52,16 +52,24 @@ namespace st {
 
 // TRAIN: also writes the log2-sum-exp of every query row (for the backward's recomputation of P) and applies
 // dropout to the probabilities that enter P.V (not to the normaliser), as SDPA's dropout_p does.
-template <class P, bool TRAIN>
-__global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) void attention_kernel(const AttnArgs a) {
+// SPLIT (inference, `attention_precision = split`): q and k arrive as hi + lo pairs of 16-bit operands and the scores are formed as
+// q_hi k_hi + q_lo k_hi + q_hi k_lo (fp32 accumulation; the lo x lo term is below fp32's own rounding of the sum): 3x the QK^T MFMAs,
+// one more K tile per stage in LDS, 16 more registers for the q_lo fragments -- for checkpoints whose softmax is an arg-max
+// (score maxima of 80-200), where the 2^-11 rounding of q and k moves the winning probability.
+template <class P, bool TRAIN, bool SPLIT = false>
+__global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 || SPLIT ? 2 : 4) void attention_kernel(const AttnArgs a) {
+    static_assert(!(TRAIN && SPLIT), "split-precision scores: inference kernel only");
     constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW, QTILE = QB;      // waves and queries per block
     using vec8 = typename P::vec8;
     constexpr int TILE_BYTES = 64 * 128;
     constexpr int NBUF = 3;                      // K / V^T tile ring: tile kt+2 is in flight while tile kt is computed
-    constexpr int SMEM = 2 * NBUF * TILE_BYTES > NW * 32 * 144 ? 2 * NBUF * TILE_BYTES : NW * 32 * 144;
+    constexpr int NT = SPLIT ? 3 : 2;           // tiles per stage: K, V^T (, K_lo)
+    constexpr int SMEM = NT * NBUF * TILE_BYTES > NW * 32 * 144 ? NT * NBUF * TILE_BYTES : NW * 32 * 144;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    __shared__ float wave_lse[NW];
     unsigned char* Ks = smem;                       // NBUF buffers
     unsigned char* Vs = smem + NBUF * TILE_BYTES;   // NBUF buffers
+    unsigned char* KLs = smem + 2 * NBUF * TILE_BYTES;   // NBUF buffers (SPLIT)
 
     const int T = a.T, Tp = a.Tp, H = a.H;
     const int qtiles = (T + QB - 1) / QB;
@@ -88,6 +96,8 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     const unsigned char* qbase = (const unsigned char*)a.q + ((size_t)nh * T) * 128;
     const unsigned char* kbase = (const unsigned char*)a.k + ((size_t)nh * T) * 128;
     const unsigned char* vbase = (const unsigned char*)a.vt + ((size_t)nh * 64) * Tp * 2;
+    const unsigned char* qlbase = SPLIT ? (const unsigned char*)a.q_lo + ((size_t)nh * T) * 128 : nullptr;
+    const unsigned char* klbase = SPLIT ? (const unsigned char*)a.k_lo + ((size_t)nh * T) * 128 : nullptr;
     if constexpr (TRAIN) {
         if (qt * QB >= kvend) {      // ragged batch: queries past the item's last valid frame -- their rows are multiplied by the
             if (query < T) {         // mask downstream (diffusion_transformer.py:111); the backward reads them: defined zeros
@@ -108,6 +118,15 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
         if (query < T) v = *(const uint4*)(qbase + (size_t)query * 128 + ks * 32 + hi * 16);
         qf[ks] = as_vec8<P>(v);
     }
+    vec8 qlf[SPLIT ? 4 : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (query < T) v = *(const uint4*)(qlbase + (size_t)query * 128 + ks * 32 + hi * 16);
+            qlf[ks] = as_vec8<P>(v);
+        }
+    }
 
     const int ntiles = (kvend + 63) >> 6;
     // LDS-DMA: the 8 + 8 pieces (8 rows x 128 B each) of the K tile and of the V^T tile are split over the waves
@@ -126,6 +145,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
             const int seg = (ln & 7) ^ ((row >> 1) & 7);
             const int key = min(kt * 64 + row, T - 1);
             glds16s(sgpr_ptr(kbase), (unsigned)(key * 128 + seg * 16), Ks + buf * TILE_BYTES + piece * 1024);
+            if constexpr (SPLIT) glds16s(sgpr_ptr(klbase), (unsigned)(key * 128 + seg * 16), KLs + buf * TILE_BYTES + piece * 1024);
         };
         auto v_piece = [&](int piece) {
             // V^T row = head dim `row`; 8 consecutive (permuted) keys kt*64 + seg*8 .. +8, always inside Tp
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
     // everything but the youngest tile.  (With two buffers and a full drain per tile the iteration time was the LDS-DMA
     // round trip, not the tile's MFMA + softmax work.)
     if (ntiles > 0) issueKV(0, 0);
-    if (ntiles > 1) { issueKV(1, 1); if constexpr (NW <= 8) { if constexpr (NW == 8) ST_DMA_WAIT(2); else ST_DMA_WAIT(4); } else ST_DMA_WAIT(1); }
+    if (ntiles > 1) { issueKV(1, 1); if constexpr (NW <= 8) { if constexpr (NW == 8) { if constexpr (SPLIT) ST_DMA_WAIT(3); else ST_DMA_WAIT(2); } else { if constexpr (SPLIT) ST_DMA_WAIT(6); else ST_DMA_WAIT(4); } } else ST_DMA_WAIT(1); }
     else ST_DMA_WAIT(0);
     __syncthreads();
 
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
         f32x16_t s[2];
         const bool partial = (kt + 1) * 64 > nfull;       // tiles inside the valid prefix have no masked key
         // ---- S'^T = [K | 1] . [Q | -m_ref]^T (+ key bias)  (log2 units)
-        auto scores = [&]() {
+        auto scores = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -201,8 +221,15 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
                 s[kb] = P::mfma(kaug, qaug, s[kb]);
                 const unsigned char* kp = Ks + buf * TILE_BYTES + row_off[kb];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(kp + (((ks * 2 + hi) ^ swz[kb]) << 4))), qf[ks], s[kb]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const vec8 kfrag = as_vec8<P>(*(const uint4*)(kp + (((ks * 2 + hi) ^ swz[kb]) << 4)));
+                    s[kb] = P::mfma(kfrag, qf[ks], s[kb]);
+                    if constexpr (SPLIT) {      // + q_lo k_hi + q_hi k_lo
+                        s[kb] = P::mfma(kfrag, qlf[ks], s[kb]);
+                        const unsigned char* klp = KLs + buf * TILE_BYTES + row_off[kb];
+                        s[kb] = P::mfma(as_vec8<P>(*(const uint4*)(klp + (((ks * 2 + hi) ^ swz[kb]) << 4))), qf[ks], s[kb]);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (partial) {        // key bias (-1e30 on masked / out-of-range keys): only tiles that reach past the valid prefix
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
             // computed, the references of the rows above theirs raised, and the tile redone.  (On a SIMD a VALU instruction is
             // issued instead of an MFMA; the 21 v_max3 / v_max per tile were 5 % of the kernel:
             // profiles/r03_attention_sq_counters_and_ablation.txt.)
-            auto raise = [&](bool first) {      // same step as in the training branch, for every row above its reference
+            auto raise = [&](bool first) __attribute__((always_inline)) {      // same step as in the training branch, for every row above its reference
                 float mx = s[0][0];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -295,7 +322,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
                 if (hi == 0) qaug[0] = to16<P>(-m_ref);
                 scores();
             };
-            auto numerators = [&]() {
+            auto numerators = [&]() __attribute__((always_inline)) {
                 psum[0] = 0.f; psum[1] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -333,16 +360,36 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 ? 2 : 4) vo
         }
         }
         // tile kt+1 (asm-issued LDS-DMA, flying under the MFMAs and exps of two tiles) has landed; tile kt+2 stays in flight
-        if (kt + 2 < ntiles_run) { if constexpr (NW <= 8) { if constexpr (NW == 8) ST_DMA_WAIT(2); else ST_DMA_WAIT(4); } else ST_DMA_WAIT(1); }
+        if (kt + 2 < ntiles_run) { if constexpr (NW <= 8) { if constexpr (NW == 8) { if constexpr (SPLIT) ST_DMA_WAIT(3); else ST_DMA_WAIT(2); } else { if constexpr (SPLIT) ST_DMA_WAIT(6); else ST_DMA_WAIT(4); } } else ST_DMA_WAIT(1); }
         else ST_DMA_WAIT(0);
         __syncthreads();      // publishes tile kt+1, frees buffer kt % 3 for tile kt+3
         buf = buf == NBUF - 1 ? 0 : buf + 1;
     }
-    if (dead) return;      // (after the loop's last barrier; nothing below synchronises the block)
     const float m_run = m_ref;
-
     const float l_tot = xor32_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if constexpr (!TRAIN) {
+        // Run-time statistic (st_attention_stats): the largest log2-sum-exp of any VALID query row.  It bounds the row's score maximum
+        // from above within log2(T) -- a serving loop reads it to see whether a checkpoint's softmax has become an arg-max (maxima of
+        // 80-200 in natural units), the regime in which 16-bit q / k operands miss the 1e-3 parity bar.  One atomic per block.
+        if (a.lse_max) {
+            float v = -3.0e38f;
+            if (!dead && query < T && query < kvend && l_tot > 0.f) v = m_run + log2f(l_tot);
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+            if (lane == 0) wave_lse[wave] = v;
+            __syncthreads();
+            if (tid == 0) {
+                float b = wave_lse[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) b = fmaxf(b, wave_lse[w]);
+                int bits = __float_as_int(b);
+                bits = bits >= 0 ? bits : bits ^ 0x7fffffff;      // order-preserving map of floats onto signed ints
+                atomicMax((int*)a.lse_max + ((blockIdx.x % kLseCells) << 4), bits);
+            }
+        }
+    }
+    if (dead) return;      // (after the last barrier; nothing below synchronises the block)
     if constexpr (TRAIN) {
         // (the row index is re-derived here: hipcc otherwise carries its 64-bit form across the key loop -- two registers the
         //  128-VGPR training variant does not have)
@@ -551,12 +598,28 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
     if (!a.zeros || !a.kbias) return hipErrorInvalidValue;
     const int qtiles = (a.T + 32 * ST_ATTN_WAVES - 1) / (32 * ST_ATTN_WAVES);
     const int total = a.n_items * a.H * qtiles;
-    if (!a.lse && a.small_max_blocks > 0 && total <= a.small_max_blocks)
+    if (!a.lse && !a.q_lo && a.small_max_blocks > 0 && total <= a.small_max_blocks)
         return dtype == DT_BF16 ? launch_attention_small<OpBF16>(a, s) : launch_attention_small<OpF16>(a, s);
     const int grid = 8 * ((a.n_items * a.H + 7) / 8) * qtiles;      // 8 XCDs x (item, head) groups per XCD x query tiles
     if (a.lse) {
         if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
         else                  hipLaunchKernelGGL((attention_kernel<OpF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.q_lo || a.k_lo) {       // split-precision scores (72 KB of LDS: above the 64 KB default, opt in per device)
+        if (!a.q_lo || !a.k_lo) return hipErrorInvalidValue;
+        static bool attr_done_dev[64][2] = {};
+        int dev_ = 0;
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
+        const int di = dtype == DT_BF16 ? 0 : 1;
+        const void* fn = di == 0 ? (const void*)attention_kernel<OpBF16, false, true> : (const void*)attention_kernel<OpF16, false, true>;
+        if (!attr_done_dev[dev_][di]) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            (void)e;
+            attr_done_dev[dev_][di] = true;
+        }
+        if (di == 0) hipLaunchKernelGGL((attention_kernel<OpBF16, false, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+        else         hipLaunchKernelGGL((attention_kernel<OpF16, false, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
         return hipGetLastError();
     }
     if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, false>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);

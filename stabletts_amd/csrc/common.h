@@ -64,6 +64,15 @@ __device__ __forceinline__ uint2 scale_pack4(float a, float b, float c, float d,
     return pack4<P>(pa, pb, pc, pd);
 }
 
+// ... and the rounding residuals of the same four products: lo = fl16(x s - fl16(x s)) (split-precision q / k operands: hi + lo
+// carries ~22 bits of the fp32 value; the hi part is bit-identical to scale_pack4's)
+template <class P>
+__device__ __forceinline__ uint2 scale_pack4_lo(float a, float b, float c, float d, float s) {
+    float pa = a * s, pb = b * s, pc = c * s, pd = d * s;
+    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));
+    return pack4<P>(pa - (float)to16<P>(pa), pb - (float)to16<P>(pb), pc - (float)to16<P>(pc), pd - (float)to16<P>(pd));
+}
+
 template <class P>
 __device__ __forceinline__ typename P::vec8 as_vec8(uint4 v) {
     return __builtin_bit_cast(typename P::vec8, v);

@@ -440,6 +440,11 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
     const int tlim = g.t_lim ? min(T, g.t_lim[n % g.t_lim_mod]) : T;      // ragged batches: q / k rows past the last needed frame are not stored
     if (which < 2) {
         const float sc = which == 0 ? g.qscale : 1.0f;
+        unsigned char* dst_lo = (unsigned char*)(which == 0 ? g.q_lo : g.k_lo);
+        // pass 0: the 16-bit plane; pass 1 (split-precision attention operands only): the rounding residuals of the same values
+        // through the same LDS image -- the RoPE rotation is recomputed (same instructions: the hi part is bit-identical)
+        for (int pass = 0; pass < (dst_lo ? 2 : 1); ++pass) {
+        if (pass) __syncthreads();      // the row stores of pass 0 have read the image
 #pragma unroll
         for (int b = 0; b < FF; ++b) {
             const int fl = wf * TF + b * 32 + l31;
@@ -466,14 +471,20 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
                 unsigned char* row = stage + ((wc * HPW + hh) * BF + fl) * PQ + 4 * hi * 2;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    *(uint2*)(row + 16 * q4) = scale_pack4<P>(r[4 * q4 + 0], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3], sc);
-                    *(uint2*)(row + 64 + 16 * q4) = scale_pack4<P>(acc[2 * hh + 1][b][4 * q4 + 0], acc[2 * hh + 1][b][4 * q4 + 1],
-                                                                   acc[2 * hh + 1][b][4 * q4 + 2], acc[2 * hh + 1][b][4 * q4 + 3], sc);
+                    if (pass == 0) {
+                        *(uint2*)(row + 16 * q4) = scale_pack4<P>(r[4 * q4 + 0], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3], sc);
+                        *(uint2*)(row + 64 + 16 * q4) = scale_pack4<P>(acc[2 * hh + 1][b][4 * q4 + 0], acc[2 * hh + 1][b][4 * q4 + 1],
+                                                                       acc[2 * hh + 1][b][4 * q4 + 2], acc[2 * hh + 1][b][4 * q4 + 3], sc);
+                    } else {
+                        *(uint2*)(row + 16 * q4) = scale_pack4_lo<P>(r[4 * q4 + 0], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3], sc);
+                        *(uint2*)(row + 64 + 16 * q4) = scale_pack4_lo<P>(acc[2 * hh + 1][b][4 * q4 + 0], acc[2 * hh + 1][b][4 * q4 + 1],
+                                                                          acc[2 * hh + 1][b][4 * q4 + 2], acc[2 * hh + 1][b][4 * q4 + 3], sc);
+                    }
                 }
             }
         }
         __syncthreads();
-        unsigned char* dst = (unsigned char*)(which == 0 ? g.q : g.k);
+        unsigned char* dst = pass ? dst_lo : (unsigned char*)(which == 0 ? g.q : g.k);
         const int rsub = lane >> 3, seg = lane & 7;
 #pragma unroll
         for (int i = 0; i < (BC / 64) * BF / (NW * 8); ++i) {
@@ -481,6 +492,7 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
             const int head = rowid / BF, f = rowid % BF;
             const uint4 v = *(const uint4*)(stage + rowid * PQ + seg * 16);
             if (t0 + f < tlim) store_row16(dst + (((size_t)n * H + head) * T + t0 + f) * 128 + seg * 16, v);
+        }
         }
     } else {
 #pragma unroll

@@ -132,7 +132,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         }
     }
     // the fused q/k/v projection of big grids: weights in registers, activations streamed (qkv_ws.hip; bit-identical)
-    if (epi == EPI_QKV && e->qkv_ws && e->sink && a.w_frag && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
+    if (epi == EPI_QKV && e->qkv_ws && !a.q_lo && e->sink && a.w_frag && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
         (int64_t)a.n_items * ((T + 63) / 64) >= e->qkv_ws_min_tiles) {      // (per LAUNCH: a block needs a handful of tiles to amortise its weight load)
         ConvGemmArgs b = a; b.sink = e->sink;
         return launch_qkv_ws(e->dt, b, s);
@@ -201,7 +201,7 @@ struct Plan {
     bool cfg;
     // 16-bit MFMA operands.  *lo tensors hold x - float(hi): the split-precision operand pairs of the three GEMMs
     // whose rounding error reaches the output un-gated (in_proj x-part and cond-part, final_proj)
-    void *mu16, *pre1, *pre2, *cond16, *cond16lo, *x16, *x16lo, *h16, *h2_16, *q16, *k16, *vt16, *ao16, *u16, *cur16, *cur16lo;
+    void *mu16, *pre1, *pre2, *cond16, *cond16lo, *x16, *x16lo, *h16, *h2_16, *q16, *k16, *q16lo, *k16lo, *vt16, *ao16, *u16, *cur16, *cur16lo;
     void* skip16[8];
     // fp32
     float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
@@ -246,6 +246,8 @@ size_t layout_plan(st_engine* e, int B, int T, bool cfg, int n_t, size_t off, Pl
     want(&p->h2_16, N * TT * C * 2);
     want(&p->q16, N * TT * C * 2);
     want(&p->k16, N * TT * C * 2);
+    want(&p->q16lo, N * TT * C * 2);      // split-precision attention operands (st_set_option "attention_precision"): always laid out,
+    want(&p->k16lo, N * TT * C * 2);      // so that switching the mode does not move the arena
     want(&p->vt16, N * (size_t)C * p->Tp * 2);
     want(&p->ao16, N * TT * C * 2);
     want(&p->u16, N * TT * F * 2);
@@ -462,6 +464,7 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             ConvGemmArgs a = base_args(e, p, e->qkv[i], N);
             a.a0 = p.h16; a.c0 = C;
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+            if (e->attn_split) { a.q_lo = p.q16lo; a.k_lo = p.k16lo; }      // (the generic tile writes the residual planes; the weight-stationary kernel has no room for them)
             a.Tp = p.Tp; a.n_heads = e->H;
             if ((int)e->qkv_frag.size() == L) a.w_frag = e->qkv_frag[i];
             a.qscale = 1.4426950408889634f / sqrtf((float)(C / e->H));
@@ -477,6 +480,8 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.out = p.ao16; a.kbias = p.kbias; a.mask_mod = p.B; a.zeros = e->zeros;
             a.kv_end = p.kv_end; a.n_full = p.n_full; a.T = T; a.Tp = p.Tp; a.H = e->H; a.n_items = N;
             a.small_max_blocks = e->conc == 1 ? e->attn_small_blocks : 0;
+            if (e->attn_split) { a.q_lo = p.q16lo; a.k_lo = p.k16lo; }
+            a.lse_max = e->lse_cells;
             if (e->ragged_skip && !cap) a.t_lim = p.t_lim;
             ProfScope ps(e, s, PC_ATTN, 4.0 * (double)N * e->H * (double)T * T * (C / e->H));
             if (!(e->skip_mask >> PC_ATTN & 1)) HIPCHK(e, launch_attention(e->dt, a, s));
@@ -984,6 +989,8 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
     build_param_table(e);
     if (hipMalloc((void**)&e->kpart, kSplitKBytes) == hipSuccess) e->kpart_bytes = kSplitKBytes; else e->kpart = nullptr;
     if (hipMalloc(&e->sink, 65536) != hipSuccess) e->sink = nullptr;      // (without it the q/k/v projection stays on the generic tile)
+    if (hipMalloc((void**)&e->lse_cells, kLseCells * 64) != hipSuccess ||
+        hipMemsetD32((hipDeviceptr_t)e->lse_cells, (int)0x80000000, kLseCells * 16) != hipSuccess) { (void)hipGetLastError(); e->lse_cells = nullptr; }
     if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         if (e->kpart) hipFree(e->kpart);
@@ -1029,6 +1036,7 @@ void st_destroy(st_engine* e) {
     if (e->rope_sin) hipFree(e->rope_sin);
     if (e->zeros) hipFree(e->zeros);
     if (e->sink) hipFree(e->sink);
+    if (e->lse_cells) hipFree(e->lse_cells);
     if (e->kpart) hipFree(e->kpart);
     if (e->status_host) hipHostFree(e->status_host);
     delete e;
@@ -1634,6 +1642,52 @@ int st_last_solve_stats(const st_engine* e, int64_t* nfe, int64_t* steps, int64_
     if (nfe) *nfe = e->last_nfe;
     if (steps) *steps = e->last_steps;
     if (rejects) *rejects = e->last_rejects;
+    return ST_OK;
+}
+
+// Engine options by name (no reference analogue: the reference computes in fp32).
+//   "attention_precision"  0 (default): q, k, v enter the attention as 16-bit operands;  1: q and k as hi + lo pairs of 16-bit operands,
+//                          scores = q_hi k_hi + q_lo k_hi + q_hi k_lo (inference / solve path; for checkpoints whose softmax is an
+//                          arg-max -- see st_attention_stats).  Takes effect at the next call.
+//   "fused_ffn"            read-only: 0 two-kernel FFN, 1 fused direct kernel, 3 fused Winograd kernel (ST_FUSED_FFN at st_create).
+int st_set_option(st_engine* e, const char* name, int value) {
+    if (!e || !name) return ST_ERR_INVALID;
+    const std::string n(name);
+    if (n == "attention_precision") {
+        if (value != 0 && value != 1) return e->fail(ST_ERR_INVALID, "attention_precision: 0 (16-bit q / k operands) or 1 (split hi + lo operands)");
+        if (e->kind != 0) return e->fail(ST_ERR_UNSUPPORTED, "attention_precision: CFM decoder handles only");
+        if (value != e->attn_split) { e->drop_graphs(); e->attn_split = value; }
+        return ST_OK;
+    }
+    if (n == "fused_ffn") return e->fail(ST_ERR_INVALID, "fused_ffn is read-only (ST_FUSED_FFN at st_create)");
+    return e->fail(ST_ERR_INVALID, std::string("unknown option: ") + name);
+}
+
+int st_get_option(const st_engine* e, const char* name, int* value) {
+    if (!e || !name || !value) return ST_ERR_INVALID;
+    const std::string n(name);
+    if (n == "attention_precision") { *value = e->attn_split; return ST_OK; }
+    if (n == "fused_ffn") { *value = e->fused_ffn; return ST_OK; }
+    return ST_ERR_INVALID;
+}
+
+// Largest log-sum-exp (natural-log units, of the scaled scores q.k / sqrt(d) + mask) over every valid attention row of the estimator
+// evaluations completed on `stream` since the last query; -inf when there were none.  The row's score maximum lies within log(T) below
+// it.  Synchronises `stream`, reads 16 words, resets the cells.
+int st_attention_stats(st_engine* e, void* stream, float* max_lse) {
+    if (!e || !max_lse) return ST_ERR_INVALID;
+    if (!e->lse_cells) return e->fail(ST_ERR_STATE, "attention statistics unavailable (allocation failed at st_create)");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    int cells[kLseCells * 16];
+    HIPCHK(e, hipMemcpy(cells, e->lse_cells, sizeof(cells), hipMemcpyDeviceToHost));
+    int best = (int)0x80000000;
+    for (int c = 0; c < kLseCells; ++c) best = std::max(best, cells[c * 16]);
+    HIPCHK(e, hipMemsetD32((hipDeviceptr_t)e->lse_cells, (int)0x80000000, kLseCells * 16));
+    if (best == (int)0x80000000) { *max_lse = -INFINITY; return ST_OK; }
+    const int bits = best >= 0 ? best : best ^ 0x7fffffff;
+    float v; memcpy(&v, &bits, 4);
+    *max_lse = v * 0.6931471805599453f;      // the kernel works in log2 units (q is pre-scaled by log2 e / sqrt(d))
     return ST_OK;
 }
 

@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     float* branch32;                  // EPI_RESGATE: also stores the branch output (acc+b)*mask in fp32 (training: the gate's gradient needs it)
     // EPI_QKV (cout = 3*C, head_dim 64): q,k -> [item][H][T][64], vT -> [item][H][64][Tp]
     void* q; void* k; void* vt;
+    void* q_lo; void* k_lo;           // split-precision attention operands (nullptr: off): the rounding residuals of q and k, same layout
     const float* rope_cos; const float* rope_sin;   // [T][16]
     int Tp; float qscale; int n_heads;
     const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
@@ -118,6 +119,8 @@ hipError_t launch_drop_tables(const DropCfg& d, int n_rows, int n_colpairs, unsi
 // ---------------------------------------------------------------- attention
 struct AttnArgs {
     const void* q; const void* k; const void* vt; void* out;   // out: [item][T][H*64] 16-bit
+    const void* q_lo; const void* k_lo;    // inference: split-precision scores s = q_hi k_hi + q_lo k_hi + q_hi k_lo (nullptr: s = q k); 16-bit, layout of q / k
+    unsigned* lse_max;                     // inference: a group of kLseCells cells 64 B apart receiving max over rows of the log2-sum-exp (order-preserving int bits; nullptr: off)
     const float* kbias; int mask_mod;      // additive key bias [mask_mod][Tp]: 0 valid, -1e30 masked / >= T
     const int* kv_end; const int* n_full;  // per mask row: last valid key + 1, leading valid prefix length
     int T, Tp, H, n_items;
@@ -127,6 +130,7 @@ struct AttnArgs {
     const int* t_lim;                      // query tiles of mask row mb that start at or beyond t_lim[mb] are skipped (nullptr: none)
     int small_max_blocks;                  // inference: launches of <= this many 256-query blocks use the key-split small-grid kernel (0: never)
 };
+constexpr int kLseCells = 16;
 hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- FiLM + LayerNorm + adaLN modulate

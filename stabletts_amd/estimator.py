@@ -101,7 +101,7 @@ class Decoder(nn.Module):
 
     def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels,
                  dropout=0.1, n_layers=1, n_heads=4, kernel_size=3, gin_channels=0, use_lsc=True,
-                 operand_dtype="f16"):
+                 operand_dtype="f16", attention_precision="16bit"):
         super().__init__()
         assert hidden_channels % 2 == 0, "SinusoidalPosEmb requires dim to be even"
         if not use_lsc:
@@ -114,6 +114,14 @@ class Decoder(nn.Module):
         self.filter_channels, self.n_layers, self.n_heads = filter_channels, n_layers, n_heads
         self.kernel_size, self.gin_channels, self.use_lsc = kernel_size, gin_channels, use_lsc
         self.operand_dtype = operand_dtype
+        # "16bit": q, k, v enter the attention MFMAs as 16-bit operands (default).  "split": q and k as hi + lo operand pairs (three
+        # QK^T products: +~50 % attention time) for checkpoints whose softmax is an arg-max.  "auto": starts at "16bit"; CFMDecoder
+        # reads the engine's attention statistic after a solve and switches to "split" when the largest log-sum-exp exceeds
+        # AUTO_SPLIT_LSE (one stream synchronisation per solve while still undecided, none afterwards).
+        if attention_precision not in ("16bit", "split", "auto"):
+            raise ValueError("attention_precision must be '16bit', 'split' or 'auto'")
+        self.attention_precision = attention_precision
+        self._attn_split = attention_precision == "split"
         self.p_dropout = float(dropout)        # train-mode dropout of the FFN activations and attention probabilities
 
         self.time_mlp = TimestepEmbedding(hidden_channels, hidden_channels, filter_channels)
@@ -183,6 +191,8 @@ class Decoder(nn.Module):
             self._engine = _lib.Engine(self.noise_channels, self.hidden_channels, self.filter_channels, self.n_heads,
                                        self.n_layers, self.kernel_size, self.gin_channels, self.operand_dtype, dev)
             self._engine_key = None
+            if getattr(self, "_attn_split", False):
+                self._engine.set_option("attention_precision", 1)
         key, vers = self._param_key()
         if key != self._engine_key:
             with torch.no_grad():
@@ -203,6 +213,16 @@ class Decoder(nn.Module):
                 self._engine.repack(torch.cuda.current_stream(dev).cuda_stream)
             self._engine_vers = vers
         return self._engine
+
+    AUTO_SPLIT_LSE = 50.0      # natural units; seeded / initialised weights give ~10, the arg-max regime of DESIGN.md section 2 80-200
+
+    def set_attention_precision(self, mode):
+        """'16bit' / 'split' (see __init__); applies to the live engine at once."""
+        if mode not in ("16bit", "split"):
+            raise ValueError("mode must be '16bit' or 'split'")
+        self._attn_split = mode == "split"
+        if self._engine is not None:
+            self._engine.set_option("attention_precision", int(self._attn_split))
 
     def device(self):
         return next(self.parameters()).device

@@ -28,17 +28,17 @@ from .estimator import Decoder
 
 class CFMDecoder(nn.Module):
     def __init__(self, noise_channels, cond_channels, hidden_channels, out_channels, filter_channels, n_heads,
-                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="f16", check_finite=None):
+                 n_layers, kernel_size, p_dropout, gin_channels, operand_dtype="f16", check_finite=None, attention_precision="16bit"):
         super().__init__()
         # check_finite=True: every forward() asks the engine whether its output contains NaN / Inf (one stream
         # synchronisation per call) and raises -- f16 operands overflow at 65504, which an fp32 checkpoint may exceed; the
         # remedy is operand_dtype="bf16" (INTEGRATION.md section 2).  Off by default: serving loops enqueue solves back to back.
         # Exception: with the opt-in Winograd FFN (ST_FUSED_FFN=3, f16) the FFN intermediate overflows at |u| > 32,752 -- half the
         # range of the default kernels -- so the check is ON unless the caller turns it off explicitly.
-        if check_finite is None:
-            import os
-            check_finite = operand_dtype == "f16" and os.environ.get("ST_FUSED_FFN") == "3"
-        self.check_finite = bool(check_finite)
+        # (None is resolved against the ENGINE at its first use -- its "fused_ffn" option says which FFN kernel it actually runs;
+        #  the environment may have changed between this constructor and the engine's lazy creation.)
+        self._check_finite = None if check_finite is None else bool(check_finite)
+        self._auto_pending = attention_precision == "auto"
         self.noise_channels = noise_channels
         self.cond_channels = cond_channels
         self.hidden_channels = hidden_channels
@@ -48,7 +48,21 @@ class CFMDecoder(nn.Module):
         self.sigma_min = 1e-4
         self.estimator = Decoder(noise_channels, cond_channels, hidden_channels, out_channels, filter_channels,
                                  p_dropout, n_layers, n_heads, kernel_size, gin_channels,
-                                 operand_dtype=operand_dtype)
+                                 operand_dtype=operand_dtype, attention_precision=attention_precision)
+
+    @property
+    def check_finite(self):
+        if self._check_finite is not None:
+            return self._check_finite
+        eng = self.estimator._engine
+        if eng is None:        # no engine yet: what its creation would decide in the current environment
+            import os
+            return self.estimator.operand_dtype == "f16" and os.environ.get("ST_FUSED_FFN") == "3"
+        return eng.get_option("fused_ffn") == 3
+
+    @check_finite.setter
+    def check_finite(self, value):
+        self._check_finite = None if value is None else bool(value)
 
     @torch.inference_mode()
     def forward(self, mu, mask, n_timesteps, temperature=1.0, c=None, solver=None, cfg_kwargs=None, z=None):
@@ -90,6 +104,18 @@ class CFMDecoder(nn.Module):
                     import warnings
                     warnings.warn(f"implicit_adams: the Adams-Moulton corrector did not converge in {rej} step(s) "
                                   "(torchdiffeq warns 'Functional iteration did not converge. Solution may be incorrect.' here)")
+            if self._auto_pending:        # attention_precision="auto": one look at the statistic after the first solve(s) decides
+                lse = eng.attention_stats(stream)
+                if lse > self.estimator.AUTO_SPLIT_LSE:
+                    import warnings
+                    warnings.warn(f"stabletts_amd: the largest attention log-sum-exp of this solve is {lse:.1f} (> {self.estimator.AUTO_SPLIT_LSE:.0f}): "
+                                  "this checkpoint's softmax is close to an arg-max, where 16-bit q / k operands miss the 1e-3 parity bar; "
+                                  "switching to attention_precision='split' (this solve is repeated with it)")
+                    self.estimator.set_attention_precision("split")
+                    self._auto_pending = False
+                    eng.cfm_solve(mu, mask, z, c, int(n_timesteps), _lib.SOLVERS[solver], use_cfg, strength, fs, fc, out, stream)
+                elif lse > float("-inf"):
+                    self._auto_pending = False
             if self.check_finite and eng.output_nonfinite(stream):
                 raise FloatingPointError(
                     "stabletts_amd: the solve produced NaN / Inf.  With operand_dtype='f16' an activation beyond 65504 "

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.st_abi_version() == 3
+    assert lib.st_abi_version() == 4
 
 
 def _create(lib, **over):
