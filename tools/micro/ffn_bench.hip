@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "../../stabletts_amd/csrc/ffn_fused16.h"
+#include "../../stabletts_amd/csrc/ffn_fused.h"
 
 using namespace st;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -33,26 +33,8 @@ static float run(const ConvGemmArgs& a0, int reps, hipStream_t s) {
     return ms * 1000.0f / reps;
 }
 
-// the 16x16x32 kernel (ffn_fused16.h), fed the same weights packed into its own stream layout; its outputs are compared with
-// variant (0, 0)'s (the two shapes sum a K = 32 step in the same order if the hardware runs 16x16x32 as two K = 16 passes).
-template <int ABL>
-static float run16(const ConvGemmArgs& a0, int reps, hipStream_t s) {
-    CK(hipFuncSetAttribute((const void*)ffn_fused16_kernel<OpF16, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds));
-    ConvGemmArgs b = a0;
-    b.tiles_f = (b.T + kFfnFusedFrames - 1) / kFfnFusedFrames;
-    b.tiles_c = 1;
-    const int total = b.n_items * b.tiles_f, grid = ((total + 7) / 8) * 8;
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((ffn_fused16_kernel<OpF16, ABL>), dim3(grid), dim3(512), kFfnLds, s, b);      // warm-up
-    CK(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ffn_fused16_kernel<OpF16, ABL>), dim3(grid), dim3(512), kFfnLds, s, b);
-    CK(hipEventRecord(e1, s));
-    CK(hipEventSynchronize(e1));
-    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-    CK(hipGetLastError());
-    return ms * 1000.0f / reps;
-}
-
+// (The 16x16x32-fragment cut of this kernel -- round 4, removed from the library in round 5 -- had its own harness branch here:
+//  git show 8cdc22b:tools/micro/ffn_bench.hip.)
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 1000, F = 1024, C = 256, reps = 20, rounds = 3;
     // data fill (argv[3]): 0 = uniform random (default), 1 = zeros (lowest switching power: how far is the kernel from its
@@ -60,7 +42,7 @@ int main(int argc, char** argv) {
     const int fill = argc > 3 ? atoi(argv[3]) : 0;
     hipStream_t s; CK(hipStreamCreate(&s));
     const size_t rows = (size_t)N * T;
-    std::vector<_Float16> h(rows * C), w((size_t)2 * F * C * 3), w16((size_t)2 * F * C * 3);
+    std::vector<_Float16> h(rows * C), w((size_t)2 * F * C * 3);
     for (auto& v : h) v = (_Float16)(fill == 1 ? 0.0f : fill == 2 ? (frand() + frand() + frand() + frand()) * 1.7f : frand() * 2.0f);
     {   // conv_1 (F, 256, 3) and conv_2 (256, F, 3) weights, packed into the stream of either kernel (common.h: ffn_stream_index)
         std::vector<float> wsrc[2] = {std::vector<float>((size_t)F * C * 3), std::vector<float>((size_t)F * C * 3)};
@@ -70,7 +52,6 @@ int main(int argc, char** argv) {
             for (size_t idx = 0; idx < (size_t)F * C * 3; ++idx) {
                 size_t so, dof;
                 ffn_stream_index(idx, st, F, &so, &dof);     w[dof] = (_Float16)wsrc[st][so];
-                ffn_stream_index(idx, st | 2, F, &so, &dof); w16[dof] = (_Float16)wsrc[st][so];
             }
     }
     printf("fill mode %d\n", fill);
@@ -81,12 +62,12 @@ int main(int argc, char** argv) {
     for (auto& v : x) v = frand() * 2.0f;
     for (auto& v : film) v = 1.0f + frand() * 0.1f;
     for (auto& v : ada) v = frand() * 0.1f;
-    void *dh, *dw, *dw16, *db1, *db2, *dgate, *dmask, *dx, *dxo, *do16, *dln, *dfilm, *dada, *dz;
-    CK(hipMalloc(&dh, h.size() * 2)); CK(hipMalloc(&dw, w.size() * 2)); CK(hipMalloc(&dw16, w16.size() * 2)); CK(hipMalloc(&db1, F * 4)); CK(hipMalloc(&db2, C * 4));
+    void *dh, *dw, *db1, *db2, *dgate, *dmask, *dx, *dxo, *do16, *dln, *dfilm, *dada, *dz;
+    CK(hipMalloc(&dh, h.size() * 2)); CK(hipMalloc(&dw, w.size() * 2)); CK(hipMalloc(&db1, F * 4)); CK(hipMalloc(&db2, C * 4));
     CK(hipMalloc(&dgate, gate.size() * 4)); CK(hipMalloc(&dmask, mask.size() * 4)); CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&dxo, x.size() * 4));
     CK(hipMalloc(&do16, rows * C * 2)); CK(hipMalloc(&dln, rows * C * 2)); CK(hipMalloc(&dfilm, film.size() * 4)); CK(hipMalloc(&dada, ada.size() * 4));
     CK(hipMalloc(&dz, 256)); CK(hipMemset(dz, 0, 256));
-    CK(hipMemcpy(dh, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dh, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db1, b1.data(), F * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db2, b2.data(), C * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dgate, gate.data(), gate.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dmask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
@@ -108,29 +89,24 @@ int main(int argc, char** argv) {
         printf("   check %-10s: %zu of %zu outputs differ from variant (0,0)%s\n", name, bad, out.size(), bad ? "  <-- differs" : "");
     };
 #define RUNV(ABL, VAR) { const float us = run<ABL, VAR>(a, reps, s); printf("round %d  ABL %2d VAR %d : %7.1f us  %6.0f TF/s\n", r, ABL, VAR, us, gflop / us * 1e3); fflush(stdout); }
-    ConvGemmArgs a16 = a; a16.w = dw16;
-#define RUN16(ABL) { const float us = run16<ABL>(a16, reps, s); printf("round %d  16x16x32 ABL %2d : %7.1f us  %6.0f TF/s\n", r, ABL, us, gflop / us * 1e3); fflush(stdout); }
     if (argc > 4 && atoi(argv[4]) == 3) {
         // Interleaved mode: every FFN launch is preceded by an HBM-bound filler (device-to-device copy), like the solve, where the
         // fused FFN alternates with out-proj / QKV / attention; the FFN launch alone is event-timed.  Question: does the 16x16x32
         // kernel's back-to-back advantage (it draws less power) survive when the chip is not held at its sustained power limit?
-        ConvGemmArgs a16 = a; a16.w = dw16;
         const size_t fb = argc > 5 ? (size_t)atoi(argv[5]) << 20 : (size_t)128 << 20;
         void *f0, *f1; CK(hipMalloc(&f0, fb)); CK(hipMalloc(&f1, fb));
         CK(hipFuncSetAttribute((const void*)ffn_fused_kernel<OpF16, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds));
-        CK(hipFuncSetAttribute((const void*)ffn_fused16_kernel<OpF16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds));
-        ConvGemmArgs b32 = a, b16 = a16;
-        b32.tiles_f = b16.tiles_f = (T + kFfnFusedFrames - 1) / kFfnFusedFrames; b32.tiles_c = b16.tiles_c = 1;
+        ConvGemmArgs b32 = a;
+        b32.tiles_f = (T + kFfnFusedFrames - 1) / kFfnFusedFrames; b32.tiles_c = 1;
         const int total = N * b32.tiles_f, grid = ((total + 7) / 8) * 8, R = 40;
         std::vector<hipEvent_t> ev(2 * R);
         for (auto& e : ev) CK(hipEventCreate(&e));
         for (int round = 0; round < 4; ++round)
-            for (int which = 0; which < 2; ++which) {
+            for (int which = 0; which < 1; ++which) {
                 for (int i = 0; i < R; ++i) {
                     CK(hipMemcpyAsync(f1, f0, fb, hipMemcpyDeviceToDevice, s));
                     CK(hipEventRecord(ev[2 * i], s));
-                    if (which == 0) hipLaunchKernelGGL((ffn_fused_kernel<OpF16, 0, 0>), dim3(grid), dim3(512), kFfnLds, s, b32);
-                    else            hipLaunchKernelGGL((ffn_fused16_kernel<OpF16, 0>), dim3(grid), dim3(512), kFfnLds, s, b16);
+                    hipLaunchKernelGGL((ffn_fused_kernel<OpF16, 0, 0>), dim3(grid), dim3(512), kFfnLds, s, b32);
                     CK(hipEventRecord(ev[2 * i + 1], s));
                 }
                 CK(hipStreamSynchronize(s));
@@ -144,10 +120,8 @@ int main(int argc, char** argv) {
     }
     const bool quick = argc > 4 && atoi(argv[4]) >= 1, order = argc > 4 && atoi(argv[4]) == 2;      // argv[4] = 1: only the two shipped kernels and their main ablations
     for (int r = 0; r < rounds; ++r) {
-        if (order && r) { RUN16(0) RUNV(0, 0) RUNV(1, 0) RUNV(3, 0) RUNV(35, 0) RUN16(1) RUN16(3) RUN16(35) continue; }      // the two kernels in the other order
+        if (order && r) { RUNV(0, 0) RUNV(1, 0) RUNV(3, 0) RUNV(35, 0) continue; }
         RUNV(0, 0) if (r == 0) check("(0,0)", true);
-        RUN16(0) if (r == 0) check("16x16x32", false);
-        RUN16(1) RUN16(3) RUN16(35)
         if (quick) { RUNV(1, 0) RUNV(3, 0) RUNV(35, 0) continue; }
         RUNV(0, 1) if (r == 0) check("(0,1)", false);
         RUNV(0, 3) if (r == 0) check("(0,3)", false);
