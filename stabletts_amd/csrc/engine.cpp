@@ -206,7 +206,6 @@ struct Plan {
     // fp32
     float *cpart, *X, *v32, *xstate, *kbuf[7], *ynew, *ode_partial, *ode_out, *tvals, *emb, *th, *tau, *film, *cvec, *ada, *ada_tmp;
     int *n_full, *kv_end;
-    unsigned* wq;       // qkv_ws work-queue counters: a ring of 64 sets x 64 counters (zero after the arena is zeroed; launch k uses set k % 64 and clears set (k + 32) % 64)
     int* t_lim;         // [B + 1] frames of every utterance that are computed (mask_prep: last valid + 1 + halo), [B] = the longest
     float* kbias;
     float* maskbuf;     // engine-owned copy of the caller's (B,1,T) mask: the solve body touches arena memory only
@@ -266,7 +265,6 @@ size_t layout_plan(st_engine* e, int B, int T, bool cfg, int n_t, size_t off, Pl
     want((void**)&p->ada, (size_t)L * N * 6 * C * 4);
     want((void**)&p->n_full, (size_t)B * 4);
     want((void**)&p->kv_end, (size_t)B * 4);
-    want((void**)&p->wq, (size_t)64 * 64 * 4);
     want((void**)&p->t_lim, (size_t)(B + 1) * 4);
     want((void**)&p->kbias, (size_t)B * p->Tp * 4);
     want((void**)&p->maskbuf, (size_t)B * TT * 4);
@@ -286,7 +284,6 @@ int ensure_ws(st_engine* e, size_t bytes) {
 int arena_fresh(st_engine* e, uint64_t sig, size_t used_bytes, hipStream_t s) {
     if (sig == e->ws_sig) return ST_OK;
     HIPCHK(e, hipMemsetAsync(e->ws, 0, used_bytes, s));
-    e->wq_k.clear();
     e->ws_sig = sig;
     return ST_OK;
 }
@@ -468,11 +465,6 @@ int run_estimator(st_engine* e, const Plan& p, const float* mask, int ev, hipStr
             a.a0 = p.h16; a.c0 = C;
             a.q = p.q16; a.k = p.k16; a.vt = p.vt16; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
             if (e->attn_split) { a.q_lo = p.q16lo; a.k_lo = p.k16lo; }      // (the generic tile writes the residual planes; the weight-stationary kernel has no room for them)
-            if (e->qkv_queue && 3 * ((T + 63) / 64) <= 64 && N <= 256) {
-                unsigned& k = e->wq_k[p.wq];
-                a.wq = p.wq + (size_t)(k % 64) * 64; a.wq_clear = p.wq + (size_t)((k + 32) % 64) * 64;
-                k += 1;
-            }
             a.Tp = p.Tp; a.n_heads = e->H;
             if ((int)e->qkv_frag.size() == L) a.w_frag = e->qkv_frag[i];
             a.qscale = 1.4426950408889634f / sqrtf((float)(C / e->H));
@@ -986,8 +978,6 @@ static int create_engine(const st_config* cfg, int kind, int n_vocab, int device
 #endif
     if (const char* v = getenv("ST_QKV_WS")) e->qkv_ws = atoi(v);
     if (const char* v = getenv("ST_QKV_WS_MIN_TILES")) e->qkv_ws_min_tiles = atoi(v);
-    if (const char* v = getenv("ST_QKV_WS_QUEUE")) e->qkv_queue = atoi(v);
-    if (const char* v = getenv("ST_HIP_GRAPH")) { if (atoi(v)) e->qkv_queue = 0; }      // (a replayed graph would replay the same counter set)
     if (const char* v = getenv("ST_OPROJ_WS")) e->oproj_ws = atoi(v);
     if (const char* v = getenv("ST_OPROJ_WS_MIN_TILES")) e->oproj_ws_min_tiles = atoi(v);
     if (const char* v = getenv("ST_QKV_RC1")) e->qkv_rc1 = atoi(v);     // 0: compute every padded frame tile (A/B runs)

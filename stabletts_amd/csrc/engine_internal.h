@@ -125,8 +125,6 @@ struct st_engine {
     int splitk_max = kSplitKMax, splitk_min_stages = 4;
     int small_tiles = 256;              // conv launches of <= this many 128x128 tiles use the 64-frame tile variants (0: never)
     int splitk_target = 256;            // split-K: blocks a small conv launch is brought up to (gemm())
-    int qkv_queue = 0;                  // ST_QKV_WS_QUEUE=1 (round-6 experiment, opt-in): qkv_ws blocks pull their tiles from a shared per-launch queue (qkv_ws.hip: QUEUE)
-    std::map<const void*, unsigned> wq_k;   // launches so far per queue-counter ring (key: the ring's arena address; cleared when the arena is re-zeroed)
     int attn_split = 0;                 // st_set_option("attention_precision", 1): q and k as hi + lo operand pairs, scores from three products (attention.hip: SPLIT)
     unsigned* lse_cells = nullptr;      // kLseCells cells 64 B apart: max over attention rows of the log2-sum-exp since the last st_attention_stats (order-preserving int bits)
     int attn_small_blocks = 32;         // attention launches of <= this many 256-query blocks use the key-split kernel

@@ -43,7 +43,6 @@ struct ConvGemmArgs {
     int Tp; float qscale; int n_heads;
     const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
     const void* w_frag;               // qkv_ws.hip: the q/k/v weight in fragment order (launch_pack_qkv_frag)
-    unsigned* wq; unsigned* wq_clear;  // qkv_ws.hip work-queue mode (nullptr: static lists): this launch's counters [3 * ceil(T / 64)], zero on entry, and a later launch's set, zeroed by this one
     void* sink;                       // >= 64 KiB of scratch that rows outside the tensor are stored to (qkv_ws.hip: every wave issues a FIXED number of stores)
     // fused prologue of the NEXT op (row-complete tiles, cout == 256): FiLM -> *mask -> LayerNorm -> modulate.
     // When ln_h16 != nullptr, out32 receives the post-FiLM residual stream and ln_h16 the 16-bit operand.

@@ -53,14 +53,7 @@ constexpr int kQwsLds = kQwsRing * kQwsTile + 2 * kQwsImage + kQwsRope;         
 // stores, 4 = LDS-DMA of the first two tiles only, 8 = no MFMAs, 16 = no image writes (+ no RoPE), 32 = one barrier per tile,
 // 64 = s_memtime stamps per loop segment into g.dbg.  (As a run-time argument the same switches cost the loop its schedule and
 // 12 bytes of scratch per lane.)
-// QUEUE (round 6, opt-in: ST_QKV_WS_QUEUE=1): the L blocks of one (plane, frame-tile position) share ONE work queue instead of owning
-// static lists (items first, first + L, ...): a block pops the next item with an atomic on a per-launch counter, so a block that
-// starts late -- its CU was still held by the other solve part's FFN block -- takes fewer tiles and the launch ends when the QUEUE
-// is empty, not when the unluckiest list is.  The pop is asynchronous: wave 0's lane 0 issues a returning atomic (inline asm, counted
-// on vmcnt like the LDS-DMA pieces) right after the barrier of iteration i, BEFORE the tile's 4 pieces; the `vmcnt(4)` at the top of
-// iteration i + 1 therefore retires it together with those pieces, wave 0 parks the value in LDS in front of the barrier and every
-// wave reads it behind the barrier -- as the item of tile i + 2.  Results are independent of which block computes a tile.
-template <class P, int VAR, bool QUEUE>
+template <class P, int VAR>
 __global__ __launch_bounds__(512, 1)
 void qkv_ws_kernel(const ConvGemmArgs g, int L) {
     constexpr int var = VAR;
@@ -82,39 +75,21 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
 
     // the block's work list: items first, first + L, ... whose tile tf is needed (ragged batches: t_lim), as a 64-bit mask built
     // with ONE vector load before the loop -- a load inside the loop would put a compiler-generated vmcnt(0) into the pipeline
-    unsigned long long todo = 0;
-    __shared__ int qslot[2];
-    __shared__ int tlimS[QUEUE ? 256 : 1];      // QUEUE: last needed frame of every item (an in-loop global load would count in vmcnt)
-    unsigned* qctr = nullptr;
-    unsigned qret = 0;                           // wave 0, lane 0: the value the in-flight atomic returns
-    if constexpr (!QUEUE) {
+    unsigned long long todo;
+    {
         const int n = first + lane * L;
         bool need = n < g.n_items;
         if (need && g.t_lim) need = t0 < g.t_lim[n % g.t_lim_mod];
         todo = __ballot(need);
-        if (todo == 0) return;
     }
+    if (todo == 0) return;
     auto pop_item = [&]() {       // next item of the list, g.n_items when it is exhausted (wave-uniform scalar arithmetic)
         if (todo == 0) return g.n_items;
         const int j = __builtin_ctzll(todo);
         todo &= todo - 1;
         return first + j * L;
     };
-    int ncur, n1;
-    if constexpr (QUEUE) {
-        qctr = g.wq + plane * tiles_f + tf;
-        if (tid < 256) tlimS[tid] = (tid < g.n_items && g.t_lim) ? g.t_lim[tid % g.t_lim_mod] : 0x7fffffff;
-        if (tid == 0) qslot[0] = (int)atomicAdd(qctr, 2u);                       // the block's first two items
-        if (lin == 0 && tid < 3 * tiles_f) g.wq_clear[tid] = 0u;                // a later launch's counters (engine.cpp: ring of sets)
-        __syncthreads();
-        const int q0 = qslot[0];
-        ncur = q0 < g.n_items ? q0 : g.n_items;
-        n1 = q0 + 1 < g.n_items ? q0 + 1 : g.n_items;
-        if (ncur >= g.n_items) return;      // the queue was empty when this block arrived
-        __syncthreads();                    // (qslot is rewritten inside the loop)
-    } else {
-        ncur = pop_item(); n1 = pop_item();
-    }
+    int ncur = pop_item(), n1 = pop_item();
 
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)smem);
     const unsigned char* zeros = (const unsigned char*)g.zeros;
@@ -131,8 +106,7 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
         voff[k] = (unsigned)((t0 + row) * 512 + chunk * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
     }
     auto issue_tile = [&](int n, int slot) {
-        bool unit = n < g.n_items;
-        if constexpr (QUEUE) unit = unit && t0 < tlimS[unit ? n : 0];      // ragged batches: a popped item that does not need this frame tile streams the zero page
+        const bool unit = n < g.n_items;
         const unsigned char* hb = (const unsigned char*)g.a0 + (size_t)((unit ? n : 0) % g.a0_mod) * T * 512;
         const unsigned dst = lds0 + (unsigned)(slot * kQwsTile + chunk * 8192 + (wave & 1) * 4096);
 #pragma unroll
@@ -235,15 +209,9 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
         else if constexpr ((var & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                         // younger than tile i's pieces: the 4 stores of tile i-2
         QWS_STAMP(0)
-        if constexpr (QUEUE) { if (i > 0 && tid == 0) qslot[i & 1] = (int)qret; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // (the atomic of iteration i - 1 has returned: it is older than tile i's pieces)
         ST_RAW_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
         QWS_STAMP(1)
-        if constexpr (QUEUE) {
-            if (i > 0) { const int q = qslot[i & 1]; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const int qq = __builtin_amdgcn_readfirstlane(q); n1 = qq < g.n_items ? qq : g.n_items; }
-            if (n1 < g.n_items && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(qret) : "v"(qctr), "v"(1u) : "memory");      // item of tile i + 2
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if constexpr (!(var & 4)) issue_tile(n1, slot ^ 1); else issue_tile(g.n_items, slot ^ 1);
         QWS_STAMP(2)
         __builtin_amdgcn_sched_barrier(0);
@@ -341,7 +309,7 @@ void qkv_ws_kernel(const ConvGemmArgs g, int L) {
         QWS_STAMP(4)
         nprev = ncur; last_ib = i & 1;
         if (n1 >= g.n_items) break;
-        ncur = n1; if constexpr (!QUEUE) n1 = pop_item();
+        ncur = n1; n1 = pop_item();
         slot ^= 1;
     }
     // the last tile's rows
@@ -372,9 +340,7 @@ static hipError_t launch_qkv_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return hipErrorInvalidDevice;
     if (!attr_done_dev[dev_]) {
-        hipError_t e = hipFuncSetAttribute((const void*)qkv_ws_kernel<P, ST_QWS_VAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)qkv_ws_kernel<P, ST_QWS_VAR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds);
+        hipError_t e = hipFuncSetAttribute((const void*)qkv_ws_kernel<P, ST_QWS_VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds);
         if (e != hipSuccess) return e;
         attr_done_dev[dev_] = true;
     }
@@ -386,10 +352,7 @@ static hipError_t launch_qkv_ws_t(const ConvGemmArgs& a, hipStream_t s) {
     if (L < (a.n_items + 63) / 64) L = (a.n_items + 63) / 64;      // a block's work list is a 64-bit mask
     if (L > a.n_items) L = a.n_items;
     const int grid = ((3 * tiles_f * L + 7) / 8) * 8;
-    if (a.wq && a.wq_clear && a.n_items <= 256 && 3 * tiles_f <= 512)
-        hipLaunchKernelGGL((qkv_ws_kernel<P, ST_QWS_VAR, true>), dim3(grid), dim3(512), kQwsLds, s, a, L);
-    else
-        hipLaunchKernelGGL((qkv_ws_kernel<P, ST_QWS_VAR, false>), dim3(grid), dim3(512), kQwsLds, s, a, L);
+    hipLaunchKernelGGL((qkv_ws_kernel<P, ST_QWS_VAR>), dim3(grid), dim3(512), kQwsLds, s, a, L);
     return hipGetLastError();
 }
 

@@ -225,3 +225,17 @@ def test_bench_refuses_engine_changing_environment():
     assert "refusing to measure" not in (r.stderr + r.stdout)       # build-only left-overs do not cost the harness its line
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs a HIP device" in (r.stderr + r.stdout)
+
+
+def test_micro_benchmarks_still_compile_against_the_kernel_headers():
+    """pruning a kernel header silently broke tools/micro/ffn_bench.hip (it included the deleted ffn_fused16.h), i.e. the
+    evidence tools DESIGN.md cites.  A front-end-only pass (hipcc -fsyntax-only, host + gfx950 device, ~8 s) over the micro-benchmarks
+    that instantiate library kernels keeps them compiling."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    srcs = [os.path.join(ROOT, "tools", "micro", f) for f in ("ffn_bench.hip", "qkv_bench.hip", "ffn_wino_bench.hip")]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-unused-value", *srcs], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -45,11 +45,11 @@ int main(int argc, char** argv) {
             const int grid = ((3 * tiles_f * L + 7) / 8) * 8;
             auto run = [&](auto tag) {
                 constexpr int VAR = decltype(tag)::value;
-                CK(hipFuncSetAttribute((const void*)qkv_ws_kernel<OpF16, VAR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds));
+                CK(hipFuncSetAttribute((const void*)qkv_ws_kernel<OpF16, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds));
                 const int reps = 20;
-                hipLaunchKernelGGL((qkv_ws_kernel<OpF16, VAR, false>), dim3(grid), dim3(512), kQwsLds, s, a, L);
+                hipLaunchKernelGGL((qkv_ws_kernel<OpF16, VAR>), dim3(grid), dim3(512), kQwsLds, s, a, L);
                 CK(hipEventRecord(e0, s));
-                for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((qkv_ws_kernel<OpF16, VAR, false>), dim3(grid), dim3(512), kQwsLds, s, a, L);
+                for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((qkv_ws_kernel<OpF16, VAR>), dim3(grid), dim3(512), kQwsLds, s, a, L);
                 CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipGetLastError());
                 printf("N %2d L %2d grid %3d (%.1f tiles per block) var %2d : %6.1f us\n", N, L, grid, (double)N * tiles_f / (tiles_f * L), VAR, ms * 1000 / reps);
@@ -67,8 +67,8 @@ int main(int argc, char** argv) {
         a.zeros = dz; a.sink = dsink;
         unsigned long long* dd; CK(hipMalloc(&dd, 64 * 2 * 8 * 8)); CK(hipMemset(dd, 0, 64 * 2 * 8 * 8)); a.dbg = dd;
         const int grid = ((3 * tiles_f * L + 7) / 8) * 8;
-        CK(hipFuncSetAttribute((const void*)qkv_ws_kernel<OpF16, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds));
-        hipLaunchKernelGGL((qkv_ws_kernel<OpF16, 64, false>), dim3(grid), dim3(512), kQwsLds, s, a, L);
+        CK(hipFuncSetAttribute((const void*)qkv_ws_kernel<OpF16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kQwsLds));
+        hipLaunchKernelGGL((qkv_ws_kernel<OpF16, 64>), dim3(grid), dim3(512), kQwsLds, s, a, L);
         CK(hipStreamSynchronize(s));
         std::vector<unsigned long long> hd(64 * 2 * 8); CK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
         const char* nm[8] = {"top wait", "barrier A", "DMA issue", "reads+MFMA", "epilogue", "barrier B", "stores", "prologue"};
