@@ -549,9 +549,9 @@ hipError_t launch_attn_bwd_dkv(int dtype, const AttnBwdArgs& a, hipStream_t s) {
 // one block per (item, head): thread (row group ty of 32, lane tx of 8) reads 16 bytes = head dims tx*8 .. +8 of row t,
 // four rows in flight; the 32 row-group partials are combined in a fixed order (deterministic)
 template <class P>
-__global__ __launch_bounds__(256) void attn_mean_nat_kernel(const typename P::elem* nat, int T, float* mean) {
+__device__ __forceinline__ void attn_mean_nat_body(const typename P::elem* nat, int T, float* mean, int nh) {
     __shared__ float part[32][64 + 1];
-    const int nh = blockIdx.x, tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const typename P::elem* base = nat + (size_t)nh * T * 64 + tx * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int t = ty;
@@ -581,6 +581,10 @@ __global__ __launch_bounds__(256) void attn_mean_nat_kernel(const typename P::el
         mean[(size_t)nh * 64 + threadIdx.x] = s / (float)T;
     }
 }
+template <class P>
+__global__ __launch_bounds__(256) void attn_mean_nat_kernel(const typename P::elem* nat, int T, float* mean) {
+    attn_mean_nat_body<P>(nat, T, mean, blockIdx.x);
+}
 
 hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, int T, float* mean, hipStream_t s) {
     if (dtype == DT_BF16) hipLaunchKernelGGL((attn_mean_nat_kernel<OpBF16>), dim3(n_heads_total), dim3(256), 0, s, (const __bf16*)nat, T, mean);
@@ -589,11 +593,11 @@ hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, i
 }
 
 template <class P>
-__global__ __launch_bounds__(256) void attn_to_T_kernel(const typename P::elem* nat, int64_t item_stride, int64_t head_stride,
-                                                        int row_stride, int H, int T, int Tp, const float* mean,
-                                                        typename P::elem* outT) {
+__device__ __forceinline__ void attn_to_T_body(const typename P::elem* nat, int64_t item_stride, int64_t head_stride,
+                                               int row_stride, int H, int T, int Tp, const float* mean,
+                                               typename P::elem* outT, int bx, int nh) {
     __shared__ typename P::elem tile[64][64 + 2];
-    const int p0 = blockIdx.x * 64, nh = blockIdx.y;
+    const int p0 = bx * 64;
     const int n = nh / H, h = nh % H;
     const typename P::elem* src = nat + (size_t)n * item_stride + (size_t)h * head_stride;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -611,6 +615,12 @@ __global__ __launch_bounds__(256) void attn_to_T_kernel(const typename P::elem* 
         outT[((size_t)nh * 64 + d) * Tp + p0 + c] = to16<P>(v);
     }
 }
+template <class P>
+__global__ __launch_bounds__(256) void attn_to_T_kernel(const typename P::elem* nat, int64_t item_stride, int64_t head_stride,
+                                                        int row_stride, int H, int T, int Tp, const float* mean,
+                                                        typename P::elem* outT) {
+    attn_to_T_body<P>(nat, item_stride, head_stride, row_stride, H, T, Tp, mean, outT, blockIdx.x, blockIdx.y);
+}
 
 hipError_t launch_attn_to_T(int dtype, const void* nat, int64_t item_stride, int64_t head_stride, int row_stride,
                             int n_items, int H, int T, int Tp, const float* mean, void* outT, hipStream_t s) {
@@ -622,9 +632,9 @@ hipError_t launch_attn_to_T(int dtype, const void* nat, int64_t item_stride, int
 
 // c[nh][d] = mean over the positions t < T of V[t][d]  (V^T in the T layout: the zero tail adds nothing)
 template <class P>
-__global__ __launch_bounds__(256) void attn_vmean_kernel(const typename P::elem* inT, int T, int Tp, float* vmean) {
+__device__ __forceinline__ void attn_vmean_body(const typename P::elem* inT, int T, int Tp, float* vmean, int nh) {
     // one block per (item, head); wave w handles head dims w, w+4, ...; lanes stride over the positions
-    const int nh = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int d = wave; d < 64; d += 4) {          // 16 bytes (8 positions) per lane and load; Tp is a multiple of 64
         const typename P::elem* row = inT + ((size_t)nh * 64 + d) * Tp;
         float v = 0.f;
@@ -637,13 +647,17 @@ __global__ __launch_bounds__(256) void attn_vmean_kernel(const typename P::elem*
         if (lane == 0) vmean[(size_t)nh * 64 + d] = v / (float)T;
     }
 }
+template <class P>
+__global__ __launch_bounds__(256) void attn_vmean_kernel(const typename P::elem* inT, int T, int Tp, float* vmean) {
+    attn_vmean_body<P>(inT, T, Tp, vmean, blockIdx.x);
+}
 
 // T layout -> natural rows, centred: nat[t][d] = V^T[d][perm(t)] - c[d]
 template <class P>
-__global__ __launch_bounds__(256) void attn_from_T_kernel(const typename P::elem* inT, int T, int Tp, const float* vmean,
-                                                          typename P::elem* nat, typename P::elem* nat_lo) {
+__device__ __forceinline__ void attn_from_T_body(const typename P::elem* inT, int T, int Tp, const float* vmean,
+                                                 typename P::elem* nat, typename P::elem* nat_lo, int bx, int nh) {
     __shared__ typename P::elem tile[64][64 + 2];
-    const int p0 = blockIdx.x * 64, nh = blockIdx.y;
+    const int p0 = bx * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int d = ty; d < 64; d += 4) tile[d][tx] = inT[((size_t)nh * 64 + d) * Tp + p0 + tx];      // column tx = position perm(tx)
     __syncthreads();
@@ -658,6 +672,43 @@ __global__ __launch_bounds__(256) void attn_from_T_kernel(const typename P::elem
             if (nat_lo) nat_lo[((size_t)nh * T + pos) * 64 + tx] = to16<P>(v - (float)hi16);
         }
     }
+}
+template <class P>
+__global__ __launch_bounds__(256) void attn_from_T_kernel(const typename P::elem* inT, int T, int Tp, const float* vmean,
+                                                          typename P::elem* nat, typename P::elem* nat_lo) {
+    attn_from_T_body<P>(inT, T, Tp, vmean, nat, nat_lo, blockIdx.x, blockIdx.y);
+}
+
+// The gradient-independent operand copies of one attention backward in TWO launches (were six): the three means (grid.y = q, k, v),
+// then the centred copies (grid.z = V back to natural rows as a hi + lo pair, Q^T, K^T).  Same bodies, same results.
+template <class P>
+__global__ __launch_bounds__(256) void attn_prep_means_kernel(const typename P::elem* q, const typename P::elem* k, const typename P::elem* vT,
+                                                              int T, int Tp, float* qmean, float* kmean, float* vmean) {
+    if (blockIdx.y == 0) attn_mean_nat_body<P>(q, T, qmean, blockIdx.x);
+    else if (blockIdx.y == 1) attn_mean_nat_body<P>(k, T, kmean, blockIdx.x);
+    else attn_vmean_body<P>(vT, T, Tp, vmean, blockIdx.x);
+}
+template <class P>
+__global__ __launch_bounds__(256) void attn_prep_copies_kernel(const typename P::elem* q, const typename P::elem* k, const typename P::elem* vT,
+                                                               int H, int T, int Tp, const float* qmean, const float* kmean, const float* vmean,
+                                                               typename P::elem* qT, typename P::elem* kT, typename P::elem* vnat, typename P::elem* vnat_lo) {
+    if (blockIdx.z == 0) attn_from_T_body<P>(vT, T, Tp, vmean, vnat, vnat_lo, blockIdx.x, blockIdx.y);
+    else if (blockIdx.z == 1) attn_to_T_body<P>(q, (int64_t)H * T * 64, (int64_t)T * 64, 64, H, T, Tp, qmean, qT, blockIdx.x, blockIdx.y);
+    else attn_to_T_body<P>(k, (int64_t)H * T * 64, (int64_t)T * 64, 64, H, T, Tp, kmean, kT, blockIdx.x, blockIdx.y);
+}
+hipError_t launch_attn_prep(int dtype, const void* q, const void* k, const void* vT, int n_items, int H, int T, int Tp, float* qmean, float* kmean,
+                            float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s) {
+    const dim3 g1(n_items * H, 3), g2(Tp / 64, n_items * H, 3);
+    if (dtype == DT_BF16) {
+        hipLaunchKernelGGL((attn_prep_means_kernel<OpBF16>), g1, dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vT, T, Tp, qmean, kmean, vmean);
+        hipLaunchKernelGGL((attn_prep_copies_kernel<OpBF16>), g2, dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vT, H, T, Tp, qmean, kmean, vmean,
+                           (__bf16*)qT, (__bf16*)kT, (__bf16*)vnat, (__bf16*)vnat_lo);
+    } else {
+        hipLaunchKernelGGL((attn_prep_means_kernel<OpF16>), g1, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)vT, T, Tp, qmean, kmean, vmean);
+        hipLaunchKernelGGL((attn_prep_copies_kernel<OpF16>), g2, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)vT, H, T, Tp, qmean, kmean, vmean,
+                           (_Float16*)qT, (_Float16*)kT, (_Float16*)vnat, (_Float16*)vnat_lo);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_attn_from_T(int dtype, const void* inT, int n_items, int H, int T, int Tp, float* vmean, void* nat, void* nat_lo,

@@ -1482,7 +1482,8 @@ int st_cfm_solve(st_engine* e, const float* mu, const float* mask, const float* 
             // The parts run the same kernel sequence; started together they tend to sit in the same kernel at the same time (FFN beside
             // FFN: two power-limited kernels sharing the CUs).  Part k starts 100 k us late -- about half a layer of a half batch: any
             // offset from 30 to 250 us measured +0.4 ... +0.6 % per solve, paired (profiles/r05_ab_part_phase.txt).
-            for (int k = 1; k < nparts; ++k) HIPCHK(e, launch_delay(kPartPhaseUs * k, parts[k].s));
+            // (Measured for TWO parts at the headline size only: other part counts -- ST_SPLIT=3, 4 -- start together.)
+            if (nparts == 2) HIPCHK(e, launch_delay(kPartPhaseUs, parts[1].s));
             for (int i = 0; i < n_steps; ++i)
                 for (auto& pt : parts)
                     if ((rc = step_fixed(pt, i, pt.s))) return rc;

@@ -357,18 +357,25 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
     HIPCHK(e, launch_time_embed(ts->tvals, B, C, ts->emb, s));
     HIPCHK(e, launch_linear(ts->emb, B, C, P(e, "time_mlp.layer.0.weight"), P(e, "time_mlp.layer.0.bias"), F, ts->th_pre, 0, 0, s));
     HIPCHK(e, launch_linear(ts->th_pre, B, F, P(e, "time_mlp.layer.2.weight"), P(e, "time_mlp.layer.2.bias"), C, ts->tau, 1, 0, s));
-    for (int i = 0; i < L; ++i) {
-        const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
-        HIPCHK(e, launch_linear(ts->tau, B, C, P(e, pf + "weight"), P(e, pf + "bias"), 2 * C, ts->film + (size_t)i * N * 2 * C, 0, 0, s));
-        const std::string pa = e->blk(i) + "adaLN_modulation.2.";
-        const float* ain = ts->cvec;       // adaLN_modulation = [Linear(gin, hidden) if gin != hidden else Identity, SiLU, Linear(hidden, 6 hidden)]
-        if (e->G != C) {                   // (diffusion_transformer.py:92-96)
-            const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
-            float* pre = ts->ada_pre + (size_t)i * N * C;
-            HIPCHK(e, launch_linear(ts->cvec, N, e->G, P(e, p0 + "weight"), P(e, p0 + "bias"), C, pre, 0, 0, s));
-            ain = pre;
+    // FiLM (gamma, beta) and adaLN modulation of every block: per-item vectors, one launch per family and 8 blocks (were 2 L launches)
+    for (int i0 = 0; i0 < L; i0 += 8) {
+        LinearJobs jf; memset(&jf, 0, sizeof(jf));
+        LinearJobs ja; memset(&ja, 0, sizeof(ja));
+        for (int i = i0; i < std::min(L, i0 + 8); ++i) {
+            const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
+            jf.in[jf.n] = ts->tau; jf.W[jf.n] = P(e, pf + "weight"); jf.bias[jf.n] = P(e, pf + "bias"); jf.out[jf.n] = ts->film + (size_t)i * N * 2 * C; jf.n += 1;
+            const std::string pa = e->blk(i) + "adaLN_modulation.2.";
+            const float* ain = ts->cvec;       // adaLN_modulation = [Linear(gin, hidden) if gin != hidden else Identity, SiLU, Linear(hidden, 6 hidden)]
+            if (e->G != C) {                   // (diffusion_transformer.py:92-96)
+                const std::string p0 = e->blk(i) + "adaLN_modulation.0.";
+                float* pre = ts->ada_pre + (size_t)i * N * C;
+                HIPCHK(e, launch_linear(ts->cvec, N, e->G, P(e, p0 + "weight"), P(e, p0 + "bias"), C, pre, 0, 0, s));
+                ain = pre;
+            }
+            ja.in[ja.n] = ain; ja.W[ja.n] = P(e, pa + "weight"); ja.bias[ja.n] = P(e, pa + "bias"); ja.out[ja.n] = ts->ada + (size_t)i * N * 6 * C; ja.n += 1;
         }
-        HIPCHK(e, launch_linear(ain, N, C, P(e, pa + "weight"), P(e, pa + "bias"), 6 * C, ts->ada + (size_t)i * N * 6 * C, 1, 0, s));
+        HIPCHK(e, launch_linear_multi(jf, B, C, 2 * C, 0, 0, s));
+        HIPCHK(e, launch_linear_multi(ja, N, C, 6 * C, 1, 0, s));
     }
     const DropCfg nodrop = make_drop(0.f, 0, 0);
     if (make_drop(p_dropout, seed, 1).thresh16) {      // the hash tables of all L attention sites, once: forward and backward read them
@@ -671,11 +678,7 @@ int bwd_head(st_engine* e, TrainState* ts, const float* grad_out, hipStream_t s)
 int attn_prep(st_engine* e, TrainState* ts, int i, hipStream_t s) {
     const int H = e->H, N = ts->B, T = ts->T, Tp = ts->Tp;
     LayerAct& A = ts->L[i];
-    HIPCHK(e, launch_attn_from_T(e->dt, A.vt, N, H, T, Tp, ts->vmean, ts->vnat, ts->vnat_lo, s));
-    HIPCHK(e, launch_attn_mean_nat(e->dt, A.q, N * H, T, ts->qmean, s));
-    HIPCHK(e, launch_attn_mean_nat(e->dt, A.k, N * H, T, ts->kmean, s));
-    HIPCHK(e, launch_attn_to_T(e->dt, A.q, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->qmean, ts->qT, s));
-    HIPCHK(e, launch_attn_to_T(e->dt, A.k, (int64_t)H * T * 64, (int64_t)T * 64, 64, N, H, T, Tp, ts->kmean, ts->kT, s));
+    HIPCHK(e, launch_attn_prep(e->dt, A.q, A.k, A.vt, N, H, T, Tp, ts->qmean, ts->kmean, ts->vmean, ts->qT, ts->kT, ts->vnat, ts->vnat_lo, s));
     return ST_OK;
 }
 
@@ -812,6 +815,7 @@ int bwd_block(st_engine* e, TrainState* ts, int i, hipStream_t s) {
     {   // this block's per-item linears: adaLN modulation (-> d c), FiLM (-> d tau); its d ada / d film rows are complete now.
         // Every weight / bias gradient here has ONE producer (written, not accumulated: no zero fills); d c and d tau add up over
         // the blocks: the first block of a backward (L - 1) writes them, the others accumulate.
+        if (e->G == C) return ST_OK;      // the usual case: the linears of all blocks of a backward part run batched at its end (bwd_linears)
         const int acc = i == L - 1 ? 0 : 1;
         const std::string pa = e->blk(i) + "adaLN_modulation.2.";
         float* gw = G(ts, pa + "weight"); float* gb = G(ts, pa + "bias");
@@ -833,6 +837,31 @@ int bwd_block(st_engine* e, TrainState* ts, int i, hipStream_t s) {
         const float* dfo = ts->dfilm + (size_t)i * N * 2 * C;
         HIPCHK(e, launch_linear_bwd_w(ts->tau, dfo, N, C, 2 * C, 0, gw, gb, 0, s));
         HIPCHK(e, launch_linear_bwd_in(ts->tau, dfo, P(e, pf + "weight"), N, C, 2 * C, 0, ts->dtau, acc, s));
+    }
+    return ST_OK;
+}
+
+// The per-item linears (adaLN modulation -> d c, FiLM -> d tau) of blocks [lo, hi) in four launches: every block's d ada / d film rows
+// are complete when its backward part ends.  `acc`: add to d c / d tau (the first part of a backward writes them).
+int bwd_linears(st_engine* e, TrainState* ts, int lo, int hi, int acc, hipStream_t s) {
+    const int C = e->C, N = ts->B;
+    if (e->G != C) return ST_OK;          // (handled per block)
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        LinBwdJobs ja; memset(&ja, 0, sizeof(ja));
+        LinBwdJobs jf; memset(&jf, 0, sizeof(jf));
+        for (int i = i0; i < std::min(hi, i0 + 8); ++i) {
+            const std::string pa = e->blk(i) + "adaLN_modulation.2.";
+            ja.in[ja.n] = ts->cvec; ja.dout[ja.n] = ts->dada + (size_t)i * N * 6 * C; ja.W[ja.n] = P(e, pa + "weight");
+            ja.dW[ja.n] = G(ts, pa + "weight"); ja.db[ja.n] = G(ts, pa + "bias"); ja.n += 1;
+            const std::string pf = "blocks." + std::to_string(i) + ".time_fusion.film.";
+            jf.in[jf.n] = ts->tau; jf.dout[jf.n] = ts->dfilm + (size_t)i * N * 2 * C; jf.W[jf.n] = P(e, pf + "weight");
+            jf.dW[jf.n] = G(ts, pf + "weight"); jf.db[jf.n] = G(ts, pf + "bias"); jf.n += 1;
+        }
+        const int a = (acc || i0 > lo) ? 1 : 0;
+        HIPCHK(e, launch_linear_bwd_w_multi(ja, N, C, 6 * C, 1, s));
+        HIPCHK(e, launch_linear_bwd_in_multi(ja, ts->cvec, N, C, 6 * C, 1, ts->dcvec, a, s));
+        HIPCHK(e, launch_linear_bwd_w_multi(jf, N, C, 2 * C, 0, s));
+        HIPCHK(e, launch_linear_bwd_in_multi(jf, ts->tau, N, C, 2 * C, 0, ts->dtau, a, s));
     }
     return ST_OK;
 }
@@ -905,8 +934,10 @@ int bwd_part(st_engine* e, TrainState* ts, int part, const float* grad_out, floa
     if (part == 0) {
         if ((rc = bwd_head(e, ts, grad_out, s))) return rc;
         for (int i = L - 1; i >= L / 2; --i) if ((rc = bwd_block(e, ts, i, s))) return rc;
+        if ((rc = bwd_linears(e, ts, L / 2, L, 0, s))) return rc;
     } else if (part == 1) {
         for (int i = L / 2 - 1; i >= 0; --i) if ((rc = bwd_block(e, ts, i, s))) return rc;
+        if ((rc = bwd_linears(e, ts, 0, L / 2, 1, s))) return rc;
     } else {
         if ((rc = bwd_tail(e, ts, grad_x, grad_mu, grad_c, s))) return rc;
     }

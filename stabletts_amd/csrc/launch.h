@@ -150,6 +150,8 @@ hipError_t launch_film_ln(int dtype, const FilmLnArgs& a, hipStream_t s);
 hipError_t launch_time_embed(const float* t, int n_t, int dim, float* emb, hipStream_t s);
 // out[n][o] = act_out(bias[o] + sum_i W[o][i] * act_in(in[n][i]))
 hipError_t launch_silu_rows(const float* in, int64_t n, float* out, hipStream_t s);      // out = SiLU(in), fp32
+struct LinearJobs { const float* in[8]; const float* W[8]; const float* bias[8]; float* out[8]; int n; };
+hipError_t launch_linear_multi(const LinearJobs& J, int n, int k, int o, int silu_in, int silu_out, hipStream_t s);
 hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
                          float* out, int silu_in, int silu_out, hipStream_t s);
 // t_lim (optional, B + 1 ints): t_lim[b] = min(T, kv_end[b] + kFrameHalo), t_lim[B] = max over the rows

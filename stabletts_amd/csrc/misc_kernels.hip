@@ -105,6 +105,36 @@ hipError_t launch_silu_rows(const float* in, int64_t n, float* out, hipStream_t 
     return hipGetLastError();
 }
 
+// the same layer shape for up to 8 (weight, bias, output[, input]) sets in ONE launch (grid.y = set): the six FiLM linears of a training
+// forward share their input tau, the six adaLN modulation linears c -- were 12 launches of ~10 us
+__global__ __launch_bounds__(256) void linear_multi_kernel(LinearJobs J, int n, int k, int o, int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)n * o) return;
+    const int ni = (int)(wid / o), oi = (int)(wid - (long long)ni * o);
+    const float* x = J.in[blockIdx.y] + (size_t)ni * k;
+    const float* w = J.W[blockIdx.y] + (size_t)oi * k;
+    float acc = 0.f;
+    for (int i = lane * 4; i < k; i += 256) {
+        float4 xv = *(const float4*)(x + i);
+        const float4 wv = *(const float4*)(w + i);
+        if (silu_in) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
+        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + (J.bias[blockIdx.y] ? J.bias[blockIdx.y][oi] : 0.f);
+        if (silu_out) v = silu_f(v);
+        J.out[blockIdx.y][(size_t)ni * o + oi] = v;
+    }
+}
+hipError_t launch_linear_multi(const LinearJobs& J, int n, int k, int o, int silu_in, int silu_out, hipStream_t s) {
+    if (J.n < 1 || J.n > 8 || (k & 3)) return hipErrorInvalidValue;
+    const long long waves = (long long)n * o;
+    hipLaunchKernelGGL(linear_multi_kernel, dim3((unsigned)((waves + 3) / 4), J.n), dim3(256), 0, s, J, n, k, o, silu_in, silu_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear(const float* in, int n, int k, const float* W, const float* bias, int o,
                          float* out, int silu_in, int silu_out, hipStream_t s) {
     const long long waves = (long long)n * o;
@@ -245,12 +275,22 @@ __global__ void set_values_kernel(float* dst, int n, SetValuesArgs a) {
 // host values -> device array through kernel arguments (64 per launch): the evaluation times of a solve
 // holds its stream for about `us` microseconds (one wave sleeping; 100-MHz constant-rate counter): the phase offset between the
 // launch sequences of a multi-part solve (engine.cpp)
-__global__ void delay_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+__global__ void delay_kernel(unsigned long long ticks, int max_iters) {
+    // s_memrealtime counts the constant-rate wall clock (hipDeviceAttributeWallClockRate, 100 MHz on MI355X); the iteration cap bounds the
+    // wait should the rate be different on another ASIC / driver setting (s_sleep 16 = 1024 cycles: <= ~1 us per iteration at any clock)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < max_iters && __builtin_amdgcn_s_memrealtime() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
 }
 hipError_t launch_delay(int us, hipStream_t s) {
-    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)us * 100ull);
+    static int khz[64] = {};      // wall-clock rate per device, queried once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!khz[dev]) {
+        int r = 0;
+        if (hipDeviceGetAttribute(&r, hipDeviceAttributeWallClockRate, dev) != hipSuccess || r <= 0) { (void)hipGetLastError(); r = 100000; }
+        khz[dev] = r;
+    }
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)us * (unsigned long long)khz[dev] / 1000ull, 4 * us + 64);
     return hipGetLastError();
 }
 

@@ -896,6 +896,80 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* in, cons
     }
 }
 
+// Several layers of one shape in ONE launch (grid.z = layer): dW_j / db_j written (not accumulated).
+__global__ __launch_bounds__(256) void linear_bwd_w_multi_kernel(LinBwdJobs J, int n, int k, int o, int silu_in) {
+    __shared__ float red[4][16][64];
+    const float* in = J.in[blockIdx.z]; const float* dout = J.dout[blockIdx.z];
+    float* dW = J.dW[blockIdx.z]; float* db = J.db[blockIdx.z];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int ki = blockIdx.x * 64 + tx, o0 = blockIdx.y * 8;
+    float acc[8], accb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[j] = 0.f; accb[j] = 0.f; }
+    const bool full = o0 + 8 <= o && (o & 3) == 0;
+    if (ki < k) {
+#pragma unroll 4
+        for (int ni = g; ni < n; ni += 4) {
+            float x = in[(size_t)ni * k + ki];
+            if (silu_in) x = silu_f(x);
+            float d[8];
+            if (full) {
+                const float4 d0 = *(const float4*)(dout + (size_t)ni * o + o0), d1 = *(const float4*)(dout + (size_t)ni * o + o0 + 4);
+                d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = o0 + j < o ? dout[(size_t)ni * o + o0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[j] += d[j] * x; accb[j] += d[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[g][j][tx] = acc[j]; red[g][8 + j][tx] = accb[j]; }
+    __syncthreads();
+    if (ki >= k) return;
+    for (int j = g; j < 8; j += 4) {
+        if (o0 + j >= o) continue;
+        dW[(size_t)(o0 + j) * k + ki] = ((red[0][j][tx] + red[1][j][tx]) + red[2][j][tx]) + red[3][j][tx];
+        if (ki == 0 && db) db[o0 + j] = ((red[0][8 + j][0] + red[1][8 + j][0]) + red[2][8 + j][0]) + red[3][8 + j][0];
+    }
+}
+hipError_t launch_linear_bwd_w_multi(const LinBwdJobs& J, int n, int k, int o, int silu_in, hipStream_t s) {
+    if (J.n < 1 || J.n > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(linear_bwd_w_multi_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((o + 7) / 8), J.n), dim3(256), 0, s, J, n, k, o, silu_in);
+    return hipGetLastError();
+}
+// din[n][k] (+)= act'(in[n][k]) * sum_j sum_o dout_j[n][o] * W_j[o][k] over the J.n layers (they share the input `in`): one launch,
+// layers summed in order inside each thread group (deterministic)
+__global__ __launch_bounds__(1024) void linear_bwd_in_multi_kernel(LinBwdJobs J, const float* in, int n, int k, int o, int silu_in, float* din, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ni = blockIdx.y, ki = blockIdx.x * 64 + tx;
+    float acc = 0.f;
+    if (ki < k) {
+        for (int j = 0; j < J.n; ++j) {
+            const float* dout = J.dout[j]; const float* W = J.W[j];
+#pragma unroll 8
+            for (int oi = ty; oi < o; oi += 16) acc += dout[(size_t)ni * o + oi] * W[(size_t)oi * k + ki];
+        }
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && ki < k) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][tx];
+        const size_t idx = (size_t)ni * k + ki;
+        if (silu_in) t *= silu_grad(in[idx]);
+        din[idx] = accumulate ? din[idx] + t : t;
+    }
+}
+hipError_t launch_linear_bwd_in_multi(const LinBwdJobs& J, const float* in, int n, int k, int o, int silu_in, float* din, int accumulate, hipStream_t s) {
+    if (J.n < 1 || J.n > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(linear_bwd_in_multi_kernel, dim3((k + 63) / 64, n), dim3(1024), 0, s, J, in, n, k, o, silu_in, din, accumulate);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k, int o, int silu_in, float* dW, float* db,
                                int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)((o + 7) / 8)), dim3(256), 0, s, in, dout, n, k, o, silu_in, dW, db, accumulate);

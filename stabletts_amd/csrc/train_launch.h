@@ -128,6 +128,10 @@ hipError_t launch_pack_weight_t(int dtype, const float* src, int cout, int cin_t
 
 // ---------------------------------------------------------------- small fp32 linears (adaLN, FiLM, time MLP): backward
 // out = W act(in) + b:  dW[o][k] (+)= sum_n dout[n][o] act(in[n][k]);  db[o] (+)= sum_n dout[n][o]
+// several layers of one shape per launch (the per-item linears of the blocks of one backward part)
+struct LinBwdJobs { const float* in[8]; const float* dout[8]; const float* W[8]; float* dW[8]; float* db[8]; int n; };
+hipError_t launch_linear_bwd_w_multi(const LinBwdJobs& J, int n, int k, int o, int silu_in, hipStream_t s);
+hipError_t launch_linear_bwd_in_multi(const LinBwdJobs& J, const float* in, int n, int k, int o, int silu_in, float* din, int accumulate, hipStream_t s);
 hipError_t launch_linear_bwd_w(const float* in, const float* dout, int n, int k, int o, int silu_in, float* dW, float* db,
                                int accumulate, hipStream_t s);
 // din[n][k] (+)= (sum_o dout[n][o] W[o][k]) * act'(in[n][k])
@@ -147,6 +151,9 @@ hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, i
 // natural copy of a T-layout tensor, CENTRED when vmean != nullptr: vmean[item][H][64] = mean over the positions is
 // computed first and subtracted (attention_bwd.hip, "Precision")
 // nat_lo (optional): 16-bit rounding residual of the centred values (hi + lo operand pair)
+// the three means + the three centred copies of one attention backward in two launches (same bodies as the single launches below)
+hipError_t launch_attn_prep(int dtype, const void* q, const void* k, const void* vT, int n_items, int H, int T, int Tp, float* qmean, float* kmean,
+                            float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s);
 hipError_t launch_attn_from_T(int dtype, const void* inT, int n_items, int H, int T, int Tp, float* vmean, void* nat, void* nat_lo,
                               hipStream_t s);
 struct AttnBwdArgs {
