@@ -39,6 +39,15 @@
 #include "common.h"
 #include "train_launch.h"
 
+#if defined(ST_ABL_NO_VLO) && !defined(ST_DEVTOOLS)
+#error "ST_ABL_NO_VLO (ablation build: V' enters dP as ONE 16-bit operand) needs -DST_DEVTOOLS"
+#endif
+#ifdef ST_ABL_NO_VLO
+constexpr bool kNoVlo = true;
+#else
+constexpr bool kNoVlo = false;
+#endif
+
 namespace st {
 
 namespace {
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
             for (int ks = 0; ks < 4; ++ks) {
                 s[kb] = P::mfma(frag<P>(Ks + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), qf[ks], s[kb]);
                 dp[kb] = P::mfma(frag<P>(Vs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
-                dp[kb] = P::mfma(frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
+                if constexpr (!kNoVlo) dp[kb] = P::mfma(frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
             }
             if constexpr (PASS == 1) { __builtin_amdgcn_sched_barrier(0); elems(kb); __builtin_amdgcn_sched_barrier(0); }   // one key block live at a time: 128 VGPRs
         }
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
             for (int ks = 0; ks < 4; ++ks) {
                 s[qb] = P::mfma(frag<P>(Qs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), kf[ks], s[qb]);
                 dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vf[ks], dp[qb]);
-                dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vlf[ks], dp[qb]);
+                if constexpr (!kNoVlo) dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vlf[ks], dp[qb]);
             }
         }
         vec8 pdf[4], dsf[4];

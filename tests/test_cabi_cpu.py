@@ -239,3 +239,16 @@ def test_micro_benchmarks_still_compile_against_the_kernel_headers():
     srcs = [os.path.join(ROOT, "tools", "micro", f) for f in ("ffn_bench.hip", "qkv_bench.hip", "ffn_wino_bench.hip")]
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-unused-value", *srcs], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_design_md_numbers_come_from_the_committed_evidence():
+    """DESIGN.md is docs/DESIGN.template.md with its tokens filled from profiles/r06_* by tools/fill_design.py: the end-state figures
+    in the design document cannot drift from the committed bench lines / rocprofv3 summaries."""
+    import subprocess
+    import sys
+    before = open(os.path.join(ROOT, "DESIGN.md")).read()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fill_design.py")], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    after = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert after == before, "DESIGN.md is stale: run python tools/fill_design.py"
+    assert len(after.splitlines()) <= 400 and "\u27e8" not in after.encode("unicode_escape").decode()
