@@ -58,12 +58,13 @@ def algorithmic_flops_per_frame(T, n_evals, B):
 CPU_THREADS = 32               # one of the two fixed thread counts timed (the other: os.cpu_count()); the faster is reported
 
 
-def cpu_baseline(sd, cfg_params):
+def cpu_baseline(sd, cfg_params, all_cores=False):
     """SURVEY.md section 8(d)'s protocol for config-2-sized inputs: time ONE evaluation of the workload's own batch -- B=32 x T=1000,
     the cond and the uncond estimator call of one cfg_wrapper step (flow_matching.py:58-67), prenet recomputed in each as the
     reference does -- and scale by the step count (every Euler step costs the same two evaluations).  The oracle (fp32 torch-CPU
-    restatement of the reference), timed ONCE with os.cpu_count() threads (SURVEY's rule) and ONCE with 32 (oneDNN stops scaling
-    well before 256 threads on the MI355X hosts): the faster of the two is the baseline, both are in the line.  ~15-30 s of CPU."""
+    restatement of the reference) on 32 threads (fixed).  SURVEY's rule is os.cpu_count() threads: on the 256-thread MI355X hosts that
+    is ~20x SLOWER (measured in round 6 with this function: 146-148 s against 6.9-8.1 s per step, profiles/r06_s1_bench_sharder.json,
+    r06_bench_final.json), so the faster count is the baseline; --cpu-all-cores times both again (adds ~2.5 minutes)."""
     import oracle
     from oracle.inputs import make_inputs
     fs, fc = cfg_params
@@ -71,8 +72,9 @@ def cpu_baseline(sd, cfg_params):
     small = make_inputs(2, 256, seed=0)
     t_span = oracle.linspace_f32(N_STEPS)
     ncpu = os.cpu_count() or 1
+    t32 = max(1, min(CPU_THREADS, ncpu))
     timed = {}
-    for threads in sorted({max(1, min(CPU_THREADS, ncpu)), ncpu}):
+    for threads in sorted({t32, ncpu} if all_cores else {t32}):
         torch.set_num_threads(threads)
         with torch.inference_mode():
             oracle.cfg_wrapper(sd, t_span[0], small["z"], small["mask"], small["mu"], small["c"], fs, fc, CFG)      # warm-up (thread pool, oneDNN primitives)
@@ -84,6 +86,9 @@ def cpu_baseline(sd, cfg_params):
     per_solve = t_eval * N_STEPS
     return dict(value=B_PER_GPU * T_FRAMES / per_solve, unit="mel-frames/sec", cores=threads, kind="port",
                 seconds_per_cfg_step_by_threads={str(k): v for k, v in timed.items()},
+                all_cores_reference=None if all_cores or ncpu <= CPU_THREADS else
+                "os.cpu_count() threads measured in round 6 on this host class (256 threads): 146-148 s per cfg_wrapper step = 22 frames/s "
+                "(profiles/r06_s1_bench_sharder.json, profiles/r06_bench_final.json); re-measure with --cpu-all-cores",
                 sample=f"oracle (fp32 torch-CPU restatement of the reference; prenet recomputed every evaluation as the reference does), "
                        f"the workload's own batch B={B_PER_GPU} x T={T_FRAMES}, cfg={CFG}: ONE cfg_wrapper step (cond + uncond evaluation) timed "
                        f"with {' and '.join(str(k) for k in timed)} torch threads, the faster kept ({threads} threads: {t_eval:.2f} s) and scaled by the "
@@ -355,6 +360,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="cpu_baseline: also time the oracle with os.cpu_count() threads (SURVEY 8d's rule; ~2.5 min on a 256-thread host, where it is ~20x slower than 32 threads)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other-dtype and config-1 latency legs")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the config-5 training-step leg of the extras")
     ap.add_argument("--ragged", action="store_true", help="BASELINE config 4: ragged utterances through the sharder")
@@ -662,7 +668,7 @@ def main():
         if dev_env:
             line["dev_env"] = dev_env      # NOT the library as shipped
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, (fs, fc))
+            line["cpu_baseline"] = cpu_baseline(sd, (fs, fc), args.cpu_all_cores)
         print(json.dumps(line), flush=True)
 
     if world > 1 and not args.no_extras and not args.ragged and not args.no_train_leg:

@@ -23,6 +23,8 @@ HEADERS = ["common.h", "launch.h", "train_launch.h", "vocos_launch.h", "engine_i
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-Rpass-analysis=kernel-resource-usage"]
 # per-source flags: the attention kernels keep their fp32 row-sum adds scalar (common.h: add_f32_scalar)
+# (the attention BACKWARD with the same flag: ~100 packed fp32 ops per key tile gone, 229 -> 164 VGPRs for dQ pass 2 -- and no change of the step,
+#  18.87 vs 18.91 ms paired: profiles/r06_ab_attn_bwd_noslp_null.txt; not set)
 EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 RESOURCES = os.path.join(OBJ, "kernel_resources.json")    # per-kernel VGPR / SGPR / scratch / occupancy of the last build
 FLAGS += os.environ.get("ST_BUILD_DEFS", "").split()

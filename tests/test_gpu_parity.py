@@ -157,6 +157,22 @@ def test_config3_at_size_long_ode(decoders, sd, cfg_params, solver, n):
         assert _disp(got, ref, sub["z"]) <= DISP_TOL[dt], dt
 
 
+def test_config3_at_the_benchmarked_batch(decoders, sd, cfg_params):
+    """BASELINE config 3 exactly as `bench.py --n-timesteps 50` runs it -- B = 32 x T = 1000 (all-ones mask), CFG 3.0, n = 50 Euler, the
+    default two-part solve on the big-grid kernels -- f16 operands: the first and the last utterance against the oracle run on those
+    two alone (utterances are independent; 100 oracle evaluations of a 2-row batch).  Gates as for the B = 8 case."""
+    inp = make_inputs(32, 1000, seed=0)
+    rows = [0, 31]
+    sub = {k: v[rows] for k, v in inp.items() if k != "lengths"}
+    ref = oracle.cfm_forward(sd, sub["mu"], sub["mask"], 50, sub["z"], sub["c"], "euler", _cfg(cfg_params, 3.0, False))
+    out = _solve(decoders["f16"], inp, 50, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
+    assert torch.isfinite(out).all()
+    got = out[rows]
+    mel, disp = _rel(got, ref), _disp(got, ref, sub["z"])
+    print(f"config 3 at B=32 x T=1000, n=50 euler, f16: mel {mel:.2e}, displacement {disp:.2e}")
+    assert mel <= MEL_TOL and disp <= DISP_TOL["f16"]
+
+
 # ---------------------------------------------------------------- full-size (BASELINE config 2) properties
 @pytest.fixture(scope="module")
 def c2(decoders, cfg_params):

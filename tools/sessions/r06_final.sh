@@ -4,7 +4,7 @@
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 timeout 3000 python -m pytest tests -q -m gpu -s 2>&1 | grep -v "amdgpu.ids" | tail -150 > $OUT/r06_pytest_gpu_final.log; tail -3 $OUT/r06_pytest_gpu_final.log
 timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -8 > $OUT/r06_smoke_final.log; cat $OUT/r06_smoke_final.log
-timeout 900 python bench.py --steps 20 --warmup 3 2>$OUT/r06_bench_final.err | tail -1 > $OUT/r06_bench_final.json; cut -c1-300 $OUT/r06_bench_final.json
+timeout 900 python bench.py --steps 20 --warmup 3 --cpu-all-cores 2>$OUT/r06_bench_final.err | tail -1 > $OUT/r06_bench_final.json; cut -c1-300 $OUT/r06_bench_final.json
 timeout 600 python bench.py --ragged --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 > $OUT/r06_bench_ragged_final.json; cut -c1-200 $OUT/r06_bench_ragged_final.json
 timeout 300 python bench.py --n-timesteps 50 --steps 4 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | tail -1 > $OUT/r06_bench_config3_final.json; cut -c1-200 $OUT/r06_bench_config3_final.json
 BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline 2>$OUT/r06_bench_2ranks.err | tail -1 > $OUT/r06_bench_2ranks_shared_gpu.json; cut -c1-200 $OUT/r06_bench_2ranks_shared_gpu.json
