@@ -221,6 +221,8 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
         if (qok) { D_q = a.Dq[(size_t)nh * T + query]; F_q = a.Fq[(size_t)nh * T + query]; alpha = a.alphaq[(size_t)nh * T + query]; }
     }
 
+    const float a_al = a_q * alpha;                                          // (second pass only: alpha, D', F are final there)
+    const float D2_al = (dropping ? D_q + a_q * F_q : D_q) * alpha;
     if (ntiles > 0) issue(0, 0);
     ST_DMA_WAIT(0);
     __syncthreads();
@@ -253,10 +255,13 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
                         Dacc += p * f * dp[kb][r]; Facc += p * f;
                         mxpd = fmaxf(mxpd, fabsf(p * f * dp[kb][r])); mxp = fmaxf(mxp, p);
                     } else {
-                        float ds = p * (f * dp[kb][r] - D_q);
-                        if (dropping) ds += p * a_q * (f - F_q);
+                        // alpha dS = p f (dP' + a) alpha - p (D' + a F) alpha  (= alpha [p (f dP' - D') + p a (f - F)], the per-query constants folded
+                        // once per lane: 5 instead of 7 vector instructions per element; rs accumulates the SCALED values)
+                        float ds;
+                        if (dropping) ds = (p * f) * fmaf(dp[kb][r], alpha, a_al) - p * D2_al;
+                        else ds = p * fmaf(dp[kb][r], alpha, -D2_al);
                         rs += ds;
-                        dsf[kb * 2 + (r >> 3)][r & 7] = to16<P>(ds * alpha);
+                        dsf[kb * 2 + (r >> 3)][r & 7] = to16<P>(ds);
                     }
                 }
             }
@@ -265,11 +270,37 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
+            if constexpr (PASS == 2) {
+                // Second pass (229 VGPRs of 256): the fragment reads of two k-steps are issued as ONE batch in front of their six MFMAs --
+                // left to itself hipcc emits read -> s_waitcnt lgkmcnt(0) -> MFMA, an exposed LDS round trip per MFMA with two waves per
+                // SIMD to hide it.  Same MFMAs in the same order: bit-identical.  (The first pass has 128 registers and the dK/dV kernel
+                // 250: the same batching spills there.)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    vec8 fk[2], fv[2], fl[2];
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int ks = kh * 2 + k2;
+                        fk[k2] = frag<P>(Ks + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi);
+                        fv[k2] = frag<P>(Vs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi);
+                        if constexpr (!kNoVlo) fl[k2] = frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int ks = kh * 2 + k2;
+                        s[kb] = P::mfma(fk[k2], qf[ks], s[kb]);
+                        dp[kb] = P::mfma(fv[k2], dof[ks], dp[kb]);
+                        if constexpr (!kNoVlo) dp[kb] = P::mfma(fl[k2], dof[ks], dp[kb]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 s[kb] = P::mfma(frag<P>(Ks + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), qf[ks], s[kb]);
                 dp[kb] = P::mfma(frag<P>(Vs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
                 if constexpr (!kNoVlo) dp[kb] = P::mfma(frag<P>(VLs + buf * kTile, row_off[kb], swz[kb], ks * 2 + hi), dof[ks], dp[kb]);
+            }
             }
             if constexpr (PASS == 1) { __builtin_amdgcn_sched_barrier(0); elems(kb); __builtin_amdgcn_sched_barrier(0); }   // one key block live at a time: 128 VGPRs
         }
@@ -293,10 +324,14 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
             }
         } else {
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d) {
+                vec8 ft[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    o[d] = P::mfma(frag<P>(KTs + buf * kTile, row_off[d], swz[d], g * 2 + hi), dsf[g], o[d]);
+                for (int g = 0; g < 4; ++g) ft[g] = frag<P>(KTs + buf * kTile, row_off[d], swz[d], g * 2 + hi);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) o[d] = P::mfma(ft[g], dsf[g], o[d]);
+            }
         }
         ST_DMA_WAIT(0);
         __syncthreads();
@@ -309,8 +344,8 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
         return;
     }
     {   // undo the operand scale; K^T was centred: add kmean[d] * sum_k dS back (fp32)
-        rs = xor32_sum(rs);
         const float inv_alpha = 1.0f / alpha;
+        rs = xor32_sum(rs) * inv_alpha;        // (the row sum was accumulated in scaled units; alpha is a power of two)
         const float* km = a.kmean + (size_t)nh * 64;
 #pragma unroll
         for (int d2 = 0; d2 < 2; ++d2)
@@ -410,10 +445,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
         }
         if (wave == 0) {
             const int qq = qt * 64 + lane;
+            // per-query constants, folded with this (item, head)'s operand scale: D_t = (D' + a F) alpha (no dropout: D' alpha), a_t = a alpha
+            const float Dv = qq < T ? a.Dq[(size_t)nh * T + qq] : 0.f, Fv = qq < T ? a.Fq[(size_t)nh * T + qq] : 1.f, av_ = qq < T ? a.aq[(size_t)nh * T + qq] : 0.f;
             lse_t[buf * 64 + lane] = qq < T ? a.lse[(size_t)nh * T + qq] : 0.f;
-            D_t[buf * 64 + lane] = qq < T ? a.Dq[(size_t)nh * T + qq] : 0.f;
-            F_t[buf * 64 + lane] = qq < T ? a.Fq[(size_t)nh * T + qq] : 1.f;
-            a_t[buf * 64 + lane] = qq < T ? a.aq[(size_t)nh * T + qq] : 0.f;
+            D_t[buf * 64 + lane] = (dropping ? Dv + av_ * Fv : Dv) * alpha;
+            a_t[buf * 64 + lane] = av_ * alpha;
             if (DROP) rh_t[buf * 64 + lane] = a.drop.rowh[(size_t)nh * T + (qq < T ? qq : T - 1)];
         }
     };
@@ -434,29 +470,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
     for (int qt = 0; qt < nq; ++qt) {
         const int buf = qt & 1;
         if (qt + 1 < nq) issue(qt + 1, buf ^ 1);
-        f32x16_t s[2], dp[2];
+        // One 32-query half of the tile at a time, start to finish (round 6): S and dP of the half, its element-wise step, and the dV / dK
+        // MFMAs whose k-slots are those 32 queries.  Only one half's S / dP accumulators and P / dS operands are live (48 registers fewer
+        // than with both halves in flight: 250 -> ~200 VGPRs), which is what leaves room to issue a half's fragment reads as batches in
+        // front of their MFMAs instead of hipcc's read -> wait -> MFMA chain.  Every accumulator still sees its MFMAs in the same order
+        // (dv[d] / dk[d]: g = 0, 1, 2, 3): bit-identical to the two-halves-at-once form.
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[qb][r] = 0.f; dp[qb][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            {
+                vec8 fq[4], fo[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s[qb] = P::mfma(frag<P>(Qs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), kf[ks], s[qb]);
-                dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vf[ks], dp[qb]);
-                if constexpr (!kNoVlo) dp[qb] = P::mfma(frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi), vlf[ks], dp[qb]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    fq[ks] = frag<P>(Qs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi);
+                    fo[ks] = frag<P>(dOs + buf * kTile, row_off[qb], swz[qb], ks * 2 + hi);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = P::mfma(fq[ks], kf[ks], s);
+                    dp = P::mfma(fo[ks], vf[ks], dp);
+                    if constexpr (!kNoVlo) dp = P::mfma(fo[ks], vlf[ks], dp);
+                }
             }
-        }
-        vec8 pdf[4], dsf[4];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            vec8 pdf[2], dsf[2];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const float4 lz = *(const float4*)(lse_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                 const float4 dz = *(const float4*)(D_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
-                const float4 fz = *(const float4*)(F_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                 const float4 az = *(const float4*)(a_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                 const float lv[4] = {lz.x, lz.y, lz.z, lz.w}, dvv[4] = {dz.x, dz.y, dz.z, dz.w};
-                const float fv[4] = {fz.x, fz.y, fz.z, fz.w}, av[4] = {az.x, az.y, az.z, az.w};
+                const float av[4] = {az.x, az.y, az.z, az.w};
                 float fq4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (DROP) {     // this lane's key is one half of its pair: its own 16 bits of every query's pair hash (DropCfg, launch.h)
                     const uint4 rh = *(const uint4*)(rh_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
@@ -468,28 +514,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const float p = __builtin_amdgcn_exp2f(s[qb][r] + bias_k - lv[e]);
+                    const float p = __builtin_amdgcn_exp2f(s[r] + bias_k - lv[e]);
                     const float f = fq4[e];
-                    pdf[qb * 2 + (r >> 3)][r & 7] = to16<P>(p * f);
-                    float ds = p * (dp[qb][r] * f - dvv[e]);
-                    if (dropping) ds += p * av[e] * (f - fv[e]);
+                    const float pf = p * f;
+                    pdf[r >> 3][r & 7] = to16<P>(pf);
+                    // alpha dS = p f (dP' + a) alpha - p (D' + a F) alpha: the per-query constants arrive folded (issue()); cs accumulates SCALED values
+                    float ds;
+                    if (dropping) ds = pf * fmaf(dp[r], alpha, av[e]) - p * dvv[e];
+                    else ds = p * fmaf(dp[r], alpha, -dvv[e]);
                     cs += ds;
-                    dsf[qb * 2 + (r >> 3)][r & 7] = to16<P>(ds * alpha);
+                    dsf[r >> 3][r & 7] = to16<P>(ds);
                 }
             }
+            {   // dV^T / dK^T += (dO^T | Q^T)[d][the half's queries] . (P | dS): k-slot groups g = 2 qb, 2 qb + 1
+                vec8 fa[2][2], fb[2][2];
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                dv[d] = P::mfma(frag<P>(dOTs + buf * kTile, row_off[d], swz[d], g * 2 + hi), pdf[g], dv[d]);
-                dk[d] = P::mfma(frag<P>(QTs + buf * kTile, row_off[d], swz[d], g * 2 + hi), dsf[g], dk[d]);
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        fa[d][g2] = frag<P>(dOTs + buf * kTile, row_off[d], swz[d], (qb * 2 + g2) * 2 + hi);
+                        fb[d][g2] = frag<P>(QTs + buf * kTile, row_off[d], swz[d], (qb * 2 + g2) * 2 + hi);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        dv[d] = P::mfma(fa[d][g2], pdf[g2], dv[d]);
+                        dk[d] = P::mfma(fb[d][g2], dsf[g2], dk[d]);
+                    }
             }
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the second half's S / dP from being hoisted above: that would restore the register pressure)
+        }
         ST_DMA_WAIT(0);
         __syncthreads();
     }
     {   // undo the operand scale; Q^T was centred: add qmean[d] * sum_q dS back (fp32)
-        cs = xor32_sum(cs);
         const float inv_alpha = 1.0f / alpha;
+        cs = xor32_sum(cs) * inv_alpha;        // (accumulated in scaled units)
         const float* qm = a.qmean + (size_t)nh * 64;
 #pragma unroll
         for (int d2 = 0; d2 < 2; ++d2)
