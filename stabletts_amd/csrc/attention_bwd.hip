@@ -91,6 +91,30 @@ __device__ __forceinline__ void publish_absmax(const f32x16_t (&o)[2], bool vali
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(cell, __float_as_uint(m));
 }
 
+// Augmented k-step that carries a row constant and a column constant THROUGH the score MFMA (as attention.hip does for its softmax
+// reference): the row side holds -c as hi + mid + lo 16-bit terms (24 bits of c with f16 and with bf16 operands) and a 1, the column side
+// three 1s and its own constant: the accumulator comes out as s - c_row + c_col with exact products -- no per-element add / subtract.
+template <class P>
+__device__ __forceinline__ typename P::vec8 aug_neg3(float c, int hi) {
+    typename P::vec8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = to16<P>(0.f);
+    const typename P::elem h = to16<P>(-c);
+    const float r1 = -c - (float)h;
+    const typename P::elem m = to16<P>(r1);
+    const typename P::elem l = to16<P>(r1 - (float)m);
+    if (hi == 0) { v[0] = h; v[1] = m; v[2] = l; v[3] = to16<P>(1.0f); }
+    return v;
+}
+template <class P>
+__device__ __forceinline__ typename P::vec8 aug_ones_plus(float c, int hi) {
+    typename P::vec8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = to16<P>(0.f);
+    if (hi == 0) { v[0] = to16<P>(1.0f); v[1] = to16<P>(1.0f); v[2] = to16<P>(1.0f); v[3] = to16<P>(c); }
+    return v;
+}
+
 __device__ __forceinline__ void store_acc_rows(float* dst_row, const f32x16_t (&o)[2], int hi) {
     // lane = one position; o[d2][r] = value for head dim d2*32 + (r&3) + 8*(r>>2) + 4*hi
 #pragma unroll
@@ -169,7 +193,8 @@ __global__ __launch_bounds__(512, PASS == 1 ? 4 : 2) void attn_bwd_dq_kernel(con
         }
         qf[ks] = as_vec8<P>(v); dof[ks] = as_vec8<P>(w);
     }
-    const float lse_q = qok ? a.lse[(size_t)nh * T + query] : 0.f;
+    const float lse_q = qok ? a.lse[(size_t)nh * T + query] : 0.f;      // (carrying bias - lse through an augmented k-step as the dK/dV kernel does was
+                                                                        //  SLOWER here, 207 -> 220 us: the key-side operand has to be rebuilt per tile from a global load)
     // a = dO[q] . c (c = the mean that was subtracted from V): this lane holds 32 of the 64 head dims, lane^32 the others
     float a_q = 0.f;
     {
@@ -430,6 +455,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
         }
     }
     const float bias_k = kok ? a.kbias[(size_t)mb * Tp + key] : -1e30f;
+    // the key's bias (0 / masked) rides in the augmented k-step of the S MFMA, next to -lse of the query rows (aug_neg3): p = exp2(acc)
+    const vec8 kaug = aug_ones_plus<P>(fmaxf(bias_k, P::kMaskedScore), hi);
     const unsigned drop_ch = DROP ? a.drop.colh[(key < Tp ? key : Tp - 1) >> 1] : 0u;
     const unsigned drop_shl = (key & 1) ? 0u : 16u, drop_thr = a.drop.thresh16 << 16;      // (odd key: high half of the pair hash)
 
@@ -481,6 +508,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
             {
+                const vec8 qaug = aug_neg3<P>(lse_t[buf * 64 + qb * 32 + l31], hi);      // row = query qb * 32 + l31 of the tile
+                s = P::mfma(qaug, kaug, s);
                 vec8 fq[4], fo[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -498,10 +527,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
             vec8 pdf[2], dsf[2];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 lz = *(const float4*)(lse_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                 const float4 dz = *(const float4*)(D_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
                 const float4 az = *(const float4*)(a_t + buf * 64 + qb * 32 + 8 * g4 + 4 * hi);
-                const float lv[4] = {lz.x, lz.y, lz.z, lz.w}, dvv[4] = {dz.x, dz.y, dz.z, dz.w};
+                const float dvv[4] = {dz.x, dz.y, dz.z, dz.w};
                 const float av[4] = {az.x, az.y, az.z, az.w};
                 float fq4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (DROP) {     // this lane's key is one half of its pair: its own 16 bits of every query's pair hash (DropCfg, launch.h)
@@ -514,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const float p = __builtin_amdgcn_exp2f(s[r] + bias_k - lv[e]);
+                    const float p = __builtin_amdgcn_exp2f(s[r]);      // s = q.k + bias_k - lse_q straight from the MFMAs
                     const float f = fq4[e];
                     const float pf = p * f;
                     pdf[r >> 3][r & 7] = to16<P>(pf);
