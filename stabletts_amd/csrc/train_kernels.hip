@@ -220,7 +220,17 @@ __global__ __launch_bounds__(256) void reduce_sites_kernel(RedSites S, int chunk
     const RedSite st = S.s[q];
     const int n = blockIdx.y, ch = threadIdx.x;
     float v = 0.f;
-    for (int c = 0; c < chunks; ++c) v += st.part[(((size_t)n * chunks + c) * st.K + j) * 256 + ch];
+    const float* src = st.part + ((size_t)n * chunks * st.K + j) * 256 + ch;
+    const size_t cs = (size_t)st.K * 256;
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {        // eight chunk partials requested together (the loop was a chain of L2 latencies: 40 us for 16 MB), added in order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(c + u) * cs];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; c < chunks; ++c) v += src[(size_t)c * cs];
     if (st.unscale) v *= st.unscale[1];
     st.out[(size_t)n * st.out_stride + st.off[j] + ch] = v;
 }
@@ -522,7 +532,7 @@ hipError_t launch_recentre(float* a, int64_t n, unsigned* cells, bool have_max, 
         int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;
         hipLaunchKernelGGL(absmax_cells_kernel, dim3(grid), dim3(256), 0, s, a, n, cells);
     }
-    int grid = (int)((n / 4 + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 512) grid = 512; if (grid < 1) grid = 1;      // (usually f == 1: every block reads the cells and leaves)
     hipLaunchKernelGGL(rescale_apply_kernel, dim3(grid), dim3(256), 0, s, a, n / 4, cells, sc, sc_next);
     return hipGetLastError();
 }
@@ -699,9 +709,16 @@ hipError_t launch_wgrad_reduce(const float* partial, int S, int cin, int cout, i
 // their own un-scaling pairs), plus the bias gradients from the [S][cout] column-sum planes wgrad_tn_kernel writes beside its tiles:
 // blocks [0, nb_w) reduce dW elements (co fastest), the last ceil(cout / 256) blocks one bias channel per thread.  Plane order fixed.
 struct WgradRed3 { WgradRed o[3]; int n; };
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const float* partial, const float* part_b, int S, int cin, int cout, int taps,
-                                                                 WgradRed3 R, unsigned nb_w) {
-    const int64_t total = (int64_t)taps * cin * cout;
+// Tiled form (round 6): block = 64 output channels x 64 input channels x all taps.  The planes are read as float4 rows along co (the
+// partial tiles' fast axis), four planes in flight, summed IN PLANE ORDER (bit-identical to the element-per-thread form it replaces);
+// the sums go through an LDS tile [co][ci * taps + j] and out as 256-byte runs of the reference layout (co, ci, j) -- the old form
+// wrote every element as a lone 4-byte store 3 KB away from its neighbour's (786 k partial-line writes for an FFN-sized gradient).
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const float* partial, const float* part_b, int S, int cin, int cout,
+                                                                 WgradRed3 R, unsigned nb_w, int tiles_ci) {
+    constexpr int ROW = 64 * TAPS + 1;
+    __shared__ float tile[64 * ROW];
+    const int64_t total = (int64_t)TAPS * cin * cout;
     if (blockIdx.x >= nb_w) {
         const int co = (int)(blockIdx.x - nb_w) * 256 + threadIdx.x;
         if (co >= cout || !part_b) return;
@@ -715,32 +732,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const float* pa
         R.o[k].db[co - R.o[k].co_start] = v;
         return;
     }
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over (j*cin + ci) x co, co fastest
-    if (idx >= total) return;
-    const int co = (int)(idx % cout);
-    const int jc = (int)(idx / cout);
-    const int j = jc / cin, ci = jc % cin;
-    int k = -1;
+    const int co0 = (int)(blockIdx.x / tiles_ci) * 64, ci0 = (int)(blockIdx.x % tiles_ci) * 64;
+    int k = -1;      // the output this tile's 64 channels belong to (row blocks of the fused q/k/v projection are multiples of 256)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) if (q < R.n && R.o[q].dW && co >= R.o[q].co_start && co < R.o[q].co_start + R.o[q].co_cnt && ci < R.o[q].ci_cnt) k = q;
+    for (int q = 0; q < 3; ++q) if (q < R.n && R.o[q].dW && co0 >= R.o[q].co_start && co0 < R.o[q].co_start + R.o[q].co_cnt) k = q;
     if (k < 0) return;
-    float v = 0.f;
-    for (int sI = 0; sI < S; ++sI) v += partial[(size_t)sI * total + idx];
-    if (R.o[k].unscale) v *= R.o[k].unscale[1];
-    R.o[k].dW[((size_t)(co - R.o[k].co_start) * R.o[k].cin_total + R.o[k].ci_off + ci) * taps + j] = v;
+    const WgradRed o = R.o[k];
+    if (ci0 >= o.ci_cnt) return;
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cil = rg + 16 * u, ci = ci0 + cil;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < cin) {
+                const float* p = partial + ((size_t)j * cin + ci) * cout + co0 + cq * 4;
+                int sI = 0;
+                for (; sI + 4 <= S; sI += 4) {          // four planes requested together, added in plane order
+                    const float4 v0 = *(const float4*)(p + (size_t)(sI + 0) * total), v1 = *(const float4*)(p + (size_t)(sI + 1) * total);
+                    const float4 v2 = *(const float4*)(p + (size_t)(sI + 2) * total), v3 = *(const float4*)(p + (size_t)(sI + 3) * total);
+                    acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                    acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                    acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                    acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+                }
+                for (; sI < S; ++sI) { const float4 v = *(const float4*)(p + (size_t)sI * total); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            }
+            float* t = tile + (cq * 4) * ROW + cil * TAPS + j;
+            t[0] = acc.x; t[ROW] = acc.y; t[2 * ROW] = acc.z; t[3 * ROW] = acc.w;
+        }
+    __syncthreads();
+    const float us = o.unscale ? o.unscale[1] : 1.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nci = min(64, o.ci_cnt - ci0);           // valid input channels of this tile
+    for (int col = wave; col < 64; col += 4) {
+        float* dst = o.dW + ((size_t)(co0 + col - o.co_start) * o.cin_total + o.ci_off + ci0) * TAPS;
+        for (int e = lane; e < nci * TAPS; e += 64) dst[e] = tile[col * ROW + e] * us;
+    }
 }
 
 hipError_t launch_wgrad_reduce_multi(const float* partial, const float* part_b, int S, int cin, int cout, int taps, const WgradRed* outs,
                                      int n_outs, hipStream_t s) {
-    if (n_outs < 1 || n_outs > 3) return hipErrorInvalidValue;
+    if (n_outs < 1 || n_outs > 3 || (cout & 63) || (taps != 1 && taps != 3)) return hipErrorInvalidValue;
     WgradRed3 R; memset(&R, 0, sizeof(R));
     R.n = n_outs;
     bool need_b = false;
-    for (int k = 0; k < n_outs; ++k) { R.o[k] = outs[k]; need_b = need_b || outs[k].db; }
+    for (int k = 0; k < n_outs; ++k) { R.o[k] = outs[k]; need_b = need_b || outs[k].db; if (outs[k].co_start & 63) return hipErrorInvalidValue; }
     if (need_b && !part_b) return hipErrorInvalidValue;
-    const int64_t total = (int64_t)taps * cin * cout;
-    const unsigned nb_w = (unsigned)((total + 255) / 256), nb_b = need_b ? (unsigned)((cout + 255) / 256) : 0u;
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nb_w + nb_b), dim3(256), 0, s, partial, part_b, S, cin, cout, taps, R, nb_w);
+    const int tiles_ci = (cin + 63) / 64;
+    const unsigned nb_w = (unsigned)((cout / 64) * tiles_ci), nb_b = need_b ? (unsigned)((cout + 255) / 256) : 0u;
+    if (taps == 3) hipLaunchKernelGGL(wgrad_reduce_multi_kernel<3>, dim3(nb_w + nb_b), dim3(256), 0, s, partial, part_b, S, cin, cout, R, nb_w, tiles_ci);
+    else           hipLaunchKernelGGL(wgrad_reduce_multi_kernel<1>, dim3(nb_w + nb_b), dim3(256), 0, s, partial, part_b, S, cin, cout, R, nb_w, tiles_ci);
     return hipGetLastError();
 }
 
