@@ -92,7 +92,7 @@ struct TrainState {
     hipEvent_t ev_fork[16] = {}, ev_site[DY_COUNT] = {}, ev_join = nullptr, ev_blk = nullptr, ev_prep = nullptr;
     bool site_pending[DY_COUNT] = {};
     int fork_idx = 0;
-    bool use_side = true, side_prio = true;      // side streams at the device's lowest stream priority (ST_TRAIN_SIDE=1: default priority, 0: no side streams)
+    bool use_side = true, side_prio = false;     // ST_TRAIN_SIDE=2: side streams at the device's lowest stream priority (0: no side streams)
     size_t partial_cap = 0, xt_cap = 0, dyt_cap = 0;
 };
 
@@ -146,11 +146,12 @@ int train_prepare(st_engine* e, hipStream_t s) {
         e->train = new TrainState();
         if (const char* v = getenv("ST_FUSE_SILU")) e->train->fuse_silu = atoi(v) != 0;
         if (const char* v = getenv("ST_FUSE_TRAIN_LN")) e->train->fuse_ln = atoi(v) != 0;
-        if (const char* v = getenv("ST_TRAIN_SIDE")) { e->train->use_side = atoi(v) != 0; e->train->side_prio = atoi(v) != 1; }
+        if (const char* v = getenv("ST_TRAIN_SIDE")) { e->train->use_side = atoi(v) != 0; e->train->side_prio = atoi(v) == 2; }
         TrainState* t0 = e->train;
         if (t0->use_side) {
-            // the side streams run at the device's LOWEST priority: the main chain is the critical path, and when both have blocks pending the
-            // weight-gradient GEMMs should take what is left (18.64 -> 18.51 ms per step paired; ST_TRAIN_SIDE=1 = default priority, for A/B)
+            // ST_TRAIN_SIDE=2 (opt-in): the side streams at the device's LOWEST priority.  Alone in a process that is 0.7 % faster (18.64 ->
+            // 18.51 ms per step, the main chain being the critical path) -- but inside bench.py, next to the inference engines' part streams,
+            // the same setting took the step from 18.6 to 24.9 ms (streams alias onto the process's few hardware queues): not the default.
             int least = 0, greatest = 0;
             if (t0->side_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {
                 HIPCHK(e, hipStreamCreateWithPriority(&t0->side, hipStreamNonBlocking, least));
