@@ -95,7 +95,7 @@ def cpu_baseline(sd, cfg_params, all_cores=False):
                        f"{N_STEPS} euler steps (SURVEY 8d); os.cpu_count()={ncpu}")
 
 
-def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
+def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True, fused_adamw=False):
     """BASELINE config 5 on ONE GPU (train.py:78-82 shape: B=64 utterances per GPU, T <= 1000 ragged, dropout on):
     CFMDecoder.compute_loss forward (native, keeps activations) + loss.backward() (native dgrad / wgrad / attention
     backward) + AdamW step, timed phase by phase (a device sync between phases) and as whole back-to-back steps (one
@@ -106,7 +106,7 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
     dec = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dtype)
     dec.estimator.load_state_dict(sd)
     dec = dec.to(dev).train(dropout)
-    opt = torch.optim.AdamW(dec.parameters(), lr=1e-4)
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-4, fused=True) if fused_adamw else torch.optim.AdamW(dec.parameters(), lr=1e-4)      # train.py:60
     raw = make_inputs(B, T, seed=0, ragged=True)
     inp = {k: v.to(dev) for k, v in raw.items() if k != "lengths"}
     valid = int(raw["lengths"].sum())
@@ -150,7 +150,25 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True):
            "frac_of_mfma_peak": 3 * fwd_flops / fb / 1e12 / MFMA_PEAK_TFLOPS,
            "flops_basis": "valid frames: sum(len), sum(len^2)", "tflops_if_padded_frames_counted": 3 * fwd_flops_padded / fb / 1e12,
            "loss_first_last": [losses[0], losses[-1]],
-           "torch_GB": torch.cuda.max_memory_allocated(dev) / 1e9, "engine_GB": dec.estimator.engine().device_bytes() / 1e9}
+           "torch_GB": torch.cuda.max_memory_allocated(dev) / 1e9, "engine_GB": dec.estimator.engine().device_bytes() / 1e9,
+           "optimizer": "torch.optim.AdamW(fused=True)" if fused_adamw else "torch.optim.AdamW(params, lr) as train.py:60 constructs it (foreach)"}
+    if not fused_adamw:
+        # the same steps with torch's single-kernel AdamW: a one-keyword change to train.py:60, same update rule; reported beside
+        # the reference's construction, which stays the figure of this leg
+        opt = torch.optim.AdamW(dec.parameters(), lr=1e-4, fused=True)
+        with torch.enable_grad():
+            def one():
+                opt.zero_grad(set_to_none=True)
+                loss, _ = dec.compute_loss(x1, inp["mask"], inp["mu"], inp["c"])
+                loss.backward()
+                opt.step()
+            for _ in range(2):
+                one()
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize(dev)
+        res["ms_step_back_to_back_fused_adamw"] = (time.perf_counter() - t0) / steps * 1e3
     del dec, opt
     return res
 

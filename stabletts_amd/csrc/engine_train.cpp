@@ -395,12 +395,22 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
     }
     // cond prenet (estimator.py:83-89,118): pre-activations kept for SiLU'
     {
-        ConvGemmArgs a = cargs(e, e->pre[0], N, T, B); a.a0 = ts->mu16; a.c0 = Mp; a.out16 = ts->a1;
-        HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
-        HIPCHK(e, launch_silu_drop(e->dt, ts->a1, ts->p1, nullptr, 1, T, F, R, nodrop, s));
-        a = cargs(e, e->pre[1], N, T, B); a.a0 = ts->p1; a.c0 = F; a.out16 = ts->a2;
-        HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
-        HIPCHK(e, launch_silu_drop(e->dt, ts->a2, ts->p2, nullptr, 1, T, F, R, nodrop, s));
+        // conv -> SiLU twice: the activation in the GEMM's epilogue where the phased kernel runs (as the FFN's, bit-identical)
+        auto conv_silu = [&](ConvGemmArgs a, void* pre16, void* act16) -> int {
+            a.out16 = pre16;
+            if (ts->fuse_silu && gemm_is_phased(e, 3, a)) {
+                a.act16 = act16;
+                HIPCHK(e, gemm(e, 3, EPI_SILU, a, s));
+            } else {
+                HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
+                HIPCHK(e, launch_silu_drop(e->dt, pre16, act16, nullptr, 1, T, F, R, nodrop, s));
+            }
+            return ST_OK;
+        };
+        ConvGemmArgs a = cargs(e, e->pre[0], N, T, B); a.a0 = ts->mu16; a.c0 = Mp;
+        if ((rc = conv_silu(a, ts->a1, ts->p1))) return rc;
+        a = cargs(e, e->pre[1], N, T, B); a.a0 = ts->p1; a.c0 = F;
+        if ((rc = conv_silu(a, ts->a2, ts->p2))) return rc;
         a = cargs(e, e->pre[2], N, T, B); a.a0 = ts->p2; a.c0 = F; a.out16 = ts->cond16; a.out16_lo = ts->cond16lo;
         HIPCHK(e, gemm(e, 3, EPI_F32, a, s));
         a = cargs(e, e->inc, N, T, B); a.a0 = ts->cond16; a.c0 = C; a.a1 = ts->cond16lo; a.c1 = C; a.c2 = C; a.out32 = ts->cpart;
@@ -907,14 +917,24 @@ int bwd_tail(st_engine* e, TrainState* ts, float* grad_x, float* grad_mu, float*
         const DropCfg nodrop = make_drop(0.f, 0, 0);
         WgradOut o2 = {G(ts, "cond_proj.4.weight"), F, 0, F, 0, C, G(ts, "cond_proj.4.bias")};
         if ((rc = wgrad_side(e, ts, TrainState::DY_T1, ts->p2, F, nullptr, 0, C, K, &o2, 1, s))) return rc;
-        ConvGemmArgs a = cargs(e, ts->preT[2], N, T, B); a.a0 = t1; a.c0 = C; a.out32 = ts->tmpF;
-        HIPCHK(e, gemm(e, K, EPI_F32, a, s));
-        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a2, nullptr, 1, T, F, R, nodrop, t2, s));
+        // d pre-activation = dgrad x SiLU': in the dgrad's epilogue where the phased kernel runs (as the FFN's)
+        auto dgrad_silu = [&](ConvGemmArgs a, const void* pre16, void* dpre16) -> int {
+            if (ts->fuse_silu && K == 3 && gemm_is_phased(e, 3, a) && !a.bias) {
+                a.out16 = dpre16; a.dact16 = pre16;
+                HIPCHK(e, gemm(e, K, EPI_SILU, a, s));
+            } else {
+                a.out32 = ts->tmpF;
+                HIPCHK(e, gemm(e, K, EPI_F32, a, s));
+                HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, pre16, nullptr, 1, T, F, R, nodrop, dpre16, s));
+            }
+            return ST_OK;
+        };
+        ConvGemmArgs a = cargs(e, ts->preT[2], N, T, B); a.a0 = t1; a.c0 = C;
+        if ((rc = dgrad_silu(a, ts->a2, t2))) return rc;
         WgradOut o1 = {G(ts, "cond_proj.2.weight"), F, 0, F, 0, F, G(ts, "cond_proj.2.bias")};
         if ((rc = wgrad_side(e, ts, TrainState::DY_T2, ts->p1, F, nullptr, 0, F, K, &o1, 1, s))) return rc;
-        a = cargs(e, ts->preT[1], N, T, B); a.a0 = t2; a.c0 = F; a.out32 = ts->tmpF;
-        HIPCHK(e, gemm(e, K, EPI_F32, a, s));
-        HIPCHK(e, launch_silu_bwd(e->dt, ts->tmpF, ts->a1, nullptr, 1, T, F, R, nodrop, t3, s));
+        a = cargs(e, ts->preT[1], N, T, B); a.a0 = t2; a.c0 = F;
+        if ((rc = dgrad_silu(a, ts->a1, t3))) return rc;
         WgradOut o0 = {G(ts, "cond_proj.0.weight"), M, 0, M, 0, F, G(ts, "cond_proj.0.bias")};
         if ((rc = wgrad_side(e, ts, TrainState::DY_T3, ts->mu16, Mp, nullptr, 0, F, K, &o0, 1, s))) return rc;
         if (grad_mu) {

@@ -106,32 +106,66 @@ hipError_t launch_silu_rows(const float* in, int64_t n, float* out, hipStream_t 
 }
 
 // the same layer shape for up to 8 (weight, bias, output[, input]) sets in ONE launch (grid.y = set): the six FiLM linears of a training
-// forward share their input tau, the six adaLN modulation linears c -- were 12 launches of ~10 us
+// forward share their input tau, the six adaLN modulation linears c -- were 12 launches of ~10 us.
+// Block = 16 outputs x 32 items (grid.z walks the item groups): the 32 input rows and the 16 weight rows go through LDS in k-chunks of
+// 256, thread (item = tid & 31, output pair = tid >> 5) keeps two accumulators; every weight element is read from memory once per item
+// group instead of once per item (one wave per output element took 136 us for 6 x [64 x 256] -> 1536).
 __global__ __launch_bounds__(256) void linear_multi_kernel(LinearJobs J, int n, int k, int o, int silu_in, int silu_out) {
-    const int lane = threadIdx.x & 63;
-    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= (long long)n * o) return;
-    const int ni = (int)(wid / o), oi = (int)(wid - (long long)ni * o);
-    const float* x = J.in[blockIdx.y] + (size_t)ni * k;
-    const float* w = J.W[blockIdx.y] + (size_t)oi * k;
-    float acc = 0.f;
-    for (int i = lane * 4; i < k; i += 256) {
-        float4 xv = *(const float4*)(x + i);
-        const float4 wv = *(const float4*)(w + i);
-        if (silu_in) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
-        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    constexpr int NI = 32, OT = 16, KC = 256, XP = KC + 4;
+    __shared__ __attribute__((aligned(16))) float xs[NI][XP];
+    __shared__ __attribute__((aligned(16))) float ws[OT][KC];
+    const int tid = threadIdx.x;
+    const int set = blockIdx.y, o0 = blockIdx.x * OT, n0 = blockIdx.z * NI;
+    const float* X = J.in[set];
+    const float* W = J.W[set];
+    const int ni = tid & 31, op = tid >> 5;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int k0 = 0; k0 < k; k0 += KC) {
+        const int kc = min(KC, k - k0);          // multiple of 4
+#pragma unroll
+        for (int i = 0; i < NI * KC / 4 / 256; ++i) {
+            const int idx = tid + 256 * i, r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + r < n && c < kc) {
+                v = *(const float4*)(X + (size_t)(n0 + r) * k + k0 + c);
+                if (silu_in) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            }
+            *(float4*)&xs[r][c] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < OT * KC / 4 / 256; ++i) {
+            const int idx = tid + 256 * i, r = idx / (KC / 4), c = (idx % (KC / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o0 + r < o && c < kc) v = *(const float4*)(W + (size_t)(o0 + r) * k + k0 + c);
+            *(float4*)&ws[r][c] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int c = 0; c < KC; c += 4) {
+            const float4 xv = *(const float4*)&xs[ni][c];
+            const float4 w0 = *(const float4*)&ws[2 * op][c];
+            const float4 w1 = *(const float4*)&ws[2 * op + 1][c];
+            acc0 += xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+            acc1 += xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+        }
+        __syncthreads();
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-        float v = acc + (J.bias[blockIdx.y] ? J.bias[blockIdx.y][oi] : 0.f);
-        if (silu_out) v = silu_f(v);
-        J.out[blockIdx.y][(size_t)ni * o + oi] = v;
+    if (n0 + ni < n) {
+        const float* bias = J.bias[set];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oi = o0 + 2 * op + j;
+            if (oi < o) {
+                float v = (j ? acc1 : acc0) + (bias ? bias[oi] : 0.f);
+                if (silu_out) v = silu_f(v);
+                J.out[set][(size_t)(n0 + ni) * o + oi] = v;
+            }
+        }
     }
 }
 hipError_t launch_linear_multi(const LinearJobs& J, int n, int k, int o, int silu_in, int silu_out, hipStream_t s) {
-    if (J.n < 1 || J.n > 8 || (k & 3)) return hipErrorInvalidValue;
-    const long long waves = (long long)n * o;
-    hipLaunchKernelGGL(linear_multi_kernel, dim3((unsigned)((waves + 3) / 4), J.n), dim3(256), 0, s, J, n, k, o, silu_in, silu_out);
+    if (J.n < 1 || J.n > 8 || (k & 3) || n < 1 || o < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(linear_multi_kernel, dim3((unsigned)((o + 15) / 16), J.n, (unsigned)((n + 31) / 32)), dim3(256), 0, s, J, n, k, o, silu_in, silu_out);
     return hipGetLastError();
 }
 

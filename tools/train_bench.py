@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--fused-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of train.py:60's default construction")
     args = ap.parse_args()
     import oracle
     from bench import train_step_leg
     print(json.dumps(train_step_leg(torch.device("cuda", 0), oracle.make_state_dict(1234), args.batch, args.frames, args.dtype, args.steps,
-                                    dropout=not args.no_dropout)))
+                                    dropout=not args.no_dropout, fused_adamw=args.fused_adamw)))
 
 
 if __name__ == "__main__":
