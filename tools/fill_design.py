@@ -46,7 +46,7 @@ tok = {
     "RAG_MS": f"{rg['ms_per_pass']:.1f}", "RAG_MFS": f"{rg['value'] / 1e6:.3f}", "RAG_MIN": f"{min(rg['ms_per_bucket']):.1f}", "RAG_MAX": f"{max(rg['ms_per_bucket']):.1f}",
     "RAG_CEIL": f"{rg['measured_ceiling_one_bucket_per_gpu']['speedup']:.2f}", "C3_MS": f"{c3['ms_per_step']:.1f}", "C1_MS": f"{j['config1_latency']['ms_per_solve']:.2f}",
     "SPLIT_MS": f"{j['attention_precision_split']['ms_per_step']:.2f}", "TR_F": f"{tr['ms_forward']:.2f}", "TR_B": f"{tr['ms_backward']:.2f}",
-    "TR_O": f"{tr['ms_optimizer_incl_repack']:.2f}", "TR_MS": f"{tr['ms_step_back_to_back']:.2f}", "TR_TF": f"{tr['tflops_fwd_bwd_3x_forward']:.0f}",
+    "TR_O": f"{tr['ms_optimizer_incl_repack']:.2f}", "TR_MS": f"{tr['ms_step_back_to_back']:.2f}", "TR_MS_FUSED": f"{tr.get('ms_step_back_to_back_fused_adamw', float('nan')):.2f}", "TR_TF": f"{tr['tflops_fwd_bwd_3x_forward']:.0f}",
     "TR_FRAC": f"{tr['frac_of_mfma_peak']:.3f}", "VOC_MS": f"{j['vocoder']['ms_per_batch']:.2f}", "CPU_FS": f"{j['cpu_baseline']['value']:.0f}", "B64_TXT": b64,
 }
 s = open(os.path.join(ROOT, "docs", "DESIGN.template.md")).read()
