@@ -126,6 +126,26 @@ def test_config1_b1_t500_euler10(decoders, sd, dt):
     assert _disp(out, ref, inp["z"]) <= DISP_TOL[dt]
 
 
+# ---------------------------------------------------------------- a paragraph-length utterance (T beyond every BASELINE size)
+def test_long_utterances_beyond_the_benchmark_length(decoders, sd, cfg_params):
+    """api.py synthesises whole paragraphs: T = 4000 frames (46 s of audio at hop 512 / 44.1 kHz) next to a shorter item -- 63 key tiles
+    per attention row, RoPE table grown past its first size, the frame-tile / part rules at a length no benchmark exercises.  One
+    evaluation and a short CFG solve against the fp32 oracle at the usual gates."""
+    inp = make_inputs(2, 4000, seed=91, lengths=[4000, 2771])
+    t = torch.tensor(0.45)
+    with torch.inference_mode():
+        ref1 = oracle.decoder_forward(sd, t, inp["z"], inp["mask"], inp["mu"], inp["c"])
+        ref = oracle.cfm_forward(sd, inp["mu"], inp["mask"], 2, inp["z"], inp["c"], "euler", _cfg(cfg_params, 3.0, False))
+    for dt in ("bf16", "f16"):
+        out1 = decoders[dt].estimator(t, inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+        assert _rel(out1, ref1) <= NFE_TOL[dt], (dt, _rel(out1, ref1))
+        out = _solve(decoders[dt], inp, 2, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
+        assert torch.isfinite(out).all()
+        assert _rel(out, ref) <= MEL_TOL and _disp(out, ref, inp["z"]) <= DISP_TOL[dt], (dt, _rel(out, ref), _disp(out, ref, inp["z"]))
+        assert torch.equal(out[1, :, 2771:], inp["z"][1, :, 2771:])      # the velocity is exactly zero past the mask: the noise stays
+        print(f"[{dt}] T=4000: one evaluation {_rel(out1, ref1):.2e}; 2-step CFG solve mel {_rel(out, ref):.2e}, displacement {_disp(out, ref, inp['z']):.2e}")
+
+
 # ---------------------------------------------------------------- long ODE (BASELINE config 3)
 def test_long_ode_50_steps_state_drift(decoders, sd, cfg_params):
     inp = make_inputs(1, 128, seed=3)
