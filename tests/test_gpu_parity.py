@@ -146,6 +146,24 @@ def test_long_utterances_beyond_the_benchmark_length(decoders, sd, cfg_params):
         print(f"[{dt}] T=4000: one evaluation {_rel(out1, ref1):.2e}; 2-step CFG solve mel {_rel(out, ref):.2e}, displacement {_disp(out, ref, inp['z']):.2e}")
 
 
+# ---------------------------------------------------------------- many short utterances (item count beyond every BASELINE size)
+def test_many_short_utterances_in_one_batch(decoders, sd, cfg_params):
+    """B = 200 ragged utterances of <= 96 frames (400 CFG-doubled items: per-item tables, list strides and grid rules at an item count
+    no benchmark reaches), one evaluation and a 2-step CFG solve against the fp32 oracle."""
+    inp = make_inputs(200, 96, seed=92, ragged=True)
+    t = torch.tensor(0.6)
+    with torch.inference_mode():
+        ref1 = oracle.decoder_forward(sd, t, inp["z"], inp["mask"], inp["mu"], inp["c"])
+        ref = oracle.cfm_forward(sd, inp["mu"], inp["mask"], 2, inp["z"], inp["c"], "euler", _cfg(cfg_params, 3.0, False))
+    for dt in ("bf16", "f16"):
+        out1 = decoders[dt].estimator(t, inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda()).cpu()
+        assert _rel(out1, ref1) <= NFE_TOL[dt], (dt, _rel(out1, ref1))
+        out = _solve(decoders[dt], inp, 2, "euler", _cfg(cfg_params, 3.0, True), inp["z"])
+        assert torch.isfinite(out).all()
+        assert _rel(out, ref) <= MEL_TOL and _disp(out, ref, inp["z"]) <= DISP_TOL[dt], (dt, _rel(out, ref), _disp(out, ref, inp["z"]))
+        print(f"[{dt}] B=200 x T<=96: one evaluation {_rel(out1, ref1):.2e}; 2-step CFG solve displacement {_disp(out, ref, inp['z']):.2e}")
+
+
 # ---------------------------------------------------------------- long ODE (BASELINE config 3)
 def test_long_ode_50_steps_state_drift(decoders, sd, cfg_params):
     inp = make_inputs(1, 128, seed=3)

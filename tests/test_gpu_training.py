@@ -318,6 +318,43 @@ def test_gradients_at_the_benchmarked_batch(sd):
     assert all(np.isfinite(v).all() for v in got.values())
 
 
+@pytest.mark.parametrize("B,T,lengths", [(96, 64, None), (2, 2500, [2500, 1733]), (5, 333, [333, 332, 97, 32, 1])])
+def test_gradients_at_shapes_off_the_benchmarks(sd, B, T, lengths):
+    """The training path away from the BASELINE shapes: many short utterances (96 items: per-item tables, reduction chunks and the K split
+    of the weight-gradient GEMMs at an item count no benchmark has), a paragraph-length pair (T = 2500: 40 key tiles per attention row, 79
+    reduction chunks per item), and odd lengths down to ONE frame.  Eval mode, f16 operands, against one pass of the oracle's autograd;
+    gates as at the benchmark sizes (non-q/k tensors, d mu, d c: 3e-3 of max |ref|; loss 5e-4; conv_q / conv_k by direction)."""
+    raw = make_inputs(B, T, seed=33, lengths=lengths, ragged=lengths is None)
+    x1 = make_inputs(B, T, seed=34)["z"]
+    g0 = torch.Generator().manual_seed(29)
+    t_rand = torch.rand(B, 1, 1, generator=g0); z = torch.randn(B, 128, T, generator=g0)
+    dec = _decoder(sd, "f16")
+    mu = raw["mu"].cuda().requires_grad_(True)
+    c = raw["c"].cuda().requires_grad_(True)
+    loss, _ = dec.compute_loss(x1.cuda(), raw["mask"].cuda(), mu, c, t_rand=t_rand.cuda(), z=z.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {n: q.grad.detach().cpu().numpy() for n, q in dec.estimator.named_parameters()}
+    gmu, gc, lv = mu.grad.cpu().numpy(), c.grad.cpu().numpy(), float(loss.detach())
+    with torch.enable_grad():
+        pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        mu0 = raw["mu"].clone().requires_grad_(True); c0 = raw["c"].clone().requires_grad_(True)
+        ref_loss, _ = oracle.compute_loss(pr, x1, raw["mask"], mu0, c0, t_rand, z)
+        ref_loss.backward()
+    assert abs(lv - float(ref_loss.detach())) <= 5e-4 * float(ref_loss.detach())
+    worst = {n: _rel(got[n], pr[n].grad.numpy()) for n in got}
+    cosq = {n: _cos(got[n], pr[n].grad.numpy()) for n in got if _is_qk(n)}
+    wo = max(v for k, v in worst.items() if not _is_qk(k)); wq = max(v for k, v in worst.items() if _is_qk(k))
+    rmu, rc = _rel(gmu, mu0.grad.numpy()), _rel(gc, c0.grad.numpy())
+    print(f"[f16] B={B} T={T} ({int(raw['lengths'].sum())} valid frames): worst non-q/k {wo:.2e}; q/k end-to-end {wq:.2e}, min cosine {min(cosq.values()):.6f}; "
+          f"d mu {rmu:.2e}, d c {rc:.2e}")
+    bad = {k: v for k, v in worst.items() if not _is_qk(k) and v > TOL["f16"]}
+    assert not bad, bad
+    assert rmu <= TOL["f16"] and rc <= TOL["f16"]
+    assert min(cosq.values()) >= COS_QK_SIZE["f16"], cosq
+    assert all(np.isfinite(v).all() for v in got.values())
+
+
 # ---------------------------------------------------------------- K optimizer steps vs the fp32 oracle (SURVEY section 4 item 6)
 TRAJ_B, TRAJ_T, TRAJ_LENS, TRAJ_K = 4, 250, [250, 231, 188, 120], 12
 
