@@ -623,6 +623,7 @@ def main():
         del voc
         # (d) BASELINE config 5 on this GPU: one training step (forward with activations + backward + AdamW), native kernels
         if not args.no_train_leg:
+            dec.estimator.release_engine()      # as in a train.py process: no inference engine (arena, part streams) alive next to the training one (-0.15 ms per step)
             extras["train_step"] = train_step_leg(dev, sd, args.train_batch, T_FRAMES, args.dtype, 5)
 
     def emit(more):

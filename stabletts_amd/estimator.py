@@ -165,6 +165,15 @@ class Decoder(nn.Module):
         ``.to()`` are detected automatically."""
         self._engine_vers = None
 
+    def release_engine(self):
+        """Destroy the native engine (device arena, packed weights, streams); the next call builds a fresh one.  For a process that is
+        done with this module for a while -- e.g. a synthesis model kept next to a training run."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+        self._engine_key = None
+        self._engine_vers = None
+
     def _apply(self, fn, *a, **k):            # .to() / .cuda() / .half(): storage changes
         self._engine_key = None
         return super()._apply(fn, *a, **k)
