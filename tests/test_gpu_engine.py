@@ -325,6 +325,23 @@ def test_inputs_on_the_wrong_device_raise(dec):
         dec.estimator(torch.tensor(0.1).cuda(), inp["z"].cuda(), inp["mask"], inp["mu"].cuda(), inp["c"].cuda())
 
 
+def test_release_engine_frees_and_rebuilds(sd):
+    """release_engine(): the handle is destroyed (device bytes go back to the driver), the next call builds a fresh engine with the same results."""
+    from stabletts_amd.flow_matching import CFMDecoder
+    d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype="f16")
+    d.estimator.load_state_dict(sd)
+    d = d.cuda()
+    inp = make_inputs(2, 48, seed=4, lengths=[48, 31])
+    args = (torch.tensor(0.7).cuda(), inp["z"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+    a = d.estimator(*args)
+    old = d.estimator.engine()
+    d.estimator.release_engine()
+    assert old.handle is None and d.estimator._engine is None
+    d.estimator.release_engine()                          # idempotent
+    b = d.estimator(*args)
+    assert d.estimator.engine() is not old and torch.equal(a, b)
+
+
 def test_sync_weights_after_data_writes(sd):
     """Writes through ``p.data`` do not bump the version counter (EMA / weight-swap utilities): sync_weights()."""
     from stabletts_amd.flow_matching import CFMDecoder
