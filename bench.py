@@ -177,7 +177,7 @@ def train_step_leg(dev, sd, B=64, T=1000, dtype="f16", steps=5, dropout=True, fu
 # tests/test_cabi_cpu.py checks this list against the sources.  Unknown ST_* names are refused too (a new switch must be classified).
 ENGINE_ENV = ("STABLETTS_HIP_LIB", "ST_BIG_MIN_BLOCKS", "ST_PHASED", "ST_FUSED_FFN", "ST_RAGGED_SKIP", "ST_SKIP_CLASSES", "ST_QKV_WS",
               "ST_QKV_WS_MIN_TILES", "ST_OPROJ_WS", "ST_OPROJ_WS_MIN_TILES", "ST_QKV_RC1", "ST_SMALL_GRID", "ST_FUSE_SILU", "ST_FUSE_TRAIN_LN",
-              "ST_TRAIN_SIDE")
+              "ST_TRAIN_SIDE", "ST_TRAIN_VLO")
 # ... and those that do not: ST_SPLIT / ST_HIP_GRAPH change how the same kernels are enqueued (bitwise identical, tests/test_gpu_engine.py),
 # ST_BUILD_* are read by stabletts_amd.build only (a left-over from a build step must not cost the harness its line)
 ENGINE_NEUTRAL_ENV = ("ST_SPLIT", "ST_HIP_GRAPH", "ST_BUILD_OUT", "ST_BUILD_DEFS")

@@ -56,20 +56,26 @@ namespace st {
 // q_hi k_hi + q_lo k_hi + q_hi k_lo (fp32 accumulation; the lo x lo term is below fp32's own rounding of the sum): 3x the QK^T MFMAs,
 // one more K tile per stage in LDS, 16 more registers for the q_lo fragments -- for checkpoints whose softmax is an arg-max
 // (score maxima of 80-200), where the 2^-11 rounding of q and k moves the winning probability.
-template <class P, bool TRAIN, bool SPLIT = false>
+// VLO (training): v arrives as a hi + lo pair (vt, vt_lo) and the output is P v_hi + P v_lo -- the rounding of v is the one forward operand
+// rounding the conv_q / conv_k weight gradients are ill-conditioned in at random init (a key-independent part of v cancels in dP - D, its
+// rounding error does not; tools/train_qk_split_estimate.py): 2x the PV MFMAs, one more V^T tile per stage.
+template <class P, bool TRAIN, bool SPLIT = false, bool VLO = false>
 __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 || SPLIT ? 2 : 4) void attention_kernel(const AttnArgs a) {
     static_assert(!(TRAIN && SPLIT), "split-precision scores: inference kernel only");
+    static_assert(!VLO || (TRAIN && !SPLIT), "hi + lo v: training kernel only");
+    constexpr bool X3 = SPLIT || VLO;            // a third tile per stage (K_lo or V^T_lo)
     constexpr int NW = ST_ATTN_WAVES, QB = 32 * NW, QTILE = QB;      // waves and queries per block
     using vec8 = typename P::vec8;
     constexpr int TILE_BYTES = 64 * 128;
     constexpr int NBUF = 3;                      // K / V^T tile ring: tile kt+2 is in flight while tile kt is computed
-    constexpr int NT = SPLIT ? 3 : 2;           // tiles per stage: K, V^T (, K_lo)
+    constexpr int NT = X3 ? 3 : 2;              // tiles per stage: K, V^T (, K_lo or V^T_lo)
     constexpr int SMEM = NT * NBUF * TILE_BYTES > NW * 32 * 144 ? NT * NBUF * TILE_BYTES : NW * 32 * 144;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     __shared__ float wave_lse[NW];
     unsigned char* Ks = smem;                       // NBUF buffers
     unsigned char* Vs = smem + NBUF * TILE_BYTES;   // NBUF buffers
-    unsigned char* KLs = smem + 2 * NBUF * TILE_BYTES;   // NBUF buffers (SPLIT)
+    unsigned char* KLs = smem + 2 * NBUF * TILE_BYTES;   // NBUF buffers (SPLIT: K_lo; VLO: V^T_lo)
+    unsigned char* VLs = KLs;
 
     const int T = a.T, Tp = a.Tp, H = a.H;
     const int qtiles = (T + QB - 1) / QB;
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 || SPLIT ? 
     const unsigned char* vbase = (const unsigned char*)a.vt + ((size_t)nh * 64) * Tp * 2;
     const unsigned char* qlbase = SPLIT ? (const unsigned char*)a.q_lo + ((size_t)nh * T) * 128 : nullptr;
     const unsigned char* klbase = SPLIT ? (const unsigned char*)a.k_lo + ((size_t)nh * T) * 128 : nullptr;
+    const unsigned char* vlbase = VLO ? (const unsigned char*)a.vt_lo + ((size_t)nh * 64) * Tp * 2 : nullptr;
     if constexpr (TRAIN) {
         if (qt * QB >= kvend) {      // ragged batch: queries past the item's last valid frame -- their rows are multiplied by the
             if (query < T) {         // mask downstream (diffusion_transformer.py:111); the backward reads them: defined zeros
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 || SPLIT ? 
             const int row = piece * 8 + (lane >> 3);
             const int seg = (lane & 7) ^ ((row >> 1) & 7);
             glds16s(sgpr_ptr(vbase + (size_t)kt * 128), (unsigned)((row * Tp + seg * 8) * 2), Vs + buf * TILE_BYTES + piece * 1024);
+            if constexpr (VLO) glds16s(sgpr_ptr(vlbase + (size_t)kt * 128), (unsigned)((row * Tp + seg * 8) * 2), VLs + buf * TILE_BYTES + piece * 1024);
         };
         if constexpr (NW <= 8) {
 #pragma unroll
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 || SPLIT ? 
     // everything but the youngest tile.  (With two buffers and a full drain per tile the iteration time was the LDS-DMA
     // round trip, not the tile's MFMA + softmax work.)
     if (ntiles > 0) issueKV(0, 0);
-    if (ntiles > 1) { issueKV(1, 1); if constexpr (NW <= 8) { if constexpr (NW == 8) { if constexpr (SPLIT) ST_DMA_WAIT(3); else ST_DMA_WAIT(2); } else { if constexpr (SPLIT) ST_DMA_WAIT(6); else ST_DMA_WAIT(4); } } else ST_DMA_WAIT(1); }
+    if (ntiles > 1) { issueKV(1, 1); if constexpr (NW <= 8) { if constexpr (NW == 8) { if constexpr (X3) ST_DMA_WAIT(3); else ST_DMA_WAIT(2); } else { if constexpr (X3) ST_DMA_WAIT(6); else ST_DMA_WAIT(4); } } else ST_DMA_WAIT(1); }
     else ST_DMA_WAIT(0);
     __syncthreads();
 
@@ -357,10 +365,16 @@ __global__ __launch_bounds__(64 * ST_ATTN_WAVES, ST_ATTN_WAVES >= 16 || SPLIT ? 
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
+            if constexpr (VLO) {
+                const unsigned char* vlp = VLs + buf * TILE_BYTES + row_off[d];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    o[d] = P::mfma(as_vec8<P>(*(const uint4*)(vlp + (((g * 2 + hi) ^ swz[d]) << 4))), pf[g], o[d]);
+            }
         }
         }
         // tile kt+1 (asm-issued LDS-DMA, flying under the MFMAs and exps of two tiles) has landed; tile kt+2 stays in flight
-        if (kt + 2 < ntiles_run) { if constexpr (NW <= 8) { if constexpr (NW == 8) { if constexpr (SPLIT) ST_DMA_WAIT(3); else ST_DMA_WAIT(2); } else { if constexpr (SPLIT) ST_DMA_WAIT(6); else ST_DMA_WAIT(4); } } else ST_DMA_WAIT(1); }
+        if (kt + 2 < ntiles_run) { if constexpr (NW <= 8) { if constexpr (NW == 8) { if constexpr (X3) ST_DMA_WAIT(3); else ST_DMA_WAIT(2); } else { if constexpr (X3) ST_DMA_WAIT(6); else ST_DMA_WAIT(4); } } else ST_DMA_WAIT(1); }
         else ST_DMA_WAIT(0);
         __syncthreads();      // publishes tile kt+1, frees buffer kt % 3 for tile kt+3
         buf = buf == NBUF - 1 ? 0 : buf + 1;
@@ -602,6 +616,11 @@ hipError_t launch_attention(int dtype, const AttnArgs& a, hipStream_t s) {
         return dtype == DT_BF16 ? launch_attention_small<OpBF16>(a, s) : launch_attention_small<OpF16>(a, s);
     const int grid = 8 * ((a.n_items * a.H + 7) / 8) * qtiles;      // 8 XCDs x (item, head) groups per XCD x query tiles
     if (a.lse) {
+        if (a.vt_lo) {      // v as a hi + lo pair (72 KB of LDS, as the split-score kernel)
+            if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, true, false, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+            else                  hipLaunchKernelGGL((attention_kernel<OpF16, true, false, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
+            return hipGetLastError();
+        }
         if (dtype == DT_BF16) hipLaunchKernelGGL((attention_kernel<OpBF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
         else                  hipLaunchKernelGGL((attention_kernel<OpF16, true>), dim3(grid), dim3(64 * ST_ATTN_WAVES), 0, s, a);
         return hipGetLastError();

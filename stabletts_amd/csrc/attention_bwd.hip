@@ -730,8 +730,8 @@ hipError_t launch_attn_to_T(int dtype, const void* nat, int64_t item_stride, int
 }
 
 // c[nh][d] = mean over the positions t < T of V[t][d]  (V^T in the T layout: the zero tail adds nothing)
-template <class P>
-__device__ __forceinline__ void attn_vmean_body(const typename P::elem* inT, int T, int Tp, float* vmean, int nh) {
+template <class P, bool LO = false>
+__device__ __forceinline__ void attn_vmean_body(const typename P::elem* inT, const typename P::elem* inT_lo, int T, int Tp, float* vmean, int nh) {
     // one block per (item, head); wave w handles head dims w, w+4, ...; lanes stride over the positions
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int d = wave; d < 64; d += 4) {          // 16 bytes (8 positions) per lane and load; Tp is a multiple of 64
@@ -741,6 +741,11 @@ __device__ __forceinline__ void attn_vmean_body(const typename P::elem* inT, int
             const typename P::vec8 x = as_vec8<P>(*(const uint4*)(row + c));
 #pragma unroll
             for (int e = 0; e < 8; ++e) v += (float)x[e];
+            if constexpr (LO) {       // v = hi + lo (training forward with hi + lo v operands)
+                const typename P::vec8 y = as_vec8<P>(*(const uint4*)(inT_lo + ((size_t)nh * 64 + d) * Tp + c));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v += (float)y[e];
+            }
         }
         v = wave_sum(v);
         if (lane == 0) vmean[(size_t)nh * 64 + d] = v / (float)T;
@@ -748,24 +753,29 @@ __device__ __forceinline__ void attn_vmean_body(const typename P::elem* inT, int
 }
 template <class P>
 __global__ __launch_bounds__(256) void attn_vmean_kernel(const typename P::elem* inT, int T, int Tp, float* vmean) {
-    attn_vmean_body<P>(inT, T, Tp, vmean, blockIdx.x);
+    attn_vmean_body<P>(inT, nullptr, T, Tp, vmean, blockIdx.x);
 }
 
 // T layout -> natural rows, centred: nat[t][d] = V^T[d][perm(t)] - c[d]
-template <class P>
-__device__ __forceinline__ void attn_from_T_body(const typename P::elem* inT, int T, int Tp, const float* vmean,
+template <class P, bool LO = false>
+__device__ __forceinline__ void attn_from_T_body(const typename P::elem* inT, const typename P::elem* inT_lo, int T, int Tp, const float* vmean,
                                                  typename P::elem* nat, typename P::elem* nat_lo, int bx, int nh) {
     __shared__ typename P::elem tile[64][64 + 2];
+    __shared__ typename P::elem tile_lo[LO ? 64 : 1][64 + 2];
     const int p0 = bx * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int d = ty; d < 64; d += 4) tile[d][tx] = inT[((size_t)nh * 64 + d) * Tp + p0 + tx];      // column tx = position perm(tx)
+    for (int d = ty; d < 64; d += 4) {      // column tx = position perm(tx)
+        tile[d][tx] = inT[((size_t)nh * 64 + d) * Tp + p0 + tx];
+        if constexpr (LO) tile_lo[d][tx] = inT_lo[((size_t)nh * 64 + d) * Tp + p0 + tx];
+    }
     __syncthreads();
     const float cm = vmean ? vmean[(size_t)nh * 64 + tx] : 0.f;
     for (int rr = ty; rr < 64; rr += 4) {
         const int pos = p0 + rr;
         const int c = (rr & ~12) | ((rr & 4) << 1) | ((rr & 8) >> 1);     // perm is an involution: position rr sits in column perm(rr)
         if (pos < T) {
-            const float v = (float)tile[tx][c] - cm;
+            float v = (float)tile[tx][c] - cm;
+            if constexpr (LO) v += (float)tile_lo[tx][c];
             const typename P::elem hi16 = to16<P>(v);
             nat[((size_t)nh * T + pos) * 64 + tx] = hi16;
             if (nat_lo) nat_lo[((size_t)nh * T + pos) * 64 + tx] = to16<P>(v - (float)hi16);
@@ -775,37 +785,45 @@ __device__ __forceinline__ void attn_from_T_body(const typename P::elem* inT, in
 template <class P>
 __global__ __launch_bounds__(256) void attn_from_T_kernel(const typename P::elem* inT, int T, int Tp, const float* vmean,
                                                           typename P::elem* nat, typename P::elem* nat_lo) {
-    attn_from_T_body<P>(inT, T, Tp, vmean, nat, nat_lo, blockIdx.x, blockIdx.y);
+    attn_from_T_body<P>(inT, nullptr, T, Tp, vmean, nat, nat_lo, blockIdx.x, blockIdx.y);
 }
 
 // The gradient-independent operand copies of one attention backward in TWO launches (were six): the three means (grid.y = q, k, v),
 // then the centred copies (grid.z = V back to natural rows as a hi + lo pair, Q^T, K^T).  Same bodies, same results.
-template <class P>
+template <class P, bool VLO>
 __global__ __launch_bounds__(256) void attn_prep_means_kernel(const typename P::elem* q, const typename P::elem* k, const typename P::elem* vT,
-                                                              int T, int Tp, float* qmean, float* kmean, float* vmean) {
+                                                              const typename P::elem* vT_lo, int T, int Tp, float* qmean, float* kmean, float* vmean) {
     if (blockIdx.y == 0) attn_mean_nat_body<P>(q, T, qmean, blockIdx.x);
     else if (blockIdx.y == 1) attn_mean_nat_body<P>(k, T, kmean, blockIdx.x);
-    else attn_vmean_body<P>(vT, T, Tp, vmean, blockIdx.x);
+    else attn_vmean_body<P, VLO>(vT, vT_lo, T, Tp, vmean, blockIdx.x);
 }
-template <class P>
+template <class P, bool VLO>
 __global__ __launch_bounds__(256) void attn_prep_copies_kernel(const typename P::elem* q, const typename P::elem* k, const typename P::elem* vT,
-                                                               int H, int T, int Tp, const float* qmean, const float* kmean, const float* vmean,
+                                                               const typename P::elem* vT_lo, int H, int T, int Tp, const float* qmean, const float* kmean, const float* vmean,
                                                                typename P::elem* qT, typename P::elem* kT, typename P::elem* vnat, typename P::elem* vnat_lo) {
-    if (blockIdx.z == 0) attn_from_T_body<P>(vT, T, Tp, vmean, vnat, vnat_lo, blockIdx.x, blockIdx.y);
+    if (blockIdx.z == 0) attn_from_T_body<P, VLO>(vT, vT_lo, T, Tp, vmean, vnat, vnat_lo, blockIdx.x, blockIdx.y);
     else if (blockIdx.z == 1) attn_to_T_body<P>(q, (int64_t)H * T * 64, (int64_t)T * 64, 64, H, T, Tp, qmean, qT, blockIdx.x, blockIdx.y);
     else attn_to_T_body<P>(k, (int64_t)H * T * 64, (int64_t)T * 64, 64, H, T, Tp, kmean, kT, blockIdx.x, blockIdx.y);
 }
-hipError_t launch_attn_prep(int dtype, const void* q, const void* k, const void* vT, int n_items, int H, int T, int Tp, float* qmean, float* kmean,
-                            float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s) {
+namespace {
+template <class P, bool VLO>
+void attn_prep_launch(const void* q, const void* k, const void* vT, const void* vT_lo, int n_items, int H, int T, int Tp, float* qmean, float* kmean,
+                      float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s) {
+    using E = typename P::elem;
     const dim3 g1(n_items * H, 3), g2(Tp / 64, n_items * H, 3);
+    hipLaunchKernelGGL((attn_prep_means_kernel<P, VLO>), g1, dim3(256), 0, s, (const E*)q, (const E*)k, (const E*)vT, (const E*)vT_lo, T, Tp, qmean, kmean, vmean);
+    hipLaunchKernelGGL((attn_prep_copies_kernel<P, VLO>), g2, dim3(256), 0, s, (const E*)q, (const E*)k, (const E*)vT, (const E*)vT_lo, H, T, Tp, qmean, kmean, vmean,
+                       (E*)qT, (E*)kT, (E*)vnat, (E*)vnat_lo);
+}
+}  // namespace
+hipError_t launch_attn_prep(int dtype, const void* q, const void* k, const void* vT, const void* vT_lo, int n_items, int H, int T, int Tp, float* qmean,
+                            float* kmean, float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s) {
     if (dtype == DT_BF16) {
-        hipLaunchKernelGGL((attn_prep_means_kernel<OpBF16>), g1, dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vT, T, Tp, qmean, kmean, vmean);
-        hipLaunchKernelGGL((attn_prep_copies_kernel<OpBF16>), g2, dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k, (const __bf16*)vT, H, T, Tp, qmean, kmean, vmean,
-                           (__bf16*)qT, (__bf16*)kT, (__bf16*)vnat, (__bf16*)vnat_lo);
+        if (vT_lo) attn_prep_launch<OpBF16, true>(q, k, vT, vT_lo, n_items, H, T, Tp, qmean, kmean, vmean, qT, kT, vnat, vnat_lo, s);
+        else       attn_prep_launch<OpBF16, false>(q, k, vT, vT_lo, n_items, H, T, Tp, qmean, kmean, vmean, qT, kT, vnat, vnat_lo, s);
     } else {
-        hipLaunchKernelGGL((attn_prep_means_kernel<OpF16>), g1, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)vT, T, Tp, qmean, kmean, vmean);
-        hipLaunchKernelGGL((attn_prep_copies_kernel<OpF16>), g2, dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k, (const _Float16*)vT, H, T, Tp, qmean, kmean, vmean,
-                           (_Float16*)qT, (_Float16*)kT, (_Float16*)vnat, (_Float16*)vnat_lo);
+        if (vT_lo) attn_prep_launch<OpF16, true>(q, k, vT, vT_lo, n_items, H, T, Tp, qmean, kmean, vmean, qT, kT, vnat, vnat_lo, s);
+        else       attn_prep_launch<OpF16, false>(q, k, vT, vT_lo, n_items, H, T, Tp, qmean, kmean, vmean, qT, kT, vnat, vnat_lo, s);
     }
     return hipGetLastError();
 }

@@ -495,29 +495,43 @@ __device__ __forceinline__ void g2_epilogue_qkv(f32x16_t (&acc)[BC / WC / 32][BF
         }
         }
     } else {
+        // pass 0: the 16-bit plane; pass 1 (training with g.vt_lo): the rounding residuals v - float(v16) through the same image
+        auto plane = [&](auto pass_c, unsigned char* dst) {
+            constexpr bool LO = decltype(pass_c)::value;
 #pragma unroll
-        for (int b = 0; b < FF; ++b) {
-            const int fl = wf * TF + b * 32 + l31;
-            const bool tv = t0 + fl < T;
-            const int pos = (fl & ~12) | ((fl & 4) << 1) | ((fl & 8) >> 1);
+            for (int b = 0; b < FF; ++b) {
+                const int fl = wf * TF + b * 32 + l31;
+                const bool tv = t0 + fl < T;
+                const int pos = (fl & ~12) | ((fl & 4) << 1) | ((fl & 8) >> 1);
 #pragma unroll
-            for (int a = 0; a < TC / 32; ++a)
+                for (int a = 0; a < TC / 32; ++a)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = wc * TC + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    *(typename P::elem*)(stage + ch * PV + pos * 2) = to16<P>(tv ? acc[a][b][r] : 0.0f);
-                }
-        }
-        __syncthreads();
-        constexpr int SPR = BF / 8, RPI = 64 / SPR;      // 16-B segments per channel row, channel rows per wave instruction
-        const int rsub = lane / SPR, seg = lane % SPR;
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = wc * TC + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        float x = tv ? acc[a][b][r] : 0.0f;
+                        if constexpr (LO) {
+                            asm volatile("" : "+v"(x));      // (keeps the 128 residuals from being formed ahead of the first plane's stores: registers)
+                            x -= (float)to16<P>(x);
+                        }
+                        *(typename P::elem*)(stage + ch * PV + pos * 2) = to16<P>(x);
+                    }
+            }
+            __syncthreads();
+            constexpr int SPR = BF / 8, RPI = 64 / SPR;      // 16-B segments per channel row, channel rows per wave instruction
+            const int rsub = lane / SPR, seg = lane % SPR;
 #pragma unroll
-        for (int i = 0; i < BC / (NW * RPI); ++i) {
-            const int ch = (i * NW + wave) * RPI + rsub;
-            const uint4 v = *(const uint4*)(stage + ch * PV + seg * 16);
-            const int tcol = t0 + seg * 8;
-            if (tcol < g.Tp)
-                store_row16((unsigned char*)g.vt + ((((size_t)n * H + (ch >> 6)) * 64 + (ch & 63)) * g.Tp + tcol) * 2, v);
+            for (int i = 0; i < BC / (NW * RPI); ++i) {
+                const int ch = (i * NW + wave) * RPI + rsub;
+                const uint4 v = *(const uint4*)(stage + ch * PV + seg * 16);
+                const int tcol = t0 + seg * 8;
+                if (tcol < g.Tp)
+                    store_row16(dst + ((((size_t)n * H + (ch >> 6)) * 64 + (ch & 63)) * g.Tp + tcol) * 2, v);
+            }
+        };
+        plane(std::false_type{}, (unsigned char*)g.vt);
+        if (g.vt_lo) {
+            __syncthreads();      // the row stores of the first plane have read the image
+            plane(std::true_type{}, (unsigned char*)g.vt_lo);
         }
     }
 }

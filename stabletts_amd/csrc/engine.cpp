@@ -132,7 +132,7 @@ hipError_t gemm(st_engine* e, int taps, int epi, const ConvGemmArgs& a, hipStrea
         }
     }
     // the fused q/k/v projection of big grids: weights in registers, activations streamed (qkv_ws.hip; bit-identical)
-    if (epi == EPI_QKV && e->qkv_ws && !a.q_lo && e->sink && a.w_frag && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
+    if (epi == EPI_QKV && e->qkv_ws && !a.q_lo && !a.vt_lo && e->sink && a.w_frag && a.cout == 768 && a.c0 == 256 && !a.c1 && !a.c2 && a.n_heads == 4 &&
         (int64_t)a.n_items * ((T + 63) / 64) >= e->qkv_ws_min_tiles) {      // (per LAUNCH: a block needs a handful of tiles to amortise its weight load)
         ConvGemmArgs b = a; b.sink = e->sink;
         return launch_qkv_ws(e->dt, b, s);

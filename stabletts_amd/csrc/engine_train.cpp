@@ -29,7 +29,7 @@ namespace sthost {
 
 struct LayerAct {
     float *lscout, *x1, *o32, *x2, *f32b, *x3;
-    void *h1, *q, *k, *vt, *attn16, *h2, *a16, *u16, *x3_16;
+    void *h1, *q, *k, *vt, *vt_lo, *attn16, *h2, *a16, *u16, *x3_16;      // vt_lo: rounding residuals of v (ts->v_lo), else nullptr
     float* lse;
 };
 
@@ -92,6 +92,13 @@ struct TrainState {
     hipEvent_t ev_fork[16] = {}, ev_site[DY_COUNT] = {}, ev_join = nullptr, ev_blk = nullptr, ev_prep = nullptr;
     bool site_pending[DY_COUNT] = {};
     int fork_idx = 0;
+    // ST_TRAIN_VLO=1 (opt-in): v as a hi + lo pair of 16-bit operands in the training forward (attention output = P v_hi + P v_lo, the
+    // backward's centred pair formed from both).  The conv_q / conv_k weight gradients are ill-conditioned in v at random init (a
+    // key-independent part of v cancels in dP - D, a rounding error does not): end to end vs the fp32 oracle at B = 4 x T = 1000 they are
+    // 25 % off (cosine 0.991) with one operand, 17 % (0.9965) with the pair -- the rest is the same sensitivity to the 16-bit rounding of
+    // the projections' INPUT (tools/train_qk_split_estimate.py: 11 % from h1 alone), which no operand pair of q, k, v removes.  Costs
+    // 0.35 ms per step (generic q/k/v tile instead of the weight-stationary kernel, 2x the PV MFMAs): not the default.
+    bool v_lo = false;
     bool use_side = true, side_prio = false;     // ST_TRAIN_SIDE=2: side streams at the device's lowest stream priority (0: no side streams)
     size_t partial_cap = 0, xt_cap = 0, dyt_cap = 0;
 };
@@ -146,6 +153,7 @@ int train_prepare(st_engine* e, hipStream_t s) {
         e->train = new TrainState();
         if (const char* v = getenv("ST_FUSE_SILU")) e->train->fuse_silu = atoi(v) != 0;
         if (const char* v = getenv("ST_FUSE_TRAIN_LN")) e->train->fuse_ln = atoi(v) != 0;
+        if (const char* v = getenv("ST_TRAIN_VLO")) e->train->v_lo = atoi(v) != 0;
         if (const char* v = getenv("ST_TRAIN_SIDE")) { e->train->use_side = atoi(v) != 0; e->train->side_prio = atoi(v) == 2; }
         TrainState* t0 = e->train;
         if (t0->use_side) {
@@ -271,6 +279,7 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
         want((void**)&a.x1, R * C * 4); want((void**)&a.o32, R * C * 4); want((void**)&a.x2, R * C * 4);
         want((void**)&a.f32b, R * C * 4); want((void**)&a.x3, R * C * 4);
         want(&a.h1, R * C * 2); want(&a.q, R * C * 2); want(&a.k, R * C * 2); want(&a.vt, N * C * Tp * 2);
+        if (ts->v_lo) want(&a.vt_lo, N * C * Tp * 2); else a.vt_lo = nullptr;
         want(&a.attn16, R * C * 2); want(&a.h2, R * C * 2); want(&a.a16, R * F * 2); want(&a.u16, R * F * 2);
         want(&a.x3_16, R * C * 2);
         want((void**)&a.lse, N * H * TT * 4);
@@ -442,14 +451,14 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         }
         {
             ConvGemmArgs a = cargs(e, e->qkv[i], N, T, B);
-            a.a0 = A.h1; a.c0 = C; a.q = A.q; a.k = A.k; a.vt = A.vt; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+            a.a0 = A.h1; a.c0 = C; a.q = A.q; a.k = A.k; a.vt = A.vt; a.vt_lo = A.vt_lo; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
             a.Tp = Tp; a.n_heads = H; a.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
             if ((int)e->qkv_frag.size() == e->L) a.w_frag = e->qkv_frag[i];      // weight-stationary kernel on big batches (bit-identical; re-packed with the other forward weights)
             HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));
         }
         {
             AttnArgs a; memset(&a, 0, sizeof(a));
-            a.q = A.q; a.k = A.k; a.vt = A.vt; a.out = A.attn16; a.kbias = ts->kbias; a.mask_mod = B; a.zeros = e->zeros;
+            a.q = A.q; a.k = A.k; a.vt = A.vt; a.vt_lo = A.vt_lo; a.out = A.attn16; a.kbias = ts->kbias; a.mask_mod = B; a.zeros = e->zeros;
             a.kv_end = ts->kv_end; a.n_full = ts->n_full; a.T = T; a.Tp = Tp; a.H = H; a.n_items = N;
             a.lse = A.lse; a.drop = make_drop(p_dropout, seed, 2 * i + 1);
             if (a.drop.thresh16) { a.drop.rowh = ts->drop_rowh_all + (size_t)i * ts->drop_row_stride; a.drop.colh = ts->drop_colh_all + (size_t)i * ts->drop_col_stride; }
@@ -518,7 +527,8 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
             capture(e, bn + "x1", ts->L[i].x1, R * C, false, s); capture(e, bn + "x2", ts->L[i].x2, R * C, false, s);
             capture(e, bn + "x3", ts->L[i].x3, R * C, false, s); capture(e, bn + "h1", ts->L[i].h1, R * C, true, s);
             capture(e, bn + "q", ts->L[i].q, R * C, true, s); capture(e, bn + "k", ts->L[i].k, R * C, true, s);
-            capture(e, bn + "vt", ts->L[i].vt, (int64_t)N * C * Tp, true, s); capture(e, bn + "attn", ts->L[i].attn16, R * C, true, s);
+            capture(e, bn + "vt", ts->L[i].vt, (int64_t)N * C * Tp, true, s); if (ts->L[i].vt_lo) capture(e, bn + "vtlo", ts->L[i].vt_lo, (int64_t)N * C * Tp, true, s);
+             capture(e, bn + "attn", ts->L[i].attn16, R * C, true, s);
             capture(e, bn + "lse", ts->L[i].lse, (int64_t)N * H * T, false, s);
             capture(e, bn + "u", ts->L[i].u16, R * F, true, s);
         }
@@ -697,7 +707,7 @@ int bwd_head(st_engine* e, TrainState* ts, const float* grad_out, hipStream_t s)
 int attn_prep(st_engine* e, TrainState* ts, int i, hipStream_t s) {
     const int H = e->H, N = ts->B, T = ts->T, Tp = ts->Tp;
     LayerAct& A = ts->L[i];
-    HIPCHK(e, launch_attn_prep(e->dt, A.q, A.k, A.vt, N, H, T, Tp, ts->qmean, ts->kmean, ts->vmean, ts->qT, ts->kT, ts->vnat, ts->vnat_lo, s));
+    HIPCHK(e, launch_attn_prep(e->dt, A.q, A.k, A.vt, A.vt_lo, N, H, T, Tp, ts->qmean, ts->kmean, ts->vmean, ts->qT, ts->kT, ts->vnat, ts->vnat_lo, s));
     return ST_OK;
 }
 

@@ -39,6 +39,7 @@ struct ConvGemmArgs {
     // EPI_QKV (cout = 3*C, head_dim 64): q,k -> [item][H][T][64], vT -> [item][H][64][Tp]
     void* q; void* k; void* vt;
     void* q_lo; void* k_lo;           // split-precision attention operands (nullptr: off): the rounding residuals of q and k, same layout
+    void* vt_lo;                      // training (nullptr: off): the rounding residual of v, layout of vt -- the attention output is then P (v_hi + v_lo)
     const float* rope_cos; const float* rope_sin;   // [T][16]
     int Tp; float qscale; int n_heads;
     const void* zeros;                // >= 16 bytes of zeros in global memory (halo source of the LDS-DMA path)
@@ -120,6 +121,7 @@ hipError_t launch_drop_tables(const DropCfg& d, int n_rows, int n_colpairs, unsi
 struct AttnArgs {
     const void* q; const void* k; const void* vt; void* out;   // out: [item][T][H*64] 16-bit
     const void* q_lo; const void* k_lo;    // inference: split-precision scores s = q_hi k_hi + q_lo k_hi + q_hi k_lo (nullptr: s = q k); 16-bit, layout of q / k
+    const void* vt_lo;                     // training: the rounding residuals of v (layout of vt): O = P v_hi + P v_lo (nullptr: O = P v)
     unsigned* lse_max;                     // inference: a group of kLseCells cells 64 B apart receiving max over rows of the log2-sum-exp (order-preserving int bits; nullptr: off)
     const float* kbias; int mask_mod;      // additive key bias [mask_mod][Tp]: 0 valid, -1e30 masked / >= T
     const int* kv_end; const int* n_full;  // per mask row: last valid key + 1, leading valid prefix length

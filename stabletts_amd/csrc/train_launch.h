@@ -152,8 +152,9 @@ hipError_t launch_attn_mean_nat(int dtype, const void* nat, int n_heads_total, i
 // computed first and subtracted (attention_bwd.hip, "Precision")
 // nat_lo (optional): 16-bit rounding residual of the centred values (hi + lo operand pair)
 // the three means + the three centred copies of one attention backward in two launches (same bodies as the single launches below)
-hipError_t launch_attn_prep(int dtype, const void* q, const void* k, const void* vT, int n_items, int H, int T, int Tp, float* qmean, float* kmean,
-                            float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s);
+// vT_lo (optional): the forward's rounding residuals of v (hi + lo v operands): the mean and the centred pair are then formed from vT + vT_lo
+hipError_t launch_attn_prep(int dtype, const void* q, const void* k, const void* vT, const void* vT_lo, int n_items, int H, int T, int Tp, float* qmean,
+                            float* kmean, float* vmean, void* qT, void* kT, void* vnat, void* vnat_lo, hipStream_t s);
 hipError_t launch_attn_from_T(int dtype, const void* inT, int n_items, int H, int T, int Tp, float* vmean, void* nat, void* nat_lo,
                               hipStream_t s);
 struct AttnBwdArgs {

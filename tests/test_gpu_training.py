@@ -41,6 +41,17 @@ def _is_qk(name):
     return ".attn.conv_q." in name or ".attn.conv_k." in name
 
 
+def _native_v(eng, i, B, H, T, Tp, pos):
+    """The forward's v operand of block i as the attention kernels see it, [B][H][T][64]: the 16-bit plane plus (round 6: hi + lo v
+    operands in the training forward, ST_TRAIN_VLO) its rounding residuals."""
+    v = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp).astype(np.float64)
+    try:
+        v = v + eng.debug_fetch(f"t{i}.vtlo").reshape(B, H, 64, Tp).astype(np.float64)
+    except Exception:      # noqa: BLE001  (ST_TRAIN_VLO=0: there is no residual plane)
+        pass
+    return v[..., pos][..., :T].transpose(0, 1, 3, 2)
+
+
 def _decoder(sd, dt, train=False):
     from stabletts_amd.flow_matching import CFMDecoder
     d = CFMDecoder(128, 128, 256, 128, 1024, 4, 6, 3, 0.1, 256, operand_dtype=dt)
@@ -108,7 +119,7 @@ def test_attention_backward_at_matched_inputs(sd, dt):
             scale = float(eng.debug_fetch(f"g.scale_a{i}")[0])     # the pass-wide power-of-two scale, re-centred before the attention part
             q = eng.debug_fetch(f"t{i}.q").reshape(B, 4, T, 64).astype(np.float64)        # q_s = q_r * log2(e) / 8
             k = eng.debug_fetch(f"t{i}.k").reshape(B, 4, T, 64).astype(np.float64)
-            v = eng.debug_fetch(f"t{i}.vt").reshape(B, 4, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)
+            v = _native_v(eng, i, B, 4, T, Tp, pos)
             dO = (eng.debug_fetch(f"g.dattn_{i}").reshape(B, T, 4, 64).transpose(0, 2, 1, 3) / scale).astype(np.float64)
             S2 = q @ k.transpose(0, 1, 3, 2) + bias
             S2 -= S2.max(-1, keepdims=True)
@@ -225,7 +236,7 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
             scale = float(eng.debug_fetch(f"g.scale_a{i}")[0])     # the pass-wide power-of-two scale, re-centred before the attention part
             q = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64).astype(np.float64)
             k = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64).astype(np.float64)
-            v = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2).astype(np.float64)
+            v = _native_v(eng, i, B, H, T, Tp, pos)
             dO = (eng.debug_fetch(f"g.dattn_{i}").reshape(B, T, H, 64).transpose(0, 2, 1, 3) / scale).astype(np.float64)
             S2 = q @ k.transpose(0, 1, 3, 2) + bias
             S2 -= S2.max(-1, keepdims=True)
@@ -257,7 +268,7 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
         for i in range(6):
             qn = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64) * (8.0 / math.log2(math.e))
             kn = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64)
-            vn = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2)
+            vn = _native_v(eng, i, B, H, T, Tp, pos).astype(np.float32)
             subst.append({"q": torch.from_numpy(np.ascontiguousarray(qn)), "k": torch.from_numpy(np.ascontiguousarray(kn)),
                           "v": torch.from_numpy(np.ascontiguousarray(vn))})
         with torch.enable_grad():
@@ -316,6 +327,65 @@ def test_gradients_at_the_benchmarked_batch(sd):
     assert rmu <= TOL["f16"] and rc <= TOL["f16"]
     assert min(cosq.values()) >= COS_QK_SIZE["f16"], cosq
     assert all(np.isfinite(v).all() for v in got.values())
+
+
+def test_v_as_a_hi_lo_operand_pair_in_the_training_forward(sd, size_case, monkeypatch):
+    """ST_TRAIN_VLO=1 (opt-in, round 6): v enters the training forward as hi + lo 16-bit operands.  Every gate of the default path holds, and
+    the conv_q / conv_k weight gradients end to end move towards the fp32 oracle (B = 4 x T = 1000: 2.5e-1 -> 1.7e-1, cosine 0.991 -> 0.9965)
+    -- but only that far: the same ill-conditioning applies to the rounding of the projections' 16-bit input (tools/train_qk_split_estimate.py),
+    so the mode stays opt-in.  Also: a second step on the same engine (buffers re-used) and the dropout path run under it."""
+    sc = size_case
+    inp = sc["inp"]
+
+    def run(vlo):
+        if vlo:
+            monkeypatch.setenv("ST_TRAIN_VLO", "1")
+        else:
+            monkeypatch.delenv("ST_TRAIN_VLO", raising=False)
+        dec = _decoder(sd, "f16")
+        out = None
+        for _ in range(2):
+            dec.zero_grad()
+            mu = inp["mu"].cuda().requires_grad_(True)
+            c = inp["c"].cuda().requires_grad_(True)
+            loss, _ = dec.compute_loss(sc["x1"].cuda(), inp["mask"].cuda(), mu, c, t_rand=sc["t_rand"].cuda(), z=sc["z"].cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            got = {n: q.grad.detach().cpu().numpy() for n, q in dec.estimator.named_parameters()}
+            if out is not None:
+                assert all(np.array_equal(got[n], out[0][n]) for n in got)      # deterministic across steps on re-used buffers
+            out = (got, float(loss.detach()), mu.grad.cpu().numpy(), c.grad.cpu().numpy())
+        monkeypatch.delenv("ST_TRAIN_VLO", raising=False)
+        return out
+
+    res = {}
+    for vlo in (False, True):
+        got, lv, gmu, gc = run(vlo)
+        assert abs(lv - sc["loss"]) <= 5e-4 * sc["loss"]
+        worst = {n: _rel(got[n], sc["grads"][n]) for n in got}
+        bad = {k: v for k, v in worst.items() if not _is_qk(k) and v > TOL["f16"]}
+        assert not bad, bad
+        assert _rel(gmu, sc["gmu"]) <= TOL["f16"] and _rel(gc, sc["gc"]) <= TOL["f16"]
+        res[vlo] = (max(v for k, v in worst.items() if _is_qk(k)), min(_cos(got[n], sc["grads"][n]) for n in got if _is_qk(n)),
+                    max(v for k, v in worst.items() if not _is_qk(k)))
+        print(f"[f16, v {'hi + lo' if vlo else 'one operand'}] B={SIZE_B} T={SIZE_T}: q/k end-to-end {res[vlo][0]:.2e}, min cosine {res[vlo][1]:.6f}; worst non-q/k {res[vlo][2]:.2e}")
+    assert res[True][0] < 0.85 * res[False][0] and res[True][1] > res[False][1]
+    assert res[True][1] >= 0.995
+    # train mode (dropout masks) under the mode: finite, deterministic for a fixed torch seed
+    monkeypatch.setenv("ST_TRAIN_VLO", "1")
+    dec = _decoder(sd, "f16", train=True)
+    monkeypatch.delenv("ST_TRAIN_VLO", raising=False)
+    vals = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        dec.zero_grad()
+        loss, _ = dec.compute_loss(sc["x1"].cuda(), inp["mask"].cuda(), inp["mu"].cuda(), inp["c"].cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        g = {n: q.grad.detach().cpu().numpy().copy() for n, q in dec.estimator.named_parameters()}
+        assert all(np.isfinite(v).all() for v in g.values())
+        vals.append((float(loss.detach()), g))
+    assert vals[0][0] == vals[1][0] and all(np.array_equal(vals[0][1][n], vals[1][1][n]) for n in vals[0][1])
 
 
 @pytest.mark.parametrize("B,T,lengths", [(96, 64, None), (2, 2500, [2500, 1733]), (5, 333, [333, 332, 97, 32, 1])])
@@ -542,7 +612,7 @@ def test_gradients_with_trained_like_weights(size_case):
         for i in range(6):
             qn = eng.debug_fetch(f"t{i}.q").reshape(B, H, T, 64) * (8.0 / math.log2(math.e))
             kn = eng.debug_fetch(f"t{i}.k").reshape(B, H, T, 64)
-            vn = eng.debug_fetch(f"t{i}.vt").reshape(B, H, 64, Tp)[..., pos][..., :T].transpose(0, 1, 3, 2)
+            vn = _native_v(eng, i, B, H, T, Tp, pos).astype(np.float32)
             subst.append({"q": torch.from_numpy(np.ascontiguousarray(qn)), "k": torch.from_numpy(np.ascontiguousarray(kn)),
                           "v": torch.from_numpy(np.ascontiguousarray(vn))})
     finally:
