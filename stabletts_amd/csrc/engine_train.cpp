@@ -29,7 +29,7 @@ namespace sthost {
 
 struct LayerAct {
     float *lscout, *x1, *o32, *x2, *f32b, *x3;
-    void *h1, *q, *k, *vt, *vt_lo, *attn16, *h2, *a16, *u16, *x3_16;      // vt_lo: rounding residuals of v (ts->v_lo), else nullptr
+    void *h1, *h1lo, *q, *k, *vt, *vt_lo, *attn16, *h2, *a16, *u16, *x3_16;      // vt_lo: rounding residuals of v (ts->v_lo), else nullptr
     float* lse;
 };
 
@@ -37,6 +37,7 @@ struct TrainState {
     // transposed (dgrad) weights
     Conv finT, inxT, incT, preT[3];
     std::vector<Conv> ffn1T, ffn2T, oprojT, qkvT, lscTa, lscTb;
+    std::vector<Conv> qkv2;                     // ST_TRAIN_VLO=2: q/k/v weights over K = [h_hi | h_lo]: [W_q 0; W_k 0; W_v W_v]
     std::vector<void*> owned;
     // fp32 parameter gradients, reference shapes, in ONE flat buffer: parameter-name order (st_param_info's), every slice starting
     // on a 64-byte boundary (goff; st_train_grad_offset).  gbase = where the running backward writes them: the engine's own
@@ -92,13 +93,15 @@ struct TrainState {
     hipEvent_t ev_fork[16] = {}, ev_site[DY_COUNT] = {}, ev_join = nullptr, ev_blk = nullptr, ev_prep = nullptr;
     bool site_pending[DY_COUNT] = {};
     int fork_idx = 0;
-    // ST_TRAIN_VLO=1 (opt-in): v as a hi + lo pair of 16-bit operands in the training forward (attention output = P v_hi + P v_lo, the
-    // backward's centred pair formed from both).  The conv_q / conv_k weight gradients are ill-conditioned in v at random init (a
-    // key-independent part of v cancels in dP - D, a rounding error does not): end to end vs the fp32 oracle at B = 4 x T = 1000 they are
-    // 25 % off (cosine 0.991) with one operand, 17 % (0.9965) with the pair -- the rest is the same sensitivity to the 16-bit rounding of
-    // the projections' INPUT (tools/train_qk_split_estimate.py: 11 % from h1 alone), which no operand pair of q, k, v removes.  Costs
-    // 0.35 ms per step (generic q/k/v tile instead of the weight-stationary kernel, 2x the PV MFMAs): not the default.
-    bool v_lo = false;
+    // The conv_q / conv_k weight gradients are ill-conditioned in v at random init (near-uniform softmax: dS ~ dO.(v_j - o_i), the
+    // key-independent bulk of v cancels in that difference, its 16-bit error does not): with v and its input h1 as single 16-bit operands they
+    // are 25 % off the fp32 oracle end to end at B = 4 x T = 1000 (cosine 0.991; tools/train_qk_split_estimate.py: rounding v 18 %, rounding
+    // h1 11 %, rounding q and k 0.1 %).  Default (ST_TRAIN_VLO=2): the LayerNorm kernel also stores h1's rounding residuals, the q/k/v
+    // GEMM runs over K = [h_hi | h_lo] against [W_q 0; W_k 0; W_v W_v] (q, k bit-identical) and stores v's residual plane, the attention
+    // forward adds P v_lo, the backward's centred v pair is formed from both: 2.9 % (cosine 0.99957), 3.8 % at B = 64.  Costs 0.40 ms per
+    // step (generic q/k/v tile with twice the K instead of the weight-stationary kernel, 2x the PV MFMAs).  1: v as a pair but from h_hi only
+    // (17 %); 0: rounds 1-5.
+    bool v_lo = true, h_lo = true;
     bool use_side = true, side_prio = false;     // ST_TRAIN_SIDE=2: side streams at the device's lowest stream priority (0: no side streams)
     size_t partial_cap = 0, xt_cap = 0, dyt_cap = 0;
 };
@@ -153,7 +156,7 @@ int train_prepare(st_engine* e, hipStream_t s) {
         e->train = new TrainState();
         if (const char* v = getenv("ST_FUSE_SILU")) e->train->fuse_silu = atoi(v) != 0;
         if (const char* v = getenv("ST_FUSE_TRAIN_LN")) e->train->fuse_ln = atoi(v) != 0;
-        if (const char* v = getenv("ST_TRAIN_VLO")) e->train->v_lo = atoi(v) != 0;
+        if (const char* v = getenv("ST_TRAIN_VLO")) { e->train->v_lo = atoi(v) != 0; e->train->h_lo = atoi(v) == 2; }
         if (const char* v = getenv("ST_TRAIN_SIDE")) { e->train->use_side = atoi(v) != 0; e->train->side_prio = atoi(v) == 2; }
         TrainState* t0 = e->train;
         if (t0->use_side) {
@@ -199,6 +202,19 @@ int train_prepare(st_engine* e, hipStream_t s) {
         if ((rc = pack_T(e, ts, ts->ffn1T[i], b + "mlp.conv_1.weight", F, C, K, 0, C, C, F, s))) return rc;
         if ((rc = pack_T(e, ts, ts->ffn2T[i], b + "mlp.conv_2.weight", C, F, K, 0, F, F, C, s))) return rc;
         if ((rc = pack_T(e, ts, ts->oprojT[i], b + "attn.conv_o.weight", C, C, 1, 0, C, C, C, s))) return rc;
+        if (ts->h_lo) {      // forward q/k/v weights over K = [h_hi | h_lo]
+            if ((int)ts->qkv2.size() != L) ts->qkv2.assign(L, Conv());
+            Conv& q2 = ts->qkv2[i];
+            q2.cout = 3 * C; q2.cin = 2 * C; q2.taps = 1; q2.bias = e->qkv[i].bias;
+            if (!q2.w) { HIPCHK(e, hipMalloc(&q2.w, (size_t)3 * C * 2 * C * 2)); ts->owned.push_back(q2.w); HIPCHK(e, hipMemsetAsync(q2.w, 0, (size_t)3 * C * 2 * C * 2, s)); }
+            int r2 = 0;
+            for (const char* nm : {"q", "k", "v"}) {
+                const float* w = P(e, b + "attn.conv_" + nm + ".weight");
+                if ((rc = pk_weight(e, e->pk_T, w, C, C, 1, 0, C, q2.w, r2 * C, 2 * C, 0, r2 == 2 ? C : 2 * C, 0, s))) return rc;
+                if (r2 == 2 && (rc = pk_weight(e, e->pk_T, w, C, C, 1, 0, C, q2.w, r2 * C, 2 * C, C, C, 0, s))) return rc;
+                ++r2;
+            }
+        }
         // fused q/k/v: K of the dgrad GEMM = [dq | dk | dv] (3C)
         Conv& q = ts->qkvT[i];
         q.cout = C; q.cin = 3 * C; q.taps = 1;
@@ -280,6 +296,7 @@ int layout_train(st_engine* e, TrainState* ts, int B, int T) {
         want((void**)&a.f32b, R * C * 4); want((void**)&a.x3, R * C * 4);
         want(&a.h1, R * C * 2); want(&a.q, R * C * 2); want(&a.k, R * C * 2); want(&a.vt, N * C * Tp * 2);
         if (ts->v_lo) want(&a.vt_lo, N * C * Tp * 2); else a.vt_lo = nullptr;
+        if (ts->h_lo) want(&a.h1lo, R * C * 2); else a.h1lo = nullptr;
         want(&a.attn16, R * C * 2); want(&a.h2, R * C * 2); want(&a.a16, R * F * 2); want(&a.u16, R * F * 2);
         want(&a.x3_16, R * C * 2);
         want((void**)&a.lse, N * H * TT * 4);
@@ -443,15 +460,16 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         }
         {   // FiLM * mask -> x1 ; LN1 + modulate -> h1
             TrainLnArgs a; memset(&a, 0, sizeof(a));
-            a.xin = xpre_of(ts, i, L); a.xout = A.x1; a.h16 = A.h1;
+            a.xin = xpre_of(ts, i, L); a.xout = A.x1; a.h16 = A.h1; a.h16lo = A.h1lo;
             a.film = ts->film + (size_t)i * N * 2 * C; a.film_stride = 2 * C; a.film_mod = N;
             a.ada = ada_i; a.ada_stride = 6 * C; a.shift_off = 0; a.scale_off = C;
             a.mask = m; a.mask_mod = B; a.mask_out = 0; a.T = T; a.rows = (int)R;
             HIPCHK(e, launch_train_ln(e->dt, a, s));
         }
         {
-            ConvGemmArgs a = cargs(e, e->qkv[i], N, T, B);
+            ConvGemmArgs a = cargs(e, ts->h_lo ? ts->qkv2[i] : e->qkv[i], N, T, B);
             a.a0 = A.h1; a.c0 = C; a.q = A.q; a.k = A.k; a.vt = A.vt; a.vt_lo = A.vt_lo; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+            if (ts->h_lo) { a.a1 = A.h1lo; a.c1 = C; }      // K = [h_hi | h_lo] against [W 0] (q, k rows: bit-identical) / [W_v W_v] (v rows)
             a.Tp = Tp; a.n_heads = H; a.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
             if ((int)e->qkv_frag.size() == e->L) a.w_frag = e->qkv_frag[i];      // weight-stationary kernel on big batches (bit-identical; re-packed with the other forward weights)
             HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));

@@ -87,9 +87,11 @@ __global__ __launch_bounds__(256) void train_ln_kernel(const TrainLnArgs a) {
             const float* ad = a.ada + (size_t)n * a.ada_stride + lane * 4;
             const float4 sh = *(const float4*)(ad + a.shift_off), sc = *(const float4*)(ad + a.scale_off);
             const float mm = a.mask_out ? m : 1.0f;
-            *(uint2*)((unsigned char*)a.h16 + o * 2) =
-                pack4<P>((d0 * rstd * (1.0f + sc.x) + sh.x) * mm, (d1 * rstd * (1.0f + sc.y) + sh.y) * mm,
-                         (d2 * rstd * (1.0f + sc.z) + sh.z) * mm, (d3 * rstd * (1.0f + sc.w) + sh.w) * mm);
+            const float h0 = (d0 * rstd * (1.0f + sc.x) + sh.x) * mm, h1 = (d1 * rstd * (1.0f + sc.y) + sh.y) * mm;
+            const float h2 = (d2 * rstd * (1.0f + sc.z) + sh.z) * mm, h3 = (d3 * rstd * (1.0f + sc.w) + sh.w) * mm;
+            *(uint2*)((unsigned char*)a.h16 + o * 2) = pack4<P>(h0, h1, h2, h3);
+            if (a.h16lo)
+                *(uint2*)((unsigned char*)a.h16lo + o * 2) = pack4<P>(h0 - (float)to16<P>(h0), h1 - (float)to16<P>(h1), h2 - (float)to16<P>(h2), h3 - (float)to16<P>(h3));
         }
     }
 }

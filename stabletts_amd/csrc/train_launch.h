@@ -19,6 +19,7 @@ DropCfg make_drop(float p, unsigned long long seed, int salt);
 // h16 = (LayerNorm(x) * (1 + scale) + shift) [* mask if mask_out]
 struct TrainLnArgs {
     const float* xin; float* xout; void* x16; void* x16lo; void* h16;
+    void* h16lo;                // optional: the rounding residuals of h16 (ST_TRAIN_VLO=2: the v projection reads h as a hi + lo pair)
     const float* film; int film_stride; int film_mod;
     const float* gate; int gate_stride; const float* branch;
     const float* ada; int ada_stride; int shift_off; int scale_off;

@@ -5,12 +5,14 @@ masks, and a 2-process DDP run.  Run with ``-m gpu``.
 
 Gates (max |native - ref| / max |ref| per tensor): f16 operands 3e-3, bf16 operands 2e-2 -- except the q / k
 projections of the attention: d loss / d q and d loss / d k subtract two nearly equal terms (dP - D) and, at these
-random-init weights where V and K are almost uncorrelated over the keys, a 5e-4 relative difference in V (the size of
-the 16-bit FORWARD's own deviation from the fp32 reference) moves them by several percent at T = 44 and by tens of
-percent at T = 1000.  For those tensors the gate is the matched-operand chain of test_gradients_at_config5_size: the
+random-init weights where the softmax is near-uniform, dS ~ dO.(v_j - o_i): the key-independent bulk of v cancels, a 16-bit
+error of v does not.  With v and the projection's input as single 16-bit operands (rounds 1-5, ST_TRAIN_VLO=0) those
+gradients were 2 % off the fp32 reference at T = 44 and 25 % at T = 1000; since round 6 v is computed from h1 as a hi + lo
+pair and kept as a hi + lo pair through the attention (2e-3 at T = 44, 3-4 % at T = 1000, cosine 0.9996): gated at 1e-2 /
+8e-2.  The chain itself is gated at matched operands in test_gradients_at_config5_size: the
 attention backward kernels vs fp64 on the native q, k, v, d attn; RoPE^T + pack + weight-gradient GEMM vs fp64 on the native
 dq, dk, h1; and END TO END against the oracle's autograd evaluated at the native forward's own q, k, v
-(oracle.attention(subst=...)): 4e-3 (f16) at B=4 x T=1000.  (That comparison is what exposed, in round 3, that f16 rounded
+(oracle.attention(subst=...)): 5e-3 (f16) at B=4 x T=1000.  (That comparison is what exposed, in round 3, that f16 rounded
 d q / d k to subnormals at the pass-wide gradient scale; they now carry their own power-of-two scales.)
 """
 import math
@@ -28,8 +30,8 @@ from oracle.inputs import make_inputs
 pytestmark = [pytest.mark.gpu, pytest.mark.grad]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = {"f16": 3e-3, "bf16": 2e-2}          # measured 5.3e-4 / 4.2e-3
-TOL_QK = {"f16": 6e-2, "bf16": 4e-1}       # end-to-end only, measured 2.3e-2 / 1.9e-1 (conditioning of dq, dk at random init, see above);
-                                           # the gate for q / k is the matched-input chain of test_gradients_at_config5_size
+TOL_QK = {"f16": 1e-2, "bf16": 1e-1}       # end to end, measured 2.1e-3 / 2.3e-2 since round 6 (v from hi + lo operands: 2.3e-2 / 3.4e-1 before -- the
+                                           # conditioning of dq, dk in v at random init, test_v_as_a_hi_lo_operand_pair_in_the_training_forward)
 
 
 def _rel(a, b):
@@ -140,11 +142,11 @@ def test_attention_backward_at_matched_inputs(sd, dt):
 # ---------------------------------------------------------------- BASELINE config 5 shapes (train.py:78-81 at T = 1000)
 SIZE_B, SIZE_T, SIZE_LENS = 4, 1000, [1000, 873, 655, 512]
 # q / k projections at T = 1000 (measured on MI355X, f16 / bf16):
-#   end to end vs the fp32 oracle       2.2e-1 / 1.46, cosine 0.992 / 0.83   -- conditioning of d q, d k in the forward's operand rounding
-#   vs the oracle AT the native q, k, v  4.2e-3 / 2.6e-2, cosine 0.999995 / 0.99978  -- the native backward chain itself (the gate)
-TOL_QK_SIZE = {"f16": 4e-1, "bf16": None}      # bf16: a max-norm gate of 250 % is no gate -- its end-to-end q / k gradients are gated by
-COS_QK_SIZE = {"f16": 0.98, "bf16": 0.7}        # direction only (cosine) and by the matched-operand chain; bf16 is not a training dtype
-                                                # with parity (train with the default f16 operands)
+#   end to end vs the fp32 oracle       2.9e-2 / 1.2e-1, cosine 0.99957 / 0.9886  (round 6: v = W_v (h_hi + h_lo) kept as a hi + lo operand pair;
+#                                        2.5e-1 / 1.6, cosine 0.991 / 0.82 with v and its input as single 16-bit operands, ST_TRAIN_VLO=0)
+#   vs the oracle AT the native q, k, v  5.4e-3 / 1.5e-2, cosine 0.999994 / 0.9999  -- the native backward chain itself
+TOL_QK_SIZE = {"f16": 8e-2, "bf16": 3e-1}
+COS_QK_SIZE = {"f16": 0.999, "bf16": 0.97}      # (bf16 is not a training dtype with parity: INTEGRATION.md, train with the default f16 operands)
 TOL_QK_MATCHED = {"f16": 1e-2, "bf16": 6e-2}
 
 
@@ -191,9 +193,9 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
     k = 3 kernels), once with the tile policy as shipped for this batch size and once with ST_BIG_MIN_BLOCKS=1, which
     makes every conv -- forward, dgrad AND wgrad -- take the 256 x 256 / phased tiles a B = 64 batch runs on.
     Gates: every tensor 3e-3 (f16) / 2e-2 (bf16) of max |ref|, as at the small size -- except conv_q / conv_k, whose
-    end-to-end error is dominated by the conditioning of dq, dk at random init (module docstring): for those the
-    MATCHED-INPUT checks below are the gate (attention backward vs fp64 on the native q, k, v, d attn; RoPE^T + pack +
-    weight-gradient GEMM vs fp64 on the native dq, dk, h1) and the end-to-end number is gated loosely and printed."""
+    end-to-end error carries the conditioning of dq, dk in v at random init (module docstring: 8e-2 / cosine 0.999 with f16 operands);
+    their chain is gated by the MATCHED-INPUT checks below (attention backward vs fp64 on the native q, k, v, d attn; RoPE^T + pack +
+    weight-gradient GEMM vs fp64 on the native dq, dk, h1)."""
     sc = size_case
     if tiles == "big":
         monkeypatch.setenv("ST_BIG_MIN_BLOCKS", "1")
@@ -279,7 +281,7 @@ def test_gradients_at_config5_size(sd, size_case, monkeypatch, dt, tiles):
         cm = {n: _cos(params[n].grad.cpu().numpy(), pr[n].grad.numpy()) for n in params if _is_qk(n)}
         print(f"[{dt}/{tiles}] q/k gradients vs the oracle evaluated at the native q, k, v: worst {max(wm.values()):.2e}, min cosine {min(cm.values()):.6f}")
         assert max(wm.values()) <= TOL_QK_MATCHED[dt], wm
-        # ---- and the end-to-end q / k numbers (conditioning-limited, see the docstring): loose gate
+        # ---- and the end-to-end q / k numbers (module docstring)
         badq = {k: v for k, v in worst.items() if _is_qk(k) and TOL_QK_SIZE[dt] is not None and v > TOL_QK_SIZE[dt]}
         assert not badq, badq
         assert min(cosq.values()) >= COS_QK_SIZE[dt], cosq
@@ -292,8 +294,8 @@ def test_gradients_at_the_benchmarked_batch(sd):
     make_inputs(64, 1000, seed=0, ragged=True), the tile policy as shipped -- no ST_* override): loss, all 116 parameter gradients,
     d mu and d c against ONE pass of the oracle's autograd on the host (fp32 PyTorch-CPU, ~1-2 min on the GPU box's cores; eval mode:
     the dropout masks of a 64 x 4 x 1000 x 1000 attention site are not reproduced in numpy here -- the dropout test above covers the
-    masks).  Gates as at B = 4: every non-q/k tensor 3e-3 of max |ref|, d mu / d c 3e-3, loss 5e-4; conv_q / conv_k end to end are
-    conditioning-limited (module docstring) and gated by direction, printed."""
+    masks).  Gates as at B = 4: every non-q/k tensor 3e-3 of max |ref|, d mu / d c 3e-3, loss 5e-4; conv_q / conv_k end to end (module docstring): cosine 0.999
+    (measured 3.8e-2, 0.99968)."""
     B, T = 64, 1000
     raw = make_inputs(B, T, seed=0, ragged=True)
     x1 = make_inputs(B, T, seed=1)["z"]
@@ -330,18 +332,17 @@ def test_gradients_at_the_benchmarked_batch(sd):
 
 
 def test_v_as_a_hi_lo_operand_pair_in_the_training_forward(sd, size_case, monkeypatch):
-    """ST_TRAIN_VLO=1 (opt-in, round 6): v enters the training forward as hi + lo 16-bit operands.  Every gate of the default path holds, and
-    the conv_q / conv_k weight gradients end to end move towards the fp32 oracle (B = 4 x T = 1000: 2.5e-1 -> 1.7e-1, cosine 0.991 -> 0.9965)
-    -- but only that far: the same ill-conditioning applies to the rounding of the projections' 16-bit input (tools/train_qk_split_estimate.py),
-    so the mode stays opt-in.  Also: a second step on the same engine (buffers re-used) and the dropout path run under it."""
+    """Round 6: the conv_q / conv_k weight gradients are ill-conditioned in v at random init (near-uniform softmax: dS ~ dO.(v_j - o_i), the
+    key-independent bulk of v cancels, its 16-bit error does not; tools/train_qk_split_estimate.py: rounding v moves them by 18 %, rounding the
+    projection's input h1 by 11 %, rounding q and k by 0.1 %).  ST_TRAIN_VLO=0: v and h1 as single 16-bit operands (rounds 1-5); 1: v kept as a hi +
+    lo pair (attention output = P v_hi + P v_lo); 2 (the default): v = W_v h_hi + W_v h_lo, kept as a pair.  End to end vs the fp32 oracle at B = 4 x
+    T = 1000: 2.5e-1 -> 1.7e-1 -> 2.9e-2 (cosine 0.991 -> 0.9965 -> 0.99957); every other gate holds in every mode; deterministic on re-used
+    buffers and under dropout."""
     sc = size_case
     inp = sc["inp"]
 
     def run(vlo):
-        if vlo:
-            monkeypatch.setenv("ST_TRAIN_VLO", "1")
-        else:
-            monkeypatch.delenv("ST_TRAIN_VLO", raising=False)
+        monkeypatch.setenv("ST_TRAIN_VLO", str(int(vlo)))
         dec = _decoder(sd, "f16")
         out = None
         for _ in range(2):
@@ -359,7 +360,7 @@ def test_v_as_a_hi_lo_operand_pair_in_the_training_forward(sd, size_case, monkey
         return out
 
     res = {}
-    for vlo in (False, True):
+    for vlo in (0, 1, 2):
         got, lv, gmu, gc = run(vlo)
         assert abs(lv - sc["loss"]) <= 5e-4 * sc["loss"]
         worst = {n: _rel(got[n], sc["grads"][n]) for n in got}
@@ -368,13 +369,12 @@ def test_v_as_a_hi_lo_operand_pair_in_the_training_forward(sd, size_case, monkey
         assert _rel(gmu, sc["gmu"]) <= TOL["f16"] and _rel(gc, sc["gc"]) <= TOL["f16"]
         res[vlo] = (max(v for k, v in worst.items() if _is_qk(k)), min(_cos(got[n], sc["grads"][n]) for n in got if _is_qk(n)),
                     max(v for k, v in worst.items() if not _is_qk(k)))
-        print(f"[f16, v {'hi + lo' if vlo else 'one operand'}] B={SIZE_B} T={SIZE_T}: q/k end-to-end {res[vlo][0]:.2e}, min cosine {res[vlo][1]:.6f}; worst non-q/k {res[vlo][2]:.2e}")
-    assert res[True][0] < 0.85 * res[False][0] and res[True][1] > res[False][1]
-    assert res[True][1] >= 0.995
+        print(f"[f16, {('v one operand', 'v hi + lo', 'v hi + lo from h1 hi + lo')[vlo]}] B={SIZE_B} T={SIZE_T}: q/k end-to-end {res[vlo][0]:.2e}, min cosine {res[vlo][1]:.6f}; "
+              f"worst non-q/k {res[vlo][2]:.2e}")
+    assert res[1][0] < 0.85 * res[0][0] and res[1][1] > res[0][1] and res[1][1] >= 0.995
+    assert res[2][0] < 0.25 * res[0][0] and res[2][0] <= TOL_QK_SIZE["f16"] and res[2][1] >= COS_QK_SIZE["f16"]
     # train mode (dropout masks) under the mode: finite, deterministic for a fixed torch seed
-    monkeypatch.setenv("ST_TRAIN_VLO", "1")
     dec = _decoder(sd, "f16", train=True)
-    monkeypatch.delenv("ST_TRAIN_VLO", raising=False)
     vals = []
     for _ in range(2):
         torch.manual_seed(7)
@@ -421,7 +421,7 @@ def test_gradients_at_shapes_off_the_benchmarks(sd, B, T, lengths):
     bad = {k: v for k, v in worst.items() if not _is_qk(k) and v > TOL["f16"]}
     assert not bad, bad
     assert rmu <= TOL["f16"] and rc <= TOL["f16"]
-    assert min(cosq.values()) >= COS_QK_SIZE["f16"], cosq
+    assert min(cosq.values()) >= 0.998 and wq <= TOL_QK_SIZE["f16"], (wq, cosq)      # (2 x 2500: 3.9e-2, cosine 0.99936)
     assert all(np.isfinite(v).all() for v in got.values())
 
 
@@ -507,7 +507,7 @@ def test_training_trajectory_matches_the_fp32_oracle(sd, oracle_trajectories, lr
 
 def test_training_trajectory_at_config5_frame_count(sd):
     """The same statement at T = 1000 (the round-5 review: the T = 250 trajectory sees attention 4x less peaky, and the single-step
-    conv_q / conv_k gradients are 22 % off end to end at T = 1000): K = 8 AdamW steps at the reference's lr = 1e-4, B = 4 x T = 1000
+    conv_q / conv_k gradients were 22 % off end to end at T = 1000 then, 3 % since round 6): K = 8 AdamW steps at the reference's lr = 1e-4, B = 4 x T = 1000
     ragged, native f16 against the fp32 oracle on the same draws.  Asserted as at T = 250: per-step loss within 1e-3, the accumulated
     update of EVERY tensor -- conv_q / conv_k included -- within cosine 0.99 of the oracle's, no element more than 3 lr off."""
     B, T, K, lr = 4, 1000, 8, 1e-4
