@@ -570,7 +570,8 @@ void conv_gemm2_kernel(const ConvGemmArgs g) {
     const int cbase = tc * BC, t0 = tf * BF;
     if (g.t_lim && t0 >= g.t_lim[n % g.t_lim_mod]) return;      // ragged batch: this tile lies past the item's last needed frame
     const int cin = g.c0 + g.c1 + g.c2;
-    const int nch_all = cin >> 6;
+    // (EPI_QKV with GF_K2_V_ONLY: the q and k planes' weights are zero beyond c0 -- their blocks skip those chunks, same sums)
+    const int nch_all = (EPI == EPI_QKV && (g.flags & GF_K2_V_ONLY) && cbase < 2 * BC ? g.c0 : cin) >> 6;
     const int cb = kz * nch_all / ks, nch = (kz + 1) * nch_all / ks;      // this block's chunks [cb, nch)
     const int T = g.T;
 

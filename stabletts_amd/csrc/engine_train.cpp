@@ -98,8 +98,8 @@ struct TrainState {
     // are 25 % off the fp32 oracle end to end at B = 4 x T = 1000 (cosine 0.991; tools/train_qk_split_estimate.py: rounding v 18 %, rounding
     // h1 11 %, rounding q and k 0.1 %).  Default (ST_TRAIN_VLO=2): the LayerNorm kernel also stores h1's rounding residuals, the q/k/v
     // GEMM runs over K = [h_hi | h_lo] against [W_q 0; W_k 0; W_v W_v] (q, k bit-identical) and stores v's residual plane, the attention
-    // forward adds P v_lo, the backward's centred v pair is formed from both: 2.9 % (cosine 0.99957), 3.8 % at B = 64.  Costs 0.40 ms per
-    // step (generic q/k/v tile with twice the K instead of the weight-stationary kernel, 2x the PV MFMAs).  1: v as a pair but from h_hi only
+    // forward adds P v_lo, the backward's centred v pair is formed from both: 2.9 % (cosine 0.99957), 3.8 % at B = 64.  Costs 0.3 ms per
+    // step (generic q/k/v tile -- twice the K for its v blocks only, GF_K2_V_ONLY -- instead of the weight-stationary kernel, 2x the PV MFMAs).  1: v as a pair but from h_hi only
     // (17 %); 0: rounds 1-5.
     bool v_lo = true, h_lo = true;
     bool use_side = true, side_prio = false;     // ST_TRAIN_SIDE=2: side streams at the device's lowest stream priority (0: no side streams)
@@ -469,7 +469,7 @@ int st_train_forward(st_engine* e, const float* t, const float* x, const float* 
         {
             ConvGemmArgs a = cargs(e, ts->h_lo ? ts->qkv2[i] : e->qkv[i], N, T, B);
             a.a0 = A.h1; a.c0 = C; a.q = A.q; a.k = A.k; a.vt = A.vt; a.vt_lo = A.vt_lo; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
-            if (ts->h_lo) { a.a1 = A.h1lo; a.c1 = C; }      // K = [h_hi | h_lo] against [W 0] (q, k rows: bit-identical) / [W_v W_v] (v rows)
+            if (ts->h_lo) { a.a1 = A.h1lo; a.c1 = C; a.flags |= GF_K2_V_ONLY; }      // K = [h_hi | h_lo] against [W 0] (q, k rows: bit-identical) / [W_v W_v] (v rows)
             a.Tp = Tp; a.n_heads = H; a.qscale = 1.4426950408889634f / sqrtf((float)(C / H));
             if ((int)e->qkv_frag.size() == e->L) a.w_frag = e->qkv_frag[i];      // weight-stationary kernel on big batches (bit-identical; re-packed with the other forward weights)
             HIPCHK(e, gemm(e, 1, EPI_QKV, a, s));

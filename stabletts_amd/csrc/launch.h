@@ -14,7 +14,8 @@ enum { DT_BF16 = 0, DT_F16 = 1 };
 enum { EPI_ACT16 = 0, EPI_F32 = 1, EPI_RESGATE = 2, EPI_QKV = 3,
        EPI_GELU16 = 4,     // EPI_ACT16 with exact-erf GELU in place of SiLU (Vocos pwconv1, module.py:38-39)
        EPI_SILU = 5 };     // training FFN (k = 3, phased kernel only): EPI_F32 + the SiLU / dropout step fused, see act16 / dact16
-enum { GF_SILU = 1, GF_MASK = 2 };
+enum { GF_SILU = 1, GF_MASK = 2,
+       GF_K2_V_ONLY = 4 };     // EPI_QKV with a second source: its weights are zero in the q and k rows (training: v = W_v h_hi + W_v h_lo) -- q / k blocks stop at c0
 
 struct ConvGemmArgs {
     const void* a0; const void* a1;   // activation sources [items][T][c0], [items][T][c1]
