@@ -1,8 +1,12 @@
-"""Which 16-bit attention operand carries the end-to-end error of the conv_q / conv_k weight gradients at config-5 frame counts?  (Round 6;
-CPU only.)  The oracle's autograd at B = 4 x T = 1000 ragged (the inputs of tests/test_gpu_training.py::size_case) is evaluated with the
-forward's q, k, v replaced -- straight through, as oracle.attention(subst=...) does -- by their f16 roundings: all three (what the native
-training path does), q and k only, v only.  The q / k-exact row is what split-precision q / k operands in the TRAINING kernels would leave;
-they are built for inference only (attention.hip), this is the estimate of what building them for training would buy.
+"""Which 16-bit operand carries the end-to-end error of the conv_q / conv_k weight gradients at config-5 frame counts?  (Round 6; CPU only.)
+The oracle's autograd at B = 4 x T = 1000 ragged (the inputs of tests/test_gpu_training.py::size_case) is evaluated with one rounding at a time,
+straight through (oracle.attention(subst=...) for q, k, v; a patched oracle.mha for the projections' input h1 and weights), each against the
+un-rounded autograd:
+    q, k, v rounded to f16 (the native path through round 5)   1.8e-1        q, k rounded, v exact   1.2e-3
+    q, k exact, v rounded                                      1.8e-1        h1 rounded              1.1e-1        projection weights rounded   1.0e-3
+-> split-precision q / k operands (built for inference, attention.hip) would buy nothing in training; v's 16-bit error does the damage, its own
+rounding and the one it inherits from h1.  The training forward therefore computes v = W_v (h_hi + h_lo) and keeps it as a hi + lo operand pair
+(ST_TRAIN_VLO, csrc/engine_train.cpp): 2.5e-1 -> 2.9e-2 on the hardware (profiles/r06_v_hi_lo_training.txt).
     python tools/train_qk_split_estimate.py"""
 import os
 import sys
