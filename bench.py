@@ -309,7 +309,7 @@ CLASS_KERNEL = {
     "ffn_conv1": "conv_gemm_phased3_kernel<st::Op{DT}, 0, false>",
     "ffn_conv2": "ffn_fused_kernel<st::Op{DT}, 0, 0>",        # the whole FFN since round 4 (conv_1 + SiLU + conv_2 in one launch); f16: CLASS_KERNEL_F16
     "lsc_conv": "conv_gemm_phased3_kernel<st::Op{DT}, 1, true>",
-    "attention": "attention_kernel<st::Op{DT}, false>",
+    "attention": "attention_kernel<st::Op{DT}, false, false",   # (inference, single-operand scores; prefix: the template has grown parameters)
     "qkv_rope": "qkv_ws_kernel<st::Op{DT}, 0>",               # weight-stationary persistent kernel (qkv_ws.hip)
     "out_proj": "oproj_ws_kernel<st::Op{DT}>",                # weight-stationary persistent kernel (oproj_ws.hip)
 }

@@ -27,7 +27,7 @@ def traffic(pattern):
     raise KeyError(pattern)
 
 
-ffn, att, opj, qkv, lsc = (kstat(k) for k in ("ffn_fused_kernel", "attention_kernel<st::OpF16, false, false>", "oproj_ws_kernel", "qkv_ws_kernel",
+ffn, att, opj, qkv, lsc = (kstat(k) for k in ("ffn_fused_kernel", "attention_kernel<st::OpF16, false, false", "oproj_ws_kernel", "qkv_ws_kernel",
                                                "conv_gemm_phased3_kernel<st::OpF16, 1, true>"))
 rg, tr = j["ragged"], j["train_step"]
 b64 = "see profiles/r06_pytest_gpu_final.log"
